@@ -1,0 +1,95 @@
+"""ctypes binding of libgist_hip.so (C ABI declared in include/gist_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to
+load, importing a compute path raises GistLibraryError -- loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgist_hip.so')
+
+ABI_VERSION = 1
+
+
+class GistLibraryError(RuntimeError):
+    pass
+
+
+class GistError(RuntimeError):
+    """A gist_* entry point returned a negative code."""
+
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_int = ctypes.c_int
+_f = ctypes.c_float
+_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); mirrors include/gist_hip.h one to one
+SIGNATURES = {
+    'gist_last_error': (ctypes.c_char_p, []),
+    'gist_abi_version': (_int, []),
+    'gist_device_count': (_int, []),
+    'gist_in_degree_norm_f32': (_int, [_p, _i64, _p, _p]),
+    'gist_spmm_csr_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p]),
+    'gist_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'gist_gemm_nt_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    'gist_gemm_nn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    'gist_gemm_tn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    'gist_ln_relu_fwd_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _f, _p]),
+    'gist_ln_relu_bwd_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
+    'gist_dropout_f32': (_int, [_p, _i64, _i64, _i64, _f, _u64, _u64, _p]),
+    'gist_colsum_partials': (_i64, [_i64]),
+    'gist_colsum_f32': (_int, [_p, _i64, _i64, _i64, _p, _p, _p]),
+    'gist_softmax_xent_f32': (_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p]),
+    'gist_adam_f32': (_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p]),
+    'gist_argmax_correct_i32': (_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p]),
+    'gist_induced_mark': (_int, [_p, _i64, _p, _p]),
+    'gist_induced_unmark': (_int, [_p, _i64, _p, _p]),
+    'gist_fill_i32': (_int, [_p, _i64, _i32, _p]),
+    'gist_induced_rowptr': (_int, [_p, _p, _p, _i64, _p, _p, _p]),
+    'gist_induced_fill': (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    'gist_gather_rows_f32': (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p]),
+    'gist_gather_i32': (_int, [_p, _p, _i64, _p, _p]),
+    'gist_block_gather_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
+    'gist_block_scatter_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
+    'gist_mean_rows_f32': (_int, [_p, _i64, _i64, _i64, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgist_hip.so once; raise GistLibraryError if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GistLibraryError(
+            'gist_amd: %s is missing. Build it with `python gist_amd/build.py` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise GistLibraryError('gist_amd: cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise GistLibraryError('gist_amd: %s does not export %s (stale build?)'
+                                   % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gist_abi_version() != ABI_VERSION:
+        raise GistLibraryError('gist_amd: ABI version mismatch: library %d, binding %d'
+                               % (lib.gist_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = load().gist_last_error()
+        raise GistError('%s failed (%d): %s' % (name, rc, msg.decode() if msg else ''))

@@ -1,0 +1,49 @@
+"""Build libgist_hip.so (the C-ABI HIP library, include/gist_hip.h) for gfx950.
+
+hipcc cross-compiles without a GPU.  The .so is built IN-TREE
+(gist_amd/libgist_hip.so) so it travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libgist_hip.so')
+SOURCES = ['capi.hip', 'spmm.hip', 'gemm.hip', 'rowops.hip', 'subgraph.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
+         '-Wno-unused-function', '-fno-gpu-rdc']
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'gist_hip.h')]
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on %s' % s)
+    if procs or not os.path.exists(OUT):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

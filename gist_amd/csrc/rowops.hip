@@ -1,0 +1,452 @@
+// Row-wise (HBM-bound) pieces of one ISTSAGELayer step on gfx950:
+// LayerNorm(no affine)+ReLU forward/backward, dropout, bias gradient (column sum),
+// softmax cross-entropy, Adam, argmax accuracy.  Reference lines are cited at the
+// C-ABI declarations in include/gist_hip.h.
+//
+// Each kernel streams its rows once or twice with 16-B accesses where alignment
+// allows; rows are owned by one wave (d <= 1024) or one 256-thread workgroup.
+#include "common.h"
+
+namespace gist {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Sum over the TPR threads that own one row (TPR = 64: a wave; TPR = 256: the block).
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float *red) {
+    v = wave_sum(v);
+    if constexpr (TPR == 64) {
+        return v;
+    } else {
+        const int w = threadIdx.x >> 6;
+        __syncthreads();                      // red[] may still be read from a previous call
+        if ((threadIdx.x & 63) == 0) red[w] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm (no affine, biased variance) + ReLU, forward.  y <- yhat in place.
+// ---------------------------------------------------------------------------
+template <int TPR, int VEC>
+__global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y, int64_t ldy,
+                                                          float *__restrict__ out, int64_t ldo,
+                                                          float *__restrict__ rstd_out,
+                                                          int n_rows, int d, int use_lynorm,
+                                                          int relu, float eps) {
+    __shared__ float red[4];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < n_rows;
+    float *yr = y + (int64_t)(live ? row : 0) * ldy;
+    float *orow = out + (int64_t)(live ? row : 0) * ldo;
+    float mean = 0.f, rstd = 1.f;
+    if (use_lynorm) {
+        float s = 0.f;
+        if (live)
+            for (int c = t * VEC; c < d; c += TPR * VEC) {
+                if constexpr (VEC == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(yr + c);
+                    s += (v.x + v.y) + (v.z + v.w);
+                } else {
+                    s += yr[c];
+                }
+            }
+        mean = row_sum<TPR>(s, red) / (float)d;
+        float q = 0.f;
+        if (live)
+            for (int c = t * VEC; c < d; c += TPR * VEC) {
+                if constexpr (VEC == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(yr + c);
+                    const float a = v.x - mean, b = v.y - mean, e = v.z - mean, f = v.w - mean;
+                    q += (a * a + b * b) + (e * e + f * f);
+                } else {
+                    const float a = yr[c] - mean;
+                    q += a * a;
+                }
+            }
+        const float var = row_sum<TPR>(q, red) / (float)d;
+        rstd = 1.0f / sqrtf(var + eps);
+        if (live && t == 0 && rstd_out) rstd_out[row] = rstd;
+    }
+    if (!live) return;
+    for (int c = t * VEC; c < d; c += TPR * VEC) {
+        if constexpr (VEC == 4) {
+            float4 v = *reinterpret_cast<const float4 *>(yr + c);
+            v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd;
+            v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+            if (use_lynorm) *reinterpret_cast<float4 *>(yr + c) = v;
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(orow + c) = v;
+        } else {
+            float v = (yr[c] - mean) * rstd;
+            if (use_lynorm) yr[c] = v;
+            if (relu) v = fmaxf(v, 0.f);
+            orow[c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: g = d_out * [yhat > 0]; dy = rstd * (g - mean(g) - yhat * mean(g*yhat))
+// ---------------------------------------------------------------------------
+template <int TPR, int VEC>
+__global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
+    const float *__restrict__ d_out, int64_t ldg, const float *yhat, int64_t ldy,
+    const float *__restrict__ rstd_in, float *dy, int64_t lddy, int n_rows, int d,
+    int use_lynorm, int relu) {
+    __shared__ float red[4];
+    constexpr int RPB = 256 / TPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    const bool live = row < n_rows;
+    const float *gr = d_out + (int64_t)(live ? row : 0) * ldg;
+    const float *yr = yhat + (int64_t)(live ? row : 0) * ldy;
+    float *dr = dy + (int64_t)(live ? row : 0) * lddy;
+    float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+    if (use_lynorm) {
+        float s1 = 0.f, s2 = 0.f;
+        if (live)
+            for (int c = t * VEC; c < d; c += TPR * VEC) {
+                if constexpr (VEC == 4) {
+                    const float4 g = *reinterpret_cast<const float4 *>(gr + c);
+                    const float4 yv = *reinterpret_cast<const float4 *>(yr + c);
+                    const float g0 = (!relu || yv.x > 0.f) ? g.x : 0.f;
+                    const float g1 = (!relu || yv.y > 0.f) ? g.y : 0.f;
+                    const float g2 = (!relu || yv.z > 0.f) ? g.z : 0.f;
+                    const float g3 = (!relu || yv.w > 0.f) ? g.w : 0.f;
+                    s1 += (g0 + g1) + (g2 + g3);
+                    s2 += (g0 * yv.x + g1 * yv.y) + (g2 * yv.z + g3 * yv.w);
+                } else {
+                    const float yv = yr[c];
+                    const float g = (!relu || yv > 0.f) ? gr[c] : 0.f;
+                    s1 += g;
+                    s2 += g * yv;
+                }
+            }
+        m1 = row_sum<TPR>(s1, red) / (float)d;
+        m2 = row_sum<TPR>(s2, red) / (float)d;
+        if (live) rstd = rstd_in[row];
+    }
+    if (!live) return;
+    for (int c = t * VEC; c < d; c += TPR * VEC) {
+        if constexpr (VEC == 4) {
+            const float4 g = *reinterpret_cast<const float4 *>(gr + c);
+            const float4 yv = *reinterpret_cast<const float4 *>(yr + c);
+            float4 o;
+            o.x = (!relu || yv.x > 0.f) ? g.x : 0.f;
+            o.y = (!relu || yv.y > 0.f) ? g.y : 0.f;
+            o.z = (!relu || yv.z > 0.f) ? g.z : 0.f;
+            o.w = (!relu || yv.w > 0.f) ? g.w : 0.f;
+            if (use_lynorm) {
+                o.x = rstd * (o.x - m1 - yv.x * m2); o.y = rstd * (o.y - m1 - yv.y * m2);
+                o.z = rstd * (o.z - m1 - yv.z * m2); o.w = rstd * (o.w - m1 - yv.w * m2);
+            }
+            *reinterpret_cast<float4 *>(dr + c) = o;
+        } else {
+            const float yv = yr[c];
+            float o = (!relu || yv > 0.f) ? gr[c] : 0.f;
+            if (use_lynorm) o = rstd * (o - m1 - yv * m2);
+            dr[c] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dropout: counter based (splitmix64 finaliser of seed-mixed element index)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// One hash serves two consecutive elements (even index -> low word, odd -> high word).
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float scale) {
+    const uint64_t h = splitmix64((idx >> 1) + seed * 0x9E3779B97F4A7C15ULL);
+    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+    const float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? scale : 0.f;
+}
+
+__global__ void dropout_kernel(float *__restrict__ z, int64_t ldz, int64_t n_rows, int64_t d,
+                               float p, float scale, uint64_t seed, uint64_t offset) {
+    const int64_t total = n_rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d, c = i - r * d;
+        float *q = z + r * ldz + c;
+        *q = *q * keep_scale(seed, offset + (uint64_t)i, p, scale);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// column sum (bias gradient), two deterministic stages
+// ---------------------------------------------------------------------------
+constexpr int kColsumRows = 128;
+
+__global__ void colsum_stage1_kernel(const float *__restrict__ g, int64_t ldg, int n_rows, int d,
+                                     float *__restrict__ partials) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const int r0 = blockIdx.y * kColsumRows;
+    const int r1 = min(n_rows, r0 + kColsumRows);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += g[(int64_t)r * ldg + c];
+    partials[(int64_t)blockIdx.y * d + c] = s;
+}
+
+__global__ void colsum_stage2_kernel(const float *__restrict__ partials, int chunks, int d,
+                                     float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partials[(int64_t)k * d + c];
+    out[c] = s;
+}
+
+// ---------------------------------------------------------------------------
+// softmax cross entropy (mean over masked rows) + gradient; one wave per row
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void xent_grad_kernel(
+    const float *__restrict__ logits, int64_t ldl, const int32_t *__restrict__ labels,
+    const uint8_t *__restrict__ mask, float inv_count, float *__restrict__ d_logits, int64_t ldg,
+    float *__restrict__ row_nll, int n_rows, int n_classes) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *lr = logits + (int64_t)row * ldl;
+    float *gr = d_logits + (int64_t)row * ldg;
+    const bool on = mask ? mask[row] != 0 : true;
+    float mx = -INFINITY;
+    for (int c = lane; c < n_classes; c += 64) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < n_classes; c += 64) se += expf(lr[c] - mx);
+    se = wave_sum(se);
+    const int lab = labels[row];
+    const float inv = 1.f / se;
+    for (int c = lane; c < ldg; c += 64) {
+        float gval = 0.f;
+        if (on && c < n_classes) gval = (expf(lr[c] - mx) * inv - (c == lab ? 1.f : 0.f)) * inv_count;
+        gr[c] = gval;
+    }
+    if (lane == 0) row_nll[row] = on ? -((lr[lab] - mx) - logf(se)) : 0.f;
+}
+
+// loss = inv_count * sum_i row_nll[i], fixed-order tree (deterministic)
+__global__ __launch_bounds__(1024) void xent_loss_kernel(const float *__restrict__ row_nll,
+                                                         int n_rows, float inv_count,
+                                                         float *__restrict__ loss) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_rows; i += 1024) s += row_nll[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = t * inv_count;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics, coupled weight decay) over a flat arena
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                            float *__restrict__ m, float *__restrict__ v, int64_t n, float beta1,
+                            float beta2, float eps, float wd, float step_size,
+                            float inv_bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        float gv = g[i];
+        if (wd != 0.f) gv = fmaf(wd, pv, gv);
+        const float mv = m[i] + (1.f - beta1) * (gv - m[i]);        // lerp_ like torch
+        const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
+        p[i] = pv - step_size * (mv / denom);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// accuracy: first-max argmax like numpy; integer atomics => deterministic
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_correct_kernel(
+    const float *__restrict__ logits, int64_t ldl, const int32_t *__restrict__ labels,
+    const uint8_t *__restrict__ mask, int32_t *__restrict__ correct, int n_rows, int n_classes) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    if (mask && !mask[row]) return;
+    const int lane = threadIdx.x & 63;
+    const float *lr = logits + (int64_t)row * ldl;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = lane; c < n_classes; c += 64) {
+        const float v = lr[c];
+        if (v > best) { best = v; arg = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oa = __shfl_xor(arg, off);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0 && arg == labels[row]) atomicAdd(correct, 1);
+}
+
+}  // namespace gist
+
+// ===========================================================================
+using namespace gist;
+
+extern "C" int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t ldo, float *rstd,
+                                    int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                    float eps, gist_stream_t stream) {
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_ln_relu_fwd_f32: negative size");
+    if (n_rows == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(y && out, "gist_ln_relu_fwd_f32: null pointer");
+    GIST_REQUIRE(!use_lynorm || rstd, "gist_ln_relu_fwd_f32: rstd is NULL with use_lynorm");
+    GIST_REQUIRE(ldy >= d && ldo >= d, "gist_ln_relu_fwd_f32: leading dimension < d");
+    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_ln_relu_fwd_f32: size >= 2^31");
+    const bool v4 = d % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out);
+    hipStream_t st = as_stream(stream);
+    const bool wide = d > 1024;
+    const unsigned grid = (unsigned)(wide ? n_rows : ceil_div(n_rows, 4));
+#define L(TPR, V)                                                                              \
+    hipLaunchKernelGGL((ln_relu_fwd_kernel<TPR, V>), dim3(grid), dim3(256), 0, st, y, ldy, out, \
+                       ldo, rstd, (int)n_rows, (int)d, use_lynorm, relu, eps)
+    if (wide) { if (v4) L(256, 4); else L(256, 1); }
+    else { if (v4) L(64, 4); else L(64, 1); }
+#undef L
+    return launch_status("gist_ln_relu_fwd_f32");
+}
+
+extern "C" int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float *yhat,
+                                    int64_t ldy, const float *rstd, float *dy, int64_t lddy,
+                                    int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                    gist_stream_t stream) {
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_ln_relu_bwd_f32: negative size");
+    if (n_rows == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(d_out && yhat && dy, "gist_ln_relu_bwd_f32: null pointer");
+    GIST_REQUIRE(!use_lynorm || rstd, "gist_ln_relu_bwd_f32: rstd is NULL with use_lynorm");
+    GIST_REQUIRE(ldg >= d && ldy >= d && lddy >= d, "gist_ln_relu_bwd_f32: leading dimension < d");
+    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_ln_relu_bwd_f32: size >= 2^31");
+    const bool v4 = d % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 &&
+                    aligned16(d_out) && aligned16(yhat) && aligned16(dy);
+    hipStream_t st = as_stream(stream);
+    const bool wide = d > 1024;
+    const unsigned grid = (unsigned)(wide ? n_rows : ceil_div(n_rows, 4));
+#define L(TPR, V)                                                                               \
+    hipLaunchKernelGGL((ln_relu_bwd_kernel<TPR, V>), dim3(grid), dim3(256), 0, st, d_out, ldg,   \
+                       yhat, ldy, rstd, dy, lddy, (int)n_rows, (int)d, use_lynorm, relu)
+    if (wide) { if (v4) L(256, 4); else L(256, 1); }
+    else { if (v4) L(64, 4); else L(64, 1); }
+#undef L
+    return launch_status("gist_ln_relu_bwd_f32");
+}
+
+extern "C" int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d, float p,
+                                uint64_t seed, uint64_t offset, gist_stream_t stream) {
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_dropout_f32: negative size");
+    GIST_REQUIRE(p >= 0.f && p < 1.f, "gist_dropout_f32: p must be in [0,1)");
+    if (n_rows == 0 || d == 0 || p == 0.f) return GIST_OK;
+    GIST_REQUIRE(z && ldz >= d, "gist_dropout_f32: bad buffer");
+    const int64_t total = n_rows * d;
+    const unsigned grid = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(256), 0, as_stream(stream), z, ldz, n_rows,
+                       d, p, 1.0f / (1.0f - p), seed, offset);
+    return launch_status("gist_dropout_f32");
+}
+
+extern "C" int64_t gist_colsum_partials(int64_t n_rows) {
+    return n_rows <= 0 ? 0 : ceil_div(n_rows, kColsumRows);
+}
+
+extern "C" int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int64_t d,
+                               float *partials, float *out, gist_stream_t stream) {
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_colsum_f32: negative size");
+    if (d == 0) return GIST_OK;
+    GIST_REQUIRE(out, "gist_colsum_f32: null output");
+    hipStream_t st = as_stream(stream);
+    const int chunks = (int)gist_colsum_partials(n_rows);
+    if (chunks > 0) {
+        GIST_REQUIRE(g && partials && ldg >= d, "gist_colsum_f32: bad buffer");
+        GIST_REQUIRE(chunks <= 65535, "gist_colsum_f32: too many rows");
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)chunks),
+                           dim3(256), 0, st, g, ldg, (int)n_rows, (int)d, partials);
+    }
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st,
+                       partials, chunks, (int)d, out);
+    return launch_status("gist_colsum_f32");
+}
+
+extern "C" int gist_softmax_xent_f32(const float *logits, int64_t ldl, const int32_t *labels,
+                                     const uint8_t *mask, int64_t count, float *row_loss,
+                                     float *loss, float *d_logits, int64_t ldg, int64_t n_rows,
+                                     int64_t n_classes, gist_stream_t stream) {
+    GIST_REQUIRE(n_rows > 0 && n_classes > 0, "gist_softmax_xent_f32: empty input");
+    GIST_REQUIRE(logits && labels && loss && d_logits && row_loss,
+                 "gist_softmax_xent_f32: null pointer");
+    GIST_REQUIRE(ldl >= n_classes && ldg >= n_classes,
+                 "gist_softmax_xent_f32: leading dimension < n_classes");
+    GIST_REQUIRE(count > 0, "gist_softmax_xent_f32: count must be > 0");
+    GIST_REQUIRE(n_rows < (1LL << 31) && ldg < (1LL << 31), "gist_softmax_xent_f32: size >= 2^31");
+    hipStream_t st = as_stream(stream);
+    const float inv = 1.0f / (float)count;
+    hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st,
+                       logits, ldl, labels, mask, inv, d_logits, ldg, row_loss, (int)n_rows,
+                       (int)n_classes);
+    hipLaunchKernelGGL(xent_loss_kernel, dim3(1), dim3(1024), 0, st, row_loss, (int)n_rows, inv,
+                       loss);
+    return launch_status("gist_softmax_xent_f32");
+}
+
+extern "C" int gist_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                             int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, gist_stream_t stream) {
+    GIST_REQUIRE(n >= 0, "gist_adam_f32: n < 0");
+    if (n == 0) return GIST_OK;
+    GIST_REQUIRE(param && grad && exp_avg && exp_avg_sq, "gist_adam_f32: null pointer");
+    GIST_REQUIRE(step >= 1, "gist_adam_f32: step is 1-based");
+    // bias corrections in double on the host, like torch's python scalar math
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 16384 ? ceil_div(n, 256) : 16384);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size,
+                       inv_bc2_sqrt);
+    return launch_status("gist_adam_f32");
+}
+
+extern "C" int gist_argmax_correct_i32(const float *logits, int64_t ldl, const int32_t *labels,
+                                       const uint8_t *mask, int32_t *correct, int64_t n_rows,
+                                       int64_t n_classes, gist_stream_t stream) {
+    GIST_REQUIRE(n_rows >= 0 && n_classes > 0, "gist_argmax_correct_i32: bad size");
+    if (n_rows == 0) return GIST_OK;
+    GIST_REQUIRE(logits && labels && correct && ldl >= n_classes,
+                 "gist_argmax_correct_i32: bad buffer");
+    GIST_REQUIRE(n_rows < (1LL << 31), "gist_argmax_correct_i32: size >= 2^31");
+    hipLaunchKernelGGL(argmax_correct_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0,
+                       as_stream(stream), logits, ldl, labels, mask, correct, (int)n_rows,
+                       (int)n_classes);
+    return launch_status("gist_argmax_correct_i32");
+}

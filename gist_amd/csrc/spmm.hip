@@ -1,0 +1,235 @@
+// CSR SpMM neighbour aggregation for gfx950 (MI355X).
+//
+// y[v,:] = (acc ? y[v,:] : 0) + out_scale[v] * sum_e src_scale[col[e]] * x[col[e],:]
+//
+// Replaces g.update_all(fn.copy_src, fn.sum) * norm  (reference
+// cluster_gcn/modules.py:223-226) and its autograd (reverse graph, src_scale).
+//
+// Mapping: one 64-lane wavefront owns one (row, column tile).  The wave reads the
+// row's column indices 64 at a time with one coalesced load, then walks them:
+//   * wide rows (d/VEC >= 64 lanes): every lane holds VEC consecutive floats of the
+//     feature tile; the neighbour id is broadcast with v_readlane (scalar address
+//     math), 4 neighbour rows in flight per lane;
+//   * narrow rows: the wave is split into G = 64/LPR lane groups, group g takes
+//     neighbours g, g+G, ... and the groups are combined by a butterfly
+//     (wavefront segmented reduction), so no lane idles on d = 41..128.
+// HBM-bound: per launch the algorithmic traffic is rowptr + col + X once + Y once
+// (DESIGN.md).  Column tiles are dealt to XCDs (blockIdx % 8 shares an L2) so that
+// one tile of X (n_rows x 1 KiB) is gathered out of ONE L2 instead of eight.
+#include "common.h"
+
+namespace gist {
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { using T = float; };
+template <> struct Vec<2> { using T = float2; };
+template <> struct Vec<4> { using T = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float *p, float (&v)[VEC]) {
+    using T = typename Vec<VEC>::T;
+    T t = *reinterpret_cast<const T *>(p);
+    if constexpr (VEC == 1) { v[0] = t; }
+    if constexpr (VEC == 2) { v[0] = t.x; v[1] = t.y; }
+    if constexpr (VEC == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float *p, const float (&v)[VEC]) {
+    using T = typename Vec<VEC>::T;
+    T t;
+    if constexpr (VEC == 1) { t = v[0]; }
+    if constexpr (VEC == 2) { t.x = v[0]; t.y = v[1]; }
+    if constexpr (VEC == 4) { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
+    *reinterpret_cast<T *>(p) = t;
+}
+
+constexpr int kSpmmWavesPerBlock = 4;
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
+    int n_rows, int d, const float *__restrict__ out_scale,
+    const float *__restrict__ src_scale, int accumulate, int n_row_blocks,
+    int n_col_tiles, int xcd_tiles) {
+    constexpr int G = kWave / LPR;
+    // ---- block -> (row block, column tile) -------------------------------
+    int rb, ct;
+    const int b = blockIdx.x;
+    if (xcd_tiles) {  // tiles dealt to XCDs: blocks b, b+8, b+16.. share an L2
+        const int xcd = b & 7, i = b >> 3;
+        ct = xcd + 8 * (i / n_row_blocks);
+        rb = i % n_row_blocks;
+        if (ct >= n_col_tiles) return;
+    } else {
+        rb = b / n_col_tiles;
+        ct = b % n_col_tiles;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = rb * kSpmmWavesPerBlock + wave;
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int c0 = (ct * LPR + sub) * VEC;
+    const bool active = c0 < d;
+
+    const int beg = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+
+    const float *xc = x + c0;
+    for (int base = beg; base < end; base += kWave) {
+        const int e = base + lane;
+        const int my = (e < end) ? col[e] : 0;
+        float mys = 1.f;
+        if (src_scale) mys = (e < end) ? src_scale[my] : 0.f;
+        const int cnt = min(kWave, end - base);
+        if constexpr (G == 1) {
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {
+                float v[4][VEC];
+                float s[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int u = __builtin_amdgcn_readlane(my, j + t);
+                    s[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                          __builtin_bit_cast(int, mys), j + t));
+                    if (active) vload<VEC>(xc + (int64_t)u * ldx, v[t]);
+                }
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(s[t], v[t][k], acc[k]);
+                }
+            }
+            for (; j < cnt; ++j) {
+                const int u = __builtin_amdgcn_readlane(my, j);
+                const float s = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mys), j));
+                if (active) {
+                    float v[VEC];
+                    vload<VEC>(xc + (int64_t)u * ldx, v);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(s, v[k], acc[k]);
+                }
+            }
+        } else {
+            // group g handles neighbours g, g+G, ...; two in flight per lane.  The trip
+            // count is wave-uniform so every lane is live at each cross-lane read.
+            const int iters = (cnt + 2 * G - 1) / (2 * G);
+            for (int t = 0; t < iters; ++t) {
+                const int j = grp + t * 2 * G, j2 = j + G;
+                const bool p0 = j < cnt, p1 = j2 < cnt;
+                const int u0 = __shfl(my, p0 ? j : 0), u1 = __shfl(my, p1 ? j2 : 0);
+                const float t0 = __shfl(mys, p0 ? j : 0), t1 = __shfl(mys, p1 ? j2 : 0);
+                const float s0 = p0 ? t0 : 0.f, s1 = p1 ? t1 : 0.f;
+                if (active) {
+                    float v0[VEC], v1[VEC];
+                    vload<VEC>(xc + (int64_t)u0 * ldx, v0);
+                    vload<VEC>(xc + (int64_t)u1 * ldx, v1);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(s0, v0[k], acc[k]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(s1, v1[k], acc[k]);
+                }
+            }
+        }
+    }
+    if constexpr (G > 1) {  // butterfly across the lane groups
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+    }
+    if (active && grp == 0) {
+        const float os = out_scale ? out_scale[row] : 1.f;
+        float *yp = y + (int64_t)row * ldy + c0;
+        float o[VEC];
+        if (accumulate) {
+            vload<VEC>(yp, o);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = fmaf(os, acc[k], o[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
+        }
+        vstore<VEC>(yp, o);
+    }
+}
+
+__global__ void in_degree_norm_kernel(const int32_t *__restrict__ rowptr, int64_t n,
+                                      float *__restrict__ norm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int deg = rowptr[i + 1] - rowptr[i];
+        norm[i] = deg > 0 ? 1.f / (float)deg : 0.f;
+    }
+}
+
+template <int VEC>
+static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
+                       float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
+                       const float *src_scale, int accumulate, hipStream_t st) {
+    const int lanes = (int)ceil_div(d, VEC);
+    int lpr = 8;
+    while (lpr < 64 && lpr < lanes) lpr <<= 1;
+    const int n_col_tiles = (int)ceil_div(lanes, lpr);
+    const int n_row_blocks = (int)ceil_div(n_rows, kSpmmWavesPerBlock);
+    const int xcd_tiles = n_col_tiles >= 8 ? 1 : 0;
+    const int64_t grid = xcd_tiles ? (int64_t)8 * ceil_div(n_col_tiles, 8) * n_row_blocks
+                                   : (int64_t)n_row_blocks * n_col_tiles;
+    if (grid > 0x7fffffffLL) {
+        set_error("gist_spmm_csr_f32: grid too large");
+        return GIST_EINVAL;
+    }
+#define GIST_SPMM_LAUNCH(L)                                                                   \
+    hipLaunchKernelGGL((spmm_csr_kernel<VEC, L>), dim3((unsigned)grid), dim3(256), 0, st,     \
+                       rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,           \
+                       src_scale, accumulate, n_row_blocks, n_col_tiles, xcd_tiles)
+    switch (lpr) {
+        case 8: GIST_SPMM_LAUNCH(8); break;
+        case 16: GIST_SPMM_LAUNCH(16); break;
+        case 32: GIST_SPMM_LAUNCH(32); break;
+        default: GIST_SPMM_LAUNCH(64); break;
+    }
+#undef GIST_SPMM_LAUNCH
+    return launch_status("gist_spmm_csr_f32");
+}
+
+}  // namespace gist
+
+extern "C" int gist_in_degree_norm_f32(const int32_t *rowptr, int64_t n_rows, float *norm,
+                                       gist_stream_t stream) {
+    GIST_REQUIRE(n_rows >= 0, "gist_in_degree_norm_f32: n_rows < 0");
+    if (n_rows == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && norm, "gist_in_degree_norm_f32: null pointer");
+    hipLaunchKernelGGL(gist::in_degree_norm_kernel, dim3((unsigned)gist::ceil_div(n_rows, 256)),
+                       dim3(256), 0, gist::as_stream(stream), rowptr, n_rows, norm);
+    return gist::launch_status("gist_in_degree_norm_f32");
+}
+
+extern "C" int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *x,
+                                 int64_t ldx, float *y, int64_t ldy, int64_t n_rows, int64_t d,
+                                 const float *out_scale, const float *src_scale, int accumulate,
+                                 gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_spmm_csr_f32: negative size");
+    if (n_rows == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && x && y, "gist_spmm_csr_f32: null pointer");
+    GIST_REQUIRE(ldx >= d && ldy >= d, "gist_spmm_csr_f32: leading dimension < d");
+    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_spmm_csr_f32: size >= 2^31");
+    hipStream_t st = as_stream(stream);
+    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
+        return launch_spmm<4>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                              accumulate, st);
+    if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y))
+        return launch_spmm<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                              accumulate, st);
+    return launch_spmm<1>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                          accumulate, st);
+}

@@ -1,0 +1,288 @@
+// Device-resident cluster batch extraction and IST weight-block movement (gfx950).
+//
+// Node-induced subgraph of a union of METIS parts (reference:
+// cluster_gcn/partition_utils.py:20-25 -> DGL g.subgraph on the CPU, followed by an
+// H2D copy every iteration, cluster_gcn_ist_distrib.py:409).  Here the training
+// graph stays in HBM and one wavefront filters one adjacency row:
+//   mark      remap[ids[i]] = i
+//   rowptr    per row: count neighbours with remap >= 0 (ballot + popcount), then an
+//             exclusive scan (single workgroup; a batch has ~2k rows)
+//   fill      per row: compact the kept neighbours in their original order
+//             (ballot prefix), relabelled through remap
+// Integer work, bit exact against the oracle.  Bound: HBM/L2 reads of the selected
+// adjacency rows, 2 x 4 B per full-graph edge of the batch rows.
+#include "common.h"
+
+namespace gist {
+
+__global__ void mark_kernel(const int32_t *__restrict__ ids, int64_t n, int32_t *__restrict__ remap,
+                            int unmark) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) remap[ids[i]] = unmark ? -1 : (int32_t)i;
+}
+
+__global__ void fill_i32_kernel(int32_t *__restrict__ p, int64_t n, int32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+// deg[i] -> out[i + 1]
+__global__ __launch_bounds__(256) void induced_count_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ ids, int n_ids, const int32_t *__restrict__ remap,
+    int32_t *__restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const int v = ids[i];
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    int cnt = 0;
+    for (int base = beg; base < end; base += kWave) {
+        const int e = base + lane;
+        const bool keep = (e < end) && (remap[col[e]] >= 0);
+        cnt += __popcll(__ballot(keep));
+    }
+    if (lane == 0) out[i + 1] = cnt;
+}
+
+// In-place inclusive scan of p[1..n] (p[0] = 0) by ONE workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void scan_rowptr_kernel(int32_t *__restrict__ p, int n) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) { p[0] = 0; carry_s = 0; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + t;
+        int v = (i < n) ? p[i + 1] : 0;
+        // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(v, off);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int pre = carry_s;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (i < n) p[i + 1] = v + pre;
+        __syncthreads();
+        if (t == 1023) carry_s = v + pre;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void induced_fill_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ ids, int n_ids, const int32_t *__restrict__ remap,
+    const int32_t *__restrict__ sub_rowptr, int32_t *__restrict__ sub_col, int64_t capacity) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const int v = ids[i];
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    int64_t w = sub_rowptr[i];
+    for (int base = beg; base < end; base += kWave) {
+        const int e = base + lane;
+        int r = -1;
+        if (e < end) r = remap[col[e]];
+        const unsigned long long m = __ballot(r >= 0);
+        if (r >= 0) {
+            const int64_t pos = w + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < capacity) sub_col[pos] = r;
+        }
+        w += __popcll(m);
+    }
+}
+
+// dst[i, :] = src[ids[i], :]; one wave per row
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src,
+                                                          int64_t lds_,
+                                                          const int32_t *__restrict__ ids,
+                                                          int n_ids, int d,
+                                                          float *__restrict__ dst, int64_t ldd) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const float *s = src + (int64_t)ids[i] * lds_;
+    float *o = dst + (int64_t)i * ldd;
+    for (int c = lane * VEC; c < d; c += kWave * VEC) {
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + c) = *reinterpret_cast<const float4 *>(s + c);
+        else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o + c) = *reinterpret_cast<const float2 *>(s + c);
+        else o[c] = s[c];
+    }
+}
+
+__global__ void gather_i32_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ ids,
+                                  int64_t n, int32_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[ids[i]];
+}
+
+// ---- IST weight blocks ---------------------------------------------------------
+// One workgroup row-strip: blockIdx.y = block row, threads sweep the columns, so the
+// contiguous side (dst for gather, src for scatter) is accessed with full lines.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void block_move_kernel(const float *__restrict__ src,
+                                                         int64_t lds_,
+                                                         const int32_t *__restrict__ row_idx,
+                                                         const int32_t *__restrict__ col_idx,
+                                                         int n_rows, int n_cols,
+                                                         float *__restrict__ dst, int64_t ldd) {
+    for (int i = blockIdx.y; i < n_rows; i += gridDim.y) {
+        const int ri = row_idx ? row_idx[i] : i;
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols;
+             j += gridDim.x * blockDim.x) {
+            const int cj = col_idx ? col_idx[j] : j;
+            if constexpr (SCATTER) dst[(int64_t)ri * ldd + cj] = src[(int64_t)i * lds_ + j];
+            else dst[(int64_t)i * ldd + j] = src[(int64_t)ri * lds_ + cj];
+        }
+    }
+}
+
+__global__ void mean_rows_kernel(const float *__restrict__ src, int64_t stride, int n_src, int64_t n,
+                                 float *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < n_src; ++k) s += src[(int64_t)k * stride + j];
+    out[j] = s / (float)n_src;
+}
+
+}  // namespace gist
+
+using namespace gist;
+
+static int mark_impl(const char *name, const int32_t *ids, int64_t n_ids, int32_t *remap, int unmark,
+                     gist_stream_t stream) {
+    if (n_ids < 0) { set_error("%s: n_ids < 0", name); return GIST_EINVAL; }
+    if (n_ids == 0) return GIST_OK;
+    if (!ids || !remap) { set_error("%s: null pointer", name); return GIST_EINVAL; }
+    hipLaunchKernelGGL(mark_kernel, dim3((unsigned)ceil_div(n_ids, 256)), dim3(256), 0,
+                       as_stream(stream), ids, n_ids, remap, unmark);
+    return launch_status(name);
+}
+
+extern "C" int gist_induced_mark(const int32_t *ids, int64_t n_ids, int32_t *remap,
+                                 gist_stream_t stream) {
+    return mark_impl("gist_induced_mark", ids, n_ids, remap, 0, stream);
+}
+
+extern "C" int gist_induced_unmark(const int32_t *ids, int64_t n_ids, int32_t *remap,
+                                   gist_stream_t stream) {
+    return mark_impl("gist_induced_unmark", ids, n_ids, remap, 1, stream);
+}
+
+extern "C" int gist_fill_i32(int32_t *p, int64_t n, int32_t value, gist_stream_t stream) {
+    GIST_REQUIRE(n >= 0, "gist_fill_i32: n < 0");
+    if (n == 0) return GIST_OK;
+    GIST_REQUIRE(p, "gist_fill_i32: null pointer");
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid), dim3(256), 0, as_stream(stream), p, n, value);
+    return launch_status("gist_fill_i32");
+}
+
+extern "C" int gist_induced_rowptr(const int32_t *rowptr, const int32_t *col, const int32_t *ids,
+                                   int64_t n_ids, const int32_t *remap, int32_t *sub_rowptr,
+                                   gist_stream_t stream) {
+    GIST_REQUIRE(n_ids >= 0 && n_ids < (1LL << 31) - 8, "gist_induced_rowptr: bad n_ids");
+    GIST_REQUIRE(sub_rowptr, "gist_induced_rowptr: null sub_rowptr");
+    hipStream_t st = as_stream(stream);
+    if (n_ids > 0) {
+        GIST_REQUIRE(rowptr && col && ids && remap, "gist_induced_rowptr: null pointer");
+        hipLaunchKernelGGL(induced_count_kernel, dim3((unsigned)ceil_div(n_ids, 4)), dim3(256), 0, st,
+                           rowptr, col, ids, (int)n_ids, remap, sub_rowptr);
+    }
+    hipLaunchKernelGGL(scan_rowptr_kernel, dim3(1), dim3(1024), 0, st, sub_rowptr, (int)n_ids);
+    return launch_status("gist_induced_rowptr");
+}
+
+extern "C" int gist_induced_fill(const int32_t *rowptr, const int32_t *col, const int32_t *ids,
+                                 int64_t n_ids, const int32_t *remap, const int32_t *sub_rowptr,
+                                 int32_t *sub_col, int64_t sub_col_capacity, gist_stream_t stream) {
+    GIST_REQUIRE(n_ids >= 0 && n_ids < (1LL << 31) - 8, "gist_induced_fill: bad n_ids");
+    GIST_REQUIRE(sub_col_capacity >= 0, "gist_induced_fill: negative capacity");
+    if (n_ids == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && col && ids && remap && sub_rowptr, "gist_induced_fill: null pointer");
+    GIST_REQUIRE(sub_col || sub_col_capacity == 0, "gist_induced_fill: null sub_col");
+    hipLaunchKernelGGL(induced_fill_kernel, dim3((unsigned)ceil_div(n_ids, 4)), dim3(256), 0,
+                       as_stream(stream), rowptr, col, ids, (int)n_ids, remap, sub_rowptr, sub_col,
+                       sub_col_capacity);
+    return launch_status("gist_induced_fill");
+}
+
+extern "C" int gist_gather_rows_f32(const float *src, int64_t lds_, const int32_t *ids,
+                                    int64_t n_ids, int64_t d, float *dst, int64_t ldd,
+                                    gist_stream_t stream) {
+    GIST_REQUIRE(n_ids >= 0 && d >= 0, "gist_gather_rows_f32: negative size");
+    if (n_ids == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(src && ids && dst, "gist_gather_rows_f32: null pointer");
+    GIST_REQUIRE(lds_ >= d && ldd >= d, "gist_gather_rows_f32: leading dimension < d");
+    GIST_REQUIRE(n_ids < (1LL << 31) - 8 && d < (1LL << 31), "gist_gather_rows_f32: size >= 2^31");
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)ceil_div(n_ids, 4));
+    if (d % 4 == 0 && lds_ % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst))
+        hipLaunchKernelGGL(gather_rows_kernel<4>, grid, dim3(256), 0, st, src, lds_, ids, (int)n_ids,
+                           (int)d, dst, ldd);
+    else if (d % 2 == 0 && lds_ % 2 == 0 && ldd % 2 == 0 && aligned8(src) && aligned8(dst))
+        hipLaunchKernelGGL(gather_rows_kernel<2>, grid, dim3(256), 0, st, src, lds_, ids, (int)n_ids,
+                           (int)d, dst, ldd);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<1>, grid, dim3(256), 0, st, src, lds_, ids, (int)n_ids,
+                           (int)d, dst, ldd);
+    return launch_status("gist_gather_rows_f32");
+}
+
+extern "C" int gist_gather_i32(const int32_t *src, const int32_t *ids, int64_t n_ids, int32_t *dst,
+                               gist_stream_t stream) {
+    GIST_REQUIRE(n_ids >= 0, "gist_gather_i32: n_ids < 0");
+    if (n_ids == 0) return GIST_OK;
+    GIST_REQUIRE(src && ids && dst, "gist_gather_i32: null pointer");
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)ceil_div(n_ids, 256)), dim3(256), 0,
+                       as_stream(stream), src, ids, n_ids, dst);
+    return launch_status("gist_gather_i32");
+}
+
+static int block_move(const char *name, bool scatter, const float *src, int64_t lds_,
+                      const int32_t *row_idx, const int32_t *col_idx, int64_t n_rows,
+                      int64_t n_cols, float *dst, int64_t ldd, gist_stream_t stream) {
+    if (n_rows < 0 || n_cols < 0) { set_error("%s: negative size", name); return GIST_EINVAL; }
+    if (n_rows == 0 || n_cols == 0) return GIST_OK;
+    if (!src || !dst) { set_error("%s: null pointer", name); return GIST_EINVAL; }
+    if (n_rows >= (1LL << 31) || n_cols >= (1LL << 31)) { set_error("%s: size >= 2^31", name); return GIST_EINVAL; }
+    const unsigned gx = (unsigned)(ceil_div(n_cols, 256) < 64 ? ceil_div(n_cols, 256) : 64);
+    const unsigned gy = (unsigned)(n_rows < 8192 ? n_rows : 8192);
+    if (scatter)
+        hipLaunchKernelGGL(block_move_kernel<true>, dim3(gx, gy), dim3(256), 0, as_stream(stream), src,
+                           lds_, row_idx, col_idx, (int)n_rows, (int)n_cols, dst, ldd);
+    else
+        hipLaunchKernelGGL(block_move_kernel<false>, dim3(gx, gy), dim3(256), 0, as_stream(stream), src,
+                           lds_, row_idx, col_idx, (int)n_rows, (int)n_cols, dst, ldd);
+    return launch_status(name);
+}
+
+extern "C" int gist_block_gather_f32(const float *src, int64_t lds_, const int32_t *row_idx,
+                                     const int32_t *col_idx, int64_t n_rows, int64_t n_cols,
+                                     float *dst, int64_t ldd, gist_stream_t stream) {
+    return block_move("gist_block_gather_f32", false, src, lds_, row_idx, col_idx, n_rows, n_cols,
+                      dst, ldd, stream);
+}
+
+extern "C" int gist_block_scatter_f32(const float *src, int64_t lds_, const int32_t *row_idx,
+                                      const int32_t *col_idx, int64_t n_rows, int64_t n_cols,
+                                      float *dst, int64_t ldd, gist_stream_t stream) {
+    return block_move("gist_block_scatter_f32", true, src, lds_, row_idx, col_idx, n_rows, n_cols,
+                      dst, ldd, stream);
+}
+
+extern "C" int gist_mean_rows_f32(const float *src, int64_t stride, int64_t n_src, int64_t n,
+                                  float *out, gist_stream_t stream) {
+    GIST_REQUIRE(n_src > 0 && n >= 0, "gist_mean_rows_f32: bad size");
+    if (n == 0) return GIST_OK;
+    GIST_REQUIRE(src && out, "gist_mean_rows_f32: null pointer");
+    hipLaunchKernelGGL(mean_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       as_stream(stream), src, stride, (int)n_src, n, out);
+    return launch_status("gist_mean_rows_f32");
+}

@@ -1,0 +1,327 @@
+"""Tensor-level wrappers over the C ABI (include/gist_hip.h).
+
+torch is used for device memory and streams only: every function takes tensors
+that already live in HBM, checks dtype / device / layout (the TORCH_CHECK role)
+and passes raw pointers to libgist_hip.so on torch's current HIP stream.
+CPU tensors are rejected -- there is no fallback path.
+"""
+import torch
+
+from . import _lib
+
+LN_EPS = 1e-5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype):
+    if not torch.is_tensor(t):
+        raise TypeError('%s must be a tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('gist_amd: %s must live on the GPU (got %s); the HIP path has no '
+                           'CPU fallback' % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError('gist_amd: %s must be %s (got %s)' % (name, dtype, t.dtype))
+    return t
+
+
+def _mat(t, name):
+    """2-D fp32 with unit inner stride -> (ptr, ld)."""
+    _dev(t, name, torch.float32)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError('gist_amd: %s must be 2-D with contiguous rows' % name)
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    return t.data_ptr(), ld
+
+
+def _vec(t, name, dtype, n=None):
+    _dev(t, name, dtype)
+    if not t.is_contiguous():
+        raise ValueError('gist_amd: %s must be contiguous' % name)
+    if n is not None and t.numel() < n:
+        raise ValueError('gist_amd: %s too small (%d < %d)' % (name, t.numel(), n))
+    return t.data_ptr()
+
+
+def _opt(t, name, dtype, n=None):
+    return None if t is None else _vec(t, name, dtype, n)
+
+
+def device_count():
+    return _lib.load().gist_device_count()
+
+
+# -- aggregation ---------------------------------------------------------------
+def in_degree_norm(rowptr, out=None):
+    L = _lib.load()
+    n = rowptr.numel() - 1
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=rowptr.device)
+    _lib.check(L.gist_in_degree_norm_f32(_vec(rowptr, 'rowptr', torch.int32), n,
+                                         _vec(out, 'norm', torch.float32, n), _stream()),
+               'gist_in_degree_norm_f32')
+    return out
+
+
+def spmm(rowptr, col, x, y, out_scale=None, src_scale=None, accumulate=False):
+    """y[v] (+)= out_scale[v] * sum_e src_scale[col[e]] * x[col[e]]; see gist_spmm_csr_f32."""
+    L = _lib.load()
+    n = rowptr.numel() - 1
+    xp, ldx = _mat(x, 'x')
+    yp, ldy = _mat(y, 'y')
+    d = x.shape[1]
+    if y.shape[0] != n or y.shape[1] != d:
+        raise ValueError('gist_amd: spmm output shape %s != (%d, %d)' % (tuple(y.shape), n, d))
+    _lib.check(L.gist_spmm_csr_f32(_vec(rowptr, 'rowptr', torch.int32),
+                                   _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n, d,
+                                   _opt(out_scale, 'out_scale', torch.float32, n),
+                                   _opt(src_scale, 'src_scale', torch.float32, x.shape[0]),
+                                   int(bool(accumulate)), _stream()), 'gist_spmm_csr_f32')
+    return y
+
+
+# -- projection ------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch for split-K partial sums."""
+    key = (device.type, device.index)
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+def _ws_for(m, n, k, device):
+    L = _lib.load()
+    need = L.gist_gemm_workspace_bytes(m, n, k)
+    if need == 0:
+        return None, 0
+    w = workspace(need, device)
+    return w.data_ptr(), w.numel()
+
+
+def gemm_nt(a, w, bias, y):
+    """y = a @ w.T + bias"""
+    L = _lib.load()
+    ap, lda = _mat(a, 'a')
+    wp, ldw = _mat(w, 'w')
+    yp, ldy = _mat(y, 'y')
+    m, k = a.shape
+    n = w.shape[0]
+    if w.shape[1] != k or tuple(y.shape) != (m, n):
+        raise ValueError('gist_amd: gemm_nt shape mismatch')
+    wsp, wsb = _ws_for(m, n, k, a.device)
+    _lib.check(L.gist_gemm_nt_f32(ap, lda, wp, ldw, _opt(bias, 'bias', torch.float32, n), yp, ldy,
+                                  m, n, k, wsp, wsb, _stream()), 'gist_gemm_nt_f32')
+    return y
+
+
+def gemm_nn(g, w, z):
+    """z = g @ w"""
+    L = _lib.load()
+    gp, ldg = _mat(g, 'g')
+    wp, ldw = _mat(w, 'w')
+    zp, ldz = _mat(z, 'z')
+    m, k = g.shape
+    n = w.shape[1]
+    if w.shape[0] != k or tuple(z.shape) != (m, n):
+        raise ValueError('gist_amd: gemm_nn shape mismatch')
+    wsp, wsb = _ws_for(m, n, k, g.device)
+    _lib.check(L.gist_gemm_nn_f32(gp, ldg, wp, ldw, zp, ldz, m, n, k, wsp, wsb, _stream()),
+               'gist_gemm_nn_f32')
+    return z
+
+
+def gemm_tn(g, a, d):
+    """d = g.T @ a"""
+    L = _lib.load()
+    gp, ldg = _mat(g, 'g')
+    ap, lda = _mat(a, 'a')
+    dp, ldd = _mat(d, 'd')
+    k, m = g.shape
+    n = a.shape[1]
+    if a.shape[0] != k or tuple(d.shape) != (m, n):
+        raise ValueError('gist_amd: gemm_tn shape mismatch')
+    wsp, wsb = _ws_for(m, n, k, g.device)
+    _lib.check(L.gist_gemm_tn_f32(gp, ldg, ap, lda, dp, ldd, m, n, k, wsp, wsb, _stream()),
+               'gist_gemm_tn_f32')
+    return d
+
+
+# -- row epilogues -----------------------------------------------------------------
+def ln_relu_fwd(y, out, rstd, use_lynorm, relu, eps=LN_EPS):
+    L = _lib.load()
+    yp, ldy = _mat(y, 'y')
+    op, ldo = _mat(out, 'out')
+    n, d = y.shape
+    if tuple(out.shape) != (n, d):
+        raise ValueError('gist_amd: ln_relu_fwd shape mismatch')
+    _lib.check(L.gist_ln_relu_fwd_f32(yp, ldy, op, ldo, _opt(rstd, 'rstd', torch.float32, n), n, d,
+                                      int(bool(use_lynorm)), int(bool(relu)), eps, _stream()),
+               'gist_ln_relu_fwd_f32')
+    return out
+
+
+def ln_relu_bwd(d_out, yhat, rstd, dy, use_lynorm, relu):
+    L = _lib.load()
+    gp, ldg = _mat(d_out, 'd_out')
+    yp, ldy = _mat(yhat, 'yhat')
+    dp, ldd = _mat(dy, 'dy')
+    n, d = yhat.shape
+    if tuple(d_out.shape) != (n, d) or tuple(dy.shape) != (n, d):
+        raise ValueError('gist_amd: ln_relu_bwd shape mismatch')
+    _lib.check(L.gist_ln_relu_bwd_f32(gp, ldg, yp, ldy, _opt(rstd, 'rstd', torch.float32, n), dp,
+                                      ldd, n, d, int(bool(use_lynorm)), int(bool(relu)), _stream()),
+               'gist_ln_relu_bwd_f32')
+    return dy
+
+
+def dropout_(z, p, seed, offset):
+    L = _lib.load()
+    zp, ldz = _mat(z, 'z')
+    _lib.check(L.gist_dropout_f32(zp, ldz, z.shape[0], z.shape[1], float(p), int(seed),
+                                  int(offset), _stream()), 'gist_dropout_f32')
+    return z
+
+
+def colsum(g, out, partials=None):
+    L = _lib.load()
+    gp, ldg = _mat(g, 'g')
+    n, d = g.shape
+    chunks = L.gist_colsum_partials(n)
+    if partials is None:
+        partials = torch.empty(max(chunks * d, 1), dtype=torch.float32, device=g.device)
+    _lib.check(L.gist_colsum_f32(gp, ldg, n, d, _vec(partials, 'partials', torch.float32, chunks * d),
+                                 _vec(out, 'out', torch.float32, d), _stream()), 'gist_colsum_f32')
+    return out
+
+
+# -- loss / optimiser ------------------------------------------------------------------
+def softmax_xent(logits, labels, mask, count, row_loss, loss, d_logits):
+    L = _lib.load()
+    lp, ldl = _mat(logits, 'logits')
+    gp, ldg = _mat(d_logits, 'd_logits')
+    n, c = logits.shape
+    _lib.check(L.gist_softmax_xent_f32(lp, ldl, _vec(labels, 'labels', torch.int32, n),
+                                       _opt(mask, 'mask', torch.uint8, n), int(count),
+                                       _vec(row_loss, 'row_loss', torch.float32, n),
+                                       _vec(loss, 'loss', torch.float32, 1), gp, ldg, n, c,
+                                       _stream()), 'gist_softmax_xent_f32')
+    return loss
+
+
+def adam_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+          weight_decay=0.0):
+    L = _lib.load()
+    n = param.numel()
+    _lib.check(L.gist_adam_f32(_vec(param, 'param', torch.float32), _vec(grad, 'grad', torch.float32, n),
+                               _vec(exp_avg, 'exp_avg', torch.float32, n),
+                               _vec(exp_avg_sq, 'exp_avg_sq', torch.float32, n), n, lr, beta1,
+                               beta2, eps, weight_decay, int(step), _stream()), 'gist_adam_f32')
+    return param
+
+
+def argmax_correct(logits, labels, mask, correct):
+    L = _lib.load()
+    lp, ldl = _mat(logits, 'logits')
+    n, c = logits.shape
+    _lib.check(L.gist_argmax_correct_i32(lp, ldl, _vec(labels, 'labels', torch.int32, n),
+                                         _opt(mask, 'mask', torch.uint8, n),
+                                         _vec(correct, 'correct', torch.int32, 1), n, c, _stream()),
+               'gist_argmax_correct_i32')
+    return correct
+
+
+# -- cluster batch extraction -------------------------------------------------------------
+def fill_i32_(t, value):
+    L = _lib.load()
+    _lib.check(L.gist_fill_i32(_vec(t, 't', torch.int32), t.numel(), int(value), _stream()),
+               'gist_fill_i32')
+    return t
+
+
+def induced_mark(ids, remap, unmark=False):
+    L = _lib.load()
+    f = L.gist_induced_unmark if unmark else L.gist_induced_mark
+    _lib.check(f(_vec(ids, 'ids', torch.int32), ids.numel(), _vec(remap, 'remap', torch.int32),
+                 _stream()), 'gist_induced_mark')
+
+
+def induced_rowptr(rowptr, col, ids, remap, sub_rowptr):
+    L = _lib.load()
+    n = ids.numel()
+    _lib.check(L.gist_induced_rowptr(_vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32),
+                                     _vec(ids, 'ids', torch.int32), n,
+                                     _vec(remap, 'remap', torch.int32),
+                                     _vec(sub_rowptr, 'sub_rowptr', torch.int32, n + 1), _stream()),
+               'gist_induced_rowptr')
+    return sub_rowptr
+
+
+def induced_fill(rowptr, col, ids, remap, sub_rowptr, sub_col):
+    L = _lib.load()
+    n = ids.numel()
+    _lib.check(L.gist_induced_fill(_vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32),
+                                   _vec(ids, 'ids', torch.int32), n, _vec(remap, 'remap', torch.int32),
+                                   _vec(sub_rowptr, 'sub_rowptr', torch.int32, n + 1),
+                                   _vec(sub_col, 'sub_col', torch.int32), sub_col.numel(), _stream()),
+               'gist_induced_fill')
+    return sub_col
+
+
+def gather_rows(src, ids, dst):
+    L = _lib.load()
+    sp, lds = _mat(src, 'src')
+    dp, ldd = _mat(dst, 'dst')
+    n, d = ids.numel(), src.shape[1]
+    if tuple(dst.shape) != (n, d):
+        raise ValueError('gist_amd: gather_rows shape mismatch')
+    _lib.check(L.gist_gather_rows_f32(sp, lds, _vec(ids, 'ids', torch.int32), n, d, dp, ldd,
+                                      _stream()), 'gist_gather_rows_f32')
+    return dst
+
+
+def gather_i32(src, ids, dst):
+    L = _lib.load()
+    n = ids.numel()
+    _lib.check(L.gist_gather_i32(_vec(src, 'src', torch.int32), _vec(ids, 'ids', torch.int32), n,
+                                 _vec(dst, 'dst', torch.int32, n), _stream()), 'gist_gather_i32')
+    return dst
+
+
+# -- IST weight blocks ------------------------------------------------------------------------
+def block_gather(src, row_idx, col_idx, dst):
+    """dst[i, j] = src[row_idx[i], col_idx[j]] (None = identity)."""
+    L = _lib.load()
+    sp, lds = _mat(src, 'src')
+    dp, ldd = _mat(dst, 'dst')
+    nr, nc = dst.shape
+    _lib.check(L.gist_block_gather_f32(sp, lds, _opt(row_idx, 'row_idx', torch.int32, nr),
+                                       _opt(col_idx, 'col_idx', torch.int32, nc), nr, nc, dp, ldd,
+                                       _stream()), 'gist_block_gather_f32')
+    return dst
+
+
+def block_scatter(src, row_idx, col_idx, dst):
+    """dst[row_idx[i], col_idx[j]] = src[i, j] (None = identity)."""
+    L = _lib.load()
+    sp, lds = _mat(src, 'src')
+    dp, ldd = _mat(dst, 'dst')
+    nr, nc = src.shape
+    _lib.check(L.gist_block_scatter_f32(sp, lds, _opt(row_idx, 'row_idx', torch.int32, nr),
+                                        _opt(col_idx, 'col_idx', torch.int32, nc), nr, nc, dp, ldd,
+                                        _stream()), 'gist_block_scatter_f32')
+    return dst
+
+
+def mean_rows(src, stride, n_src, n, out):
+    L = _lib.load()
+    _lib.check(L.gist_mean_rows_f32(_vec(src, 'src', torch.float32), stride, n_src, n,
+                                    _vec(out, 'out', torch.float32, n), _stream()),
+               'gist_mean_rows_f32')
+    return out

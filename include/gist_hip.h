@@ -1,0 +1,227 @@
+/*
+ * gist_hip.h -- C ABI of libgist_hip.so: the MI355X (gfx950) implementation of
+ * GIST's hot path (GraphSAGE forward/backward over cluster sub-graphs, cluster
+ * batch extraction, IST weight-block dispatch/sync).
+ *
+ * The reference (wolfecameron/GIST) is pure Python on DGL + PyTorch and has no
+ * FFI of its own; each entry point below replaces the native work ONE reference
+ * call site causes (cited as file:line relative to the reference root), so a
+ * maintainer binds them with ctypes at exactly those call sites
+ * (INTEGRATION.md shows the stubs).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HBM)
+ *     unless a parameter is documented as host.
+ *   - all matrices are row-major fp32 with an explicit leading dimension (in
+ *     elements); graph indices are int32 on the device (reference: g.int(),
+ *     cluster_gcn/cluster_gcn_ist_distrib.py:514).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream); nothing allocates, nothing synchronises, the
+ *     caller owns every buffer (workspaces are passed in).
+ *   - return value: 0 on success, a negative GIST_E* code otherwise; no C++
+ *     exception crosses the boundary.  gist_last_error() returns a static
+ *     string describing the last failure on the calling thread.
+ */
+#ifndef GIST_HIP_H_
+#define GIST_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gist_stream_t;
+
+#define GIST_OK 0
+#define GIST_EINVAL (-1)   /* bad argument (null pointer, negative size, misaligned) */
+#define GIST_ELAUNCH (-2)  /* hipLaunch / runtime error */
+#define GIST_ENOSPACE (-3) /* workspace too small */
+
+const char *gist_last_error(void);
+/* ABI version; bumped whenever a signature changes. */
+int gist_abi_version(void);
+/* Number of visible HIP devices (>= 0) or a negative error. */
+int gist_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Neighbour aggregation
+ * ------------------------------------------------------------------------- */
+
+/* norm[v] = 1 / in_degree(v), 0 where the degree is 0.
+ * Replaces ISTSAGELayer.get_norm, cluster_gcn/modules.py:239-243
+ * (and ClusterIter.get_norm, cluster_gcn/sampler.py:72-76). */
+int gist_in_degree_norm_f32(const int32_t *rowptr, int64_t n_rows, float *norm,
+                            gist_stream_t stream);
+
+/* y[v, 0:d] = (accumulate ? y[v,:] : 0)
+ *           + out_scale[v] * sum_{e in [rowptr[v], rowptr[v+1])} src_scale[col[e]] * x[col[e], 0:d]
+ * out_scale / src_scale may be NULL (= 1).  x and y may be column windows of wider
+ * buffers (ldx, ldy); they must not overlap.
+ * Forward: replaces g.update_all(fn.copy_src, fn.sum) followed by `* norm`,
+ * cluster_gcn/modules.py:223-226 (out_scale = norm), writing straight into the
+ * right half of the [h | ah] buffer that torch.cat builds at :227.
+ * Backward: the same call on the CSR of the reversed graph with src_scale = norm
+ * and accumulate = 1 is autograd's gradient of that op. */
+int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col,
+                      const float *x, int64_t ldx, float *y, int64_t ldy,
+                      int64_t n_rows, int64_t d,
+                      const float *out_scale, const float *src_scale,
+                      int accumulate, gist_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Dense projection (fp32 MFMA, exact fp32 arithmetic)
+ * ------------------------------------------------------------------------- */
+
+/* Bytes of workspace gist_gemm_* may need for the given output shape (split-K
+ * partial sums); 0 is a valid answer.  Host function. */
+int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
+/* Y[m,n] = A[m,k] . W[n,k]^T + bias[n]          (bias may be NULL)
+ * Replaces self.linear(h), cluster_gcn/modules.py:233 (nn.Linear: W is [out, 2*in]). */
+int gist_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw,
+                     const float *bias, float *y, int64_t ldy,
+                     int64_t m, int64_t n, int64_t k,
+                     void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
+/* Z[m,n] = G[m,k] . W[k,n]
+ * Replaces autograd of nn.Linear wrt its input (dZ = dY . W), modules.py:233. */
+int gist_gemm_nn_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
+                     float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                     void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
+/* D[m,n] = G[k,m]^T . A[k,n]
+ * Replaces autograd of nn.Linear wrt its weight (dW = dY^T . Z), modules.py:233. */
+int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
+                     float *d, int64_t ldd, int64_t m, int64_t n, int64_t k,
+                     void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Row-wise epilogues of one ISTSAGELayer
+ * ------------------------------------------------------------------------- */
+
+/* In place on y[n_rows, d]: yhat = (y - mean) / sqrt(var + eps) per row if
+ * use_lynorm (biased variance; nn.LayerNorm(out, elementwise_affine=False),
+ * cluster_gcn/modules.py:209,234), then out = relu ? max(yhat,0) : yhat is written
+ * to `out` (ldo) -- normally the LEFT half of the next layer's [h | ah] buffer.
+ * y keeps yhat (needed by the backward); rstd[n_rows] receives 1/sqrt(var+eps)
+ * (may be NULL when !use_lynorm).  Replaces modules.py:234-236. */
+int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t ldo,
+                         float *rstd, int64_t n_rows, int64_t d,
+                         int use_lynorm, int relu, float eps, gist_stream_t stream);
+
+/* dy[n_rows,d] from d_out: undo relu (mask yhat > 0) and LayerNorm
+ * (dy = rstd * (g - mean(g) - yhat * mean(g*yhat))).  dy may alias yhat.
+ * Replaces autograd of modules.py:234-236. */
+int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
+                         const float *rstd, float *dy, int64_t lddy,
+                         int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                         gist_stream_t stream);
+
+/* In place inverted dropout on z[n_rows, d]: keep with prob 1-p, scale by
+ * 1/(1-p).  The mask is a pure function of (seed, offset + row*d + col) so
+ * the backward regenerates it by calling the same function on the gradient.
+ * Replaces nn.Dropout on the concatenated tensor, modules.py:230-231 (same
+ * distribution, not torch's Philox stream -- SURVEY.md section 2.1). */
+int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d, float p,
+                     uint64_t seed, uint64_t offset, gist_stream_t stream);
+
+/* out[j] = sum_i g[i, j], deterministic two-stage reduction.
+ * `partials` must hold gist_colsum_partials(n_rows) * d floats.
+ * Replaces autograd of nn.Linear wrt its bias (db), modules.py:233. */
+int64_t gist_colsum_partials(int64_t n_rows);
+int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int64_t d,
+                    float *partials, float *out, gist_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Loss and optimiser
+ * ------------------------------------------------------------------------- */
+
+/* Mean cross entropy over rows with mask != 0 (mask NULL = all rows):
+ * loss[0] = mean_i -log softmax(logits[i])[labels[i]]; d_logits[n_rows, ldg]
+ * = (softmax - onehot) / count for masked rows, 0 elsewhere and in the pad
+ * columns [n_classes, ldg).  `count` is the number of masked rows (host int);
+ * row_loss[n_rows] receives the per-row -log p (0 for unmasked rows) and is
+ * reduced in a fixed order, so the loss is bitwise reproducible.
+ * Replaces nn.CrossEntropyLoss + its backward,
+ * cluster_gcn/cluster_gcn_ist_distrib.py:384,411-415; cluster_gcn/cluster_gcn.py:76,98-104. */
+int gist_softmax_xent_f32(const float *logits, int64_t ldl, const int32_t *labels,
+                          const uint8_t *mask, int64_t count, float *row_loss,
+                          float *loss, float *d_logits, int64_t ldg, int64_t n_rows,
+                          int64_t n_classes, gist_stream_t stream);
+
+/* One Adam step (coupled L2 like torch.optim.Adam) over a flat parameter arena.
+ * step is 1-based.  Replaces optimizer.step(),
+ * cluster_gcn/cluster_gcn_ist_distrib.py:405-407,417; cluster_gcn/cluster_gcn.py:78-80,105. */
+int gist_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                  int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, gist_stream_t stream);
+
+/* correct[0] += #{i : mask[i] && argmax_j logits[i,j] == labels[i]} (first max wins,
+ * like numpy argmax).  Replaces calc_acc / calc_f1(micro), cluster_gcn/utils.py:47-67. */
+int gist_argmax_correct_i32(const float *logits, int64_t ldl, const int32_t *labels,
+                            const uint8_t *mask, int32_t *correct, int64_t n_rows,
+                            int64_t n_classes, gist_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Cluster batch extraction (node-induced subgraph), device resident
+ * ------------------------------------------------------------------------- */
+
+/* remap[ids[i]] = i.  remap holds -1 everywhere else (caller initialises once
+ * with gist_fill_i32 and calls gist_induced_unmark after the batch). */
+int gist_induced_mark(const int32_t *ids, int64_t n_ids, int32_t *remap, gist_stream_t stream);
+int gist_induced_unmark(const int32_t *ids, int64_t n_ids, int32_t *remap, gist_stream_t stream);
+int gist_fill_i32(int32_t *p, int64_t n, int32_t value, gist_stream_t stream);
+
+/* sub_rowptr[0..n_ids] = exclusive scan of the induced degree of ids[i] in the
+ * CSR (rowptr, col): #neighbours u of ids[i] with remap[u] >= 0. */
+int gist_induced_rowptr(const int32_t *rowptr, const int32_t *col, const int32_t *ids,
+                        int64_t n_ids, const int32_t *remap, int32_t *sub_rowptr,
+                        gist_stream_t stream);
+
+/* sub_col[sub_rowptr[i] ...] = remap[u] for the kept neighbours of ids[i], in the
+ * original edge order.  sub_col_capacity guards the buffer (entries beyond it are
+ * dropped and GIST_ENOSPACE cannot be reported asynchronously, so size it with
+ * the full-degree sum of the batch).
+ * The three calls together replace g.subgraph(node_ids),
+ * cluster_gcn/partition_utils.py:20-25 and cluster_gcn/sampler.py:34. */
+int gist_induced_fill(const int32_t *rowptr, const int32_t *col, const int32_t *ids,
+                      int64_t n_ids, const int32_t *remap, const int32_t *sub_rowptr,
+                      int32_t *sub_col, int64_t sub_col_capacity, gist_stream_t stream);
+
+/* dst[i, 0:d] = src[ids[i], 0:d]  -- the ndata['feat'] gather of g.subgraph
+ * (partition_utils.py:23) written straight into the left half of layer 0's
+ * [h | ah] buffer (ldd). */
+int gist_gather_rows_f32(const float *src, int64_t lds, const int32_t *ids, int64_t n_ids,
+                         int64_t d, float *dst, int64_t ldd, gist_stream_t stream);
+int gist_gather_i32(const int32_t *src, const int32_t *ids, int64_t n_ids, int32_t *dst,
+                    gist_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * IST weight blocks (cluster_gcn/cluster_gcn_ist_distrib.py:100-367)
+ * ------------------------------------------------------------------------- */
+
+/* dst[i, j] = src[row_idx[i], col_idx[j]]   i < n_rows, j < n_cols
+ * row_idx / col_idx may be NULL (= identity).  Replaces the slicing in
+ * dispatch_model / ini_sync_dispatch_model, e.g. W[:, full_prev][next, :],
+ * cluster_gcn_ist_distrib.py:203-226,291-313. */
+int gist_block_gather_f32(const float *src, int64_t lds, const int32_t *row_idx,
+                          const int32_t *col_idx, int64_t n_rows, int64_t n_cols,
+                          float *dst, int64_t ldd, gist_stream_t stream);
+
+/* dst[row_idx[i], col_idx[j]] = src[i, j].  Replaces the write-back in sync_model,
+ * cluster_gcn_ist_distrib.py:106-133,136-195. */
+int gist_block_scatter_f32(const float *src, int64_t lds, const int32_t *row_idx,
+                           const int32_t *col_idx, int64_t n_rows, int64_t n_cols,
+                           float *dst, int64_t ldd, gist_stream_t stream);
+
+/* out[j] = (1/n_src) * sum_s src[s * stride + j], summed in s order.  Replaces
+ * all_reduce(SUM)/num_subnet of the shared last-layer bias after the packed
+ * all-gather, cluster_gcn_ist_distrib.py:38-41,103. */
+int gist_mean_rows_f32(const float *src, int64_t stride, int64_t n_src, int64_t n,
+                       float *out, gist_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIST_HIP_H_ */

@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gist_hip.h declares,
+the ctypes binding covers exactly that set, and host-only entry points behave."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'gist_hip.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(gist_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_built():
+    from gist_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'run `python gist_amd/build.py`'
+
+
+def test_exports_match_header():
+    from gist_amd import _lib
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), 'libgist_hip.so does not export %s' % n
+    assert sorted(_lib.SIGNATURES) == names, 'ctypes binding and header disagree'
+
+
+def test_host_only_entry_points():
+    from gist_amd import _lib
+    L = _lib.load()
+    assert L.gist_abi_version() == _lib.ABI_VERSION
+    assert L.gist_gemm_workspace_bytes(0, 5, 5) == 0
+    assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) == 0          # enough tiles
+    assert L.gist_gemm_workspace_bytes(2046, 41, 8192) > 0             # split-K
+    assert L.gist_colsum_partials(0) == 0 and L.gist_colsum_partials(129) == 2
+    # argument validation happens before any device work
+    assert L.gist_spmm_csr_f32(None, None, None, 4, None, 4, 3, 4, None, None, 0, None) == -1
+    assert b'null pointer' in L.gist_last_error()
+    assert L.gist_adam_f32(None, None, None, None, -1, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from gist_amd import hip
+    x = torch.zeros(4, 4)
+    rp = torch.zeros(5, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        hip.spmm(rp, rp, x, x.clone())
+
+
+def test_missing_library_is_loud(monkeypatch):
+    from gist_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libgist_hip.so')
+    with pytest.raises(_lib.GistLibraryError, match='no CPU fallback'):
+        _lib.load()

@@ -1,0 +1,364 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  fp32 values: 1e-4 (north_star tolerance, relative to the
+magnitude of the result for long reductions); integer / index work: bit exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gist_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = 'cuda:0'
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def rand_graph(n, avg_deg, seed, hub=0):
+    rs = np.random.RandomState(seed)
+    m = n * avg_deg
+    src = rs.randint(0, n, m)
+    dst = rs.randint(0, max(n - 1, 1), m)      # last node has zero in-degree
+    if hub:
+        src = np.concatenate([src, rs.randint(0, n, hub)])
+        dst = np.concatenate([dst, np.full(hub, 1)])
+    return O.csr_from_edges(src, dst, n)
+
+
+def close(a, b, tol=TOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, 'max err %g (scale %g)' % (err, scale)
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from gist_amd import hip as h
+    assert h.device_count() >= 1
+    return h
+
+
+# ------------------------------------------------------------------ SpMM
+@pytest.mark.parametrize('n,d,deg,hub', [
+    (7, 5, 3, 0), (64, 41, 4, 0), (257, 100, 6, 300), (300, 602, 8, 0),
+    (513, 256, 16, 700), (1000, 1024, 20, 0), (2046, 4096, 64, 3000), (129, 2, 5, 0),
+    (90, 12, 7, 0), (200, 3, 2, 0)])
+def test_spmm_forward(hip, n, d, deg, hub):
+    rowptr, col = rand_graph(n, deg, seed=n + d, hub=hub)
+    rs = np.random.RandomState(1)
+    x = rs.randn(n, d).astype(np.float32)
+    norm = O.in_degree_norm(rowptr)
+    ref = O.spmm_sum(rowptr, col, x, out_scale=norm)
+    rp, cl = dev(rowptr, torch.int32), dev(col, torch.int32)
+    nd = hip.in_degree_norm(rp)
+    assert np.array_equal(nd.cpu().numpy(), norm)
+    y = torch.full((n, d), 7.0, device=DEV)
+    hip.spmm(rp, cl, dev(x), y, out_scale=nd)
+    close(y, ref)
+    assert (y[np.diff(rowptr) == 0] == 0).all()       # zero in-degree rows -> exactly 0
+
+
+@pytest.mark.parametrize('n,d', [(64, 10), (300, 602), (700, 256), (1500, 1024)])
+def test_spmm_concat_window_and_backward_form(hip, n, d):
+    """x/y as the two halves of one [n, 2d] buffer; backward = src_scale + accumulate."""
+    rowptr, col = rand_graph(n, 9, seed=d)
+    t_rowptr, t_col = O.transpose_csr(rowptr, col)
+    rs = np.random.RandomState(2)
+    z = rs.randn(n, 2 * d).astype(np.float32)
+    norm = O.in_degree_norm(rowptr)
+    zt = dev(z)
+    hip.spmm(dev(rowptr, torch.int32), dev(col, torch.int32), zt[:, :d], zt[:, d:],
+             out_scale=dev(norm))
+    ref = z.copy()
+    ref[:, d:] = O.spmm_sum(rowptr, col, np.ascontiguousarray(z[:, :d]), out_scale=norm)
+    close(zt, ref)
+    # backward: dh = dz[:, :d] + A^T (norm * dz[:, d:])
+    gz = rs.randn(n, 2 * d).astype(np.float32)
+    gt = dev(gz)
+    hip.spmm(dev(t_rowptr, torch.int32), dev(t_col, torch.int32), gt[:, d:], gt[:, :d],
+             src_scale=dev(norm), accumulate=True)
+    dh = np.ascontiguousarray(gz[:, :d])
+    O.spmm_sum(t_rowptr, t_col, gz[:, d:], src_scale=norm, out=dh, accumulate=True)
+    close(gt[:, :d], dh)
+    assert np.array_equal(gt[:, d:].cpu().numpy(), gz[:, d:])
+
+
+def test_spmm_empty(hip):
+    rp = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cl = torch.zeros(0, dtype=torch.int32, device=DEV)
+    hip.spmm(rp, cl, torch.zeros(0, 8, device=DEV), torch.zeros(0, 8, device=DEV))
+
+
+# ------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (128, 128, 32), (130, 129, 33), (257, 41, 1204),
+               (300, 256, 1204), (2046, 41, 1024), (64, 512, 200), (500, 1024, 2048),
+               (41, 300, 2046), (2046, 1024, 512)]
+
+
+@pytest.mark.parametrize('m,n,k', GEMM_SHAPES)
+def test_gemm_nt(hip, m, n, k):
+    rs = np.random.RandomState(m + n + k)
+    a = rs.randn(m, k).astype(np.float32)
+    w = rs.randn(n, k).astype(np.float32)
+    b = rs.randn(n).astype(np.float32)
+    y = torch.full((m, n), np.nan, device=DEV)
+    hip.gemm_nt(dev(a), dev(w), dev(b), y)
+    ref = (a.astype(np.float64) @ w.T.astype(np.float64) + b).astype(np.float32)
+    close(y, ref, tol=2e-6 * np.sqrt(k) + 1e-6)
+    y2 = torch.full((m, n), np.nan, device=DEV)
+    hip.gemm_nt(dev(a), dev(w), None, y2)
+    close(y2, ref - b, tol=2e-6 * np.sqrt(k) + 1e-6)
+
+
+@pytest.mark.parametrize('m,n,k', GEMM_SHAPES)
+def test_gemm_nn(hip, m, n, k):
+    rs = np.random.RandomState(m + 2 * n + k)
+    g = rs.randn(m, k).astype(np.float32)
+    w = rs.randn(k, n).astype(np.float32)
+    z = torch.full((m, n), np.nan, device=DEV)
+    hip.gemm_nn(dev(g), dev(w), z)
+    close(z, (g.astype(np.float64) @ w.astype(np.float64)).astype(np.float32),
+          tol=2e-6 * np.sqrt(k) + 1e-6)
+
+
+@pytest.mark.parametrize('m,n,k', GEMM_SHAPES)
+def test_gemm_tn(hip, m, n, k):
+    rs = np.random.RandomState(m + n + 3 * k)
+    g = rs.randn(k, m).astype(np.float32)
+    a = rs.randn(k, n).astype(np.float32)
+    d = torch.full((m, n), np.nan, device=DEV)
+    hip.gemm_tn(dev(g), dev(a), d)
+    close(d, (g.T.astype(np.float64) @ a.astype(np.float64)).astype(np.float32),
+          tol=2e-6 * np.sqrt(k) + 1e-6)
+
+
+def test_gemm_strided_unaligned_operands(hip):
+    """Operands that are column windows with odd leading dimensions (scalar-load path),
+    asymmetric data so a transposed store cannot pass."""
+    rs = np.random.RandomState(9)
+    m, n, k = 70, 45, 37
+    abuf = rs.randn(m, k + 5).astype(np.float32)
+    wbuf = rs.randn(n, k + 3).astype(np.float32)
+    ybuf = torch.zeros(m, n + 7, device=DEV)
+    at, wt = dev(abuf), dev(wbuf)
+    hip.gemm_nt(at[:, 1:1 + k], wt[:, 2:2 + k], None, ybuf[:, 3:3 + n])
+    ref = abuf[:, 1:1 + k].astype(np.float64) @ wbuf[:, 2:2 + k].T.astype(np.float64)
+    close(ybuf[:, 3:3 + n], ref.astype(np.float32), tol=2e-5)
+    assert (ybuf[:, :3] == 0).all() and (ybuf[:, 3 + n:] == 0).all()
+
+
+def test_gemm_identity_asymmetric(hip):
+    """A = I against an asymmetric B catches a swapped C/D register map."""
+    n = 96
+    b = np.arange(n * n, dtype=np.float32).reshape(n, n) / 100.0
+    out = torch.zeros(n, n, device=DEV)
+    hip.gemm_nn(dev(np.eye(n, dtype=np.float32)), dev(b), out)
+    assert np.array_equal(out.cpu().numpy(), b)
+
+
+# ------------------------------------------------------------------ LN / ReLU / dropout / colsum
+@pytest.mark.parametrize('n,d', [(5, 7), (64, 41), (300, 256), (257, 1024), (100, 4096), (33, 1030)])
+@pytest.mark.parametrize('ln,relu', [(True, True), (True, False), (False, True)])
+def test_ln_relu_fwd_bwd(hip, n, d, ln, relu):
+    rs = np.random.RandomState(n + d)
+    y = (rs.randn(n, d) * 3 + 0.5).astype(np.float32)
+    g = rs.randn(n, d).astype(np.float32)
+    yt = dev(y)
+    nxt = torch.zeros(n, 2 * d, device=DEV)           # write into a left half
+    rstd = torch.zeros(n, device=DEV)
+    hip.ln_relu_fwd(yt, nxt[:, :d], rstd, ln, relu)
+    if ln:
+        mu = y.mean(1, keepdims=True, dtype=np.float32)
+        var = ((y - mu) ** 2).mean(1, keepdims=True, dtype=np.float32)
+        rs_ref = 1.0 / np.sqrt(var + 1e-5)
+        yhat = (y - mu) * rs_ref
+        close(rstd, rs_ref[:, 0], tol=1e-5)
+    else:
+        yhat = y
+    out = np.maximum(yhat, 0) if relu else yhat
+    close(yt, yhat)
+    close(nxt[:, :d], out)
+    assert (nxt[:, d:] == 0).all()
+    # backward (oracle formula)
+    gg = g * (yhat > 0) if relu else g
+    if ln:
+        m1 = gg.mean(1, keepdims=True, dtype=np.float32)
+        m2 = (gg * yhat).mean(1, keepdims=True, dtype=np.float32)
+        gg = rs_ref * (gg - m1 - yhat * m2)
+    dy = torch.empty(n, d, device=DEV)
+    hip.ln_relu_bwd(dev(g), yt, rstd, dy, ln, relu)
+    close(dy, gg.astype(np.float32))
+    hip.ln_relu_bwd(dev(g), yt, rstd, yt, ln, relu)     # in place over yhat
+    close(yt, gg.astype(np.float32))
+
+
+def _dropout_mask_ref(n, d, p, seed, offset):
+    idx = np.arange(n * d, dtype=np.uint64) + np.uint64(offset)
+    with np.errstate(over='ignore'):
+        z = (idx >> np.uint64(1)) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    w = np.where(idx & np.uint64(1), z >> np.uint64(32), z & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(n, d)
+
+
+@pytest.mark.parametrize('n,d,p', [(50, 33, 0.2), (300, 1204, 0.5), (2046, 512, 0.2)])
+def test_dropout(hip, n, d, p):
+    rs = np.random.RandomState(3)
+    z = rs.randn(n, d + 3).astype(np.float32)
+    zt = dev(z)
+    hip.dropout_(zt[:, :d], p, seed=1234, offset=77)
+    mask = _dropout_mask_ref(n, d, p, 1234, 77)
+    ref = z.copy()
+    ref[:, :d] = z[:, :d] * mask * np.float32(1.0 / (1.0 - p))
+    close(zt, ref, tol=1e-6)
+    keep = mask.mean()
+    assert abs(keep - (1 - p)) < 0.02
+    # a different offset gives a different mask; same call regenerates the same one
+    z2 = dev(z)
+    hip.dropout_(z2[:, :d], p, seed=1234, offset=77)
+    assert torch.equal(z2, zt)
+
+
+@pytest.mark.parametrize('n,d', [(1, 1), (127, 41), (300, 1024), (2046, 4096)])
+def test_colsum(hip, n, d):
+    rs = np.random.RandomState(n)
+    g = rs.randn(n, d).astype(np.float32)
+    out = torch.zeros(d, device=DEV)
+    hip.colsum(dev(g), out)
+    close(out, g.sum(0, dtype=np.float64).astype(np.float32), tol=1e-5)
+
+
+# ------------------------------------------------------------------ loss / Adam / accuracy
+@pytest.mark.parametrize('n,c,ldg', [(10, 5, 8), (300, 41, 44), (2046, 47, 48), (70, 130, 132)])
+def test_softmax_xent(hip, n, c, ldg):
+    rs = np.random.RandomState(c)
+    logits = (rs.randn(n, c) * 4).astype(np.float32)
+    labels = rs.randint(0, c, n)
+    mask = rs.rand(n) < 0.8
+    for msk in (None, mask):
+        loss_ref, d_ref = O.cross_entropy(logits, labels, msk)
+        cnt = n if msk is None else int(msk.sum())
+        dl = torch.full((n, ldg), np.nan, device=DEV)
+        loss = torch.zeros(1, device=DEV)
+        hip.softmax_xent(dev(logits), dev(labels, torch.int32),
+                         None if msk is None else dev(msk.astype(np.uint8)), cnt,
+                         torch.empty(n, device=DEV), loss, dl)
+        assert abs(loss.item() - loss_ref) < TOL
+        close(dl[:, :c], d_ref, tol=1e-6)
+        assert (dl[:, c:] == 0).all()
+
+
+@pytest.mark.parametrize('wd', [0.0, 5e-4])
+def test_adam(hip, wd):
+    rs = np.random.RandomState(4)
+    n = 10007
+    p = rs.randn(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    pt, mt, vt = dev(p), dev(m), dev(v)
+    for step in range(1, 6):
+        g = rs.randn(n).astype(np.float32)
+        O.adam_step(p, g, m, v, step, 0.01, weight_decay=wd)
+        hip.adam_(pt, dev(g), mt, vt, step, 0.01, weight_decay=wd)
+    close(pt, p, tol=1e-6)
+    close(mt, m, tol=1e-6)
+    close(vt, v, tol=1e-6)
+
+
+def test_argmax_correct(hip):
+    rs = np.random.RandomState(5)
+    n, c = 1000, 41
+    logits = rs.randn(n, c).astype(np.float32)
+    logits[::7, 3] = logits[::7].max(1)          # ties: first max wins like numpy
+    labels = rs.randint(0, c, n)
+    labels[:200] = np.argmax(logits[:200], 1)
+    mask = rs.rand(n) < 0.6
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.argmax_correct(dev(logits), dev(labels, torch.int32), dev(mask.astype(np.uint8)), cnt)
+    assert cnt.item() == int((np.argmax(logits[mask], 1) == labels[mask]).sum())
+
+
+# ------------------------------------------------------------------ cluster batch extraction
+@pytest.mark.parametrize('n,deg,nb,hub', [(50, 4, 20, 0), (3000, 30, 700, 500), (20000, 60, 2046, 4000)])
+def test_induced_subgraph(hip, n, deg, nb, hub):
+    rowptr, col = rand_graph(n, deg, seed=n, hub=hub)
+    rs = np.random.RandomState(6)
+    ids = rs.permutation(n)[:nb].astype(np.int64)
+    if hub:
+        ids[0] = 1                                  # include the hub row
+        ids = np.unique(ids)
+        rs.shuffle(ids)
+        nb = ids.shape[0]
+    ref_rp, ref_cl = O.induced_subgraph(rowptr, col, ids)
+    rp, cl, idt = dev(rowptr, torch.int32), dev(col, torch.int32), dev(ids, torch.int32)
+    remap = torch.empty(n, dtype=torch.int32, device=DEV)
+    hip.fill_i32_(remap, -1)
+    hip.induced_mark(idt, remap)
+    srp = torch.empty(nb + 1, dtype=torch.int32, device=DEV)
+    hip.induced_rowptr(rp, cl, idt, remap, srp)
+    assert np.array_equal(srp.cpu().numpy(), ref_rp)
+    scl = torch.full((int(ref_rp[-1]) + 5,), -7, dtype=torch.int32, device=DEV)
+    hip.induced_fill(rp, cl, idt, remap, srp, scl)
+    assert np.array_equal(scl.cpu().numpy()[:-5], ref_cl)
+    assert (scl[-5:] == -7).all()
+    hip.induced_mark(idt, remap, unmark=True)
+    assert (remap == -1).all()
+    # feature / label gather
+    feat = rs.randn(n, 602).astype(np.float32)
+    z0 = torch.zeros(nb, 1204, device=DEV)
+    hip.gather_rows(dev(feat), idt, z0[:, :602])
+    assert np.array_equal(z0[:, :602].cpu().numpy(), feat[ids])
+    lab = rs.randint(0, 41, n).astype(np.int32)
+    lo = torch.empty(nb, dtype=torch.int32, device=DEV)
+    hip.gather_i32(dev(lab), idt, lo)
+    assert np.array_equal(lo.cpu().numpy(), lab[ids])
+
+
+def test_scan_large(hip):
+    """train-induced subgraph size: > 1024 rows exercises the multi-chunk scan."""
+    n = 150000
+    rowptr, col = rand_graph(n, 3, seed=8)
+    ids = np.arange(0, n, 2, dtype=np.int64)
+    ref_rp, _ = O.induced_subgraph(rowptr, col, ids)
+    remap = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    idt = dev(ids, torch.int32)
+    hip.induced_mark(idt, remap)
+    srp = torch.empty(ids.shape[0] + 1, dtype=torch.int32, device=DEV)
+    hip.induced_rowptr(dev(rowptr, torch.int32), dev(col, torch.int32), idt, remap, srp)
+    assert np.array_equal(srp.cpu().numpy(), ref_rp)
+
+
+# ------------------------------------------------------------------ IST blocks
+def test_block_gather_scatter(hip):
+    rs = np.random.RandomState(7)
+    H, h = 64, 16
+    W = rs.randn(H, 2 * H).astype(np.float32)
+    rows = rs.permutation(H)[:h]
+    cols = np.concatenate([rs.permutation(H)[:h]] * 2)
+    cols[h:] += H
+    Wt = dev(W)
+    blk = torch.empty(h, 2 * h, device=DEV)
+    hip.block_gather(Wt, dev(rows, torch.int32), dev(cols, torch.int32), blk)
+    assert np.array_equal(blk.cpu().numpy(), W[np.ix_(rows, cols)])
+    blk2 = blk + 1
+    hip.block_scatter(blk2, dev(rows, torch.int32), dev(cols, torch.int32), Wt)
+    ref = W.copy()
+    ref[np.ix_(rows, cols)] += 1
+    assert np.array_equal(Wt.cpu().numpy(), ref)
+    # identity index forms
+    out = torch.empty(5, 2 * h, device=DEV)
+    hip.block_gather(Wt, None, dev(cols, torch.int32), out)
+    assert np.array_equal(out.cpu().numpy(), ref[:5][:, cols])
+    src = torch.stack([torch.arange(41, dtype=torch.float32, device=DEV) * (s + 1) for s in range(4)])
+    o = torch.empty(41, device=DEV)
+    hip.mean_rows(src.reshape(-1), 41, 4, 41, o)
+    close(o, (np.arange(41, dtype=np.float32) * 2.5), tol=1e-6)
