@@ -1,0 +1,100 @@
+"""Seeded synthetic stand-ins for the datasets GIST trains on (none are available
+offline; SURVEY.md section 8d fixes the statistics).  Pure host-side construction --
+not on the hot path.
+
+A dataset is a stochastic block model whose blocks play the role of METIS parts:
+dense inside a block, sparse between blocks, symmetric, one self loop per node
+(reddit-self-loop), a small fraction of hub nodes with 10x degree (power-law skew).
+
+  reddit-synth   N_train=153431, F=602, C=41, 1500 blocks; a 20-block batch has
+                 ~2046 rows and mean in-batch in-degree ~64
+  amazon-synth   N_train=1709997 (scalable), F=100, C=47, 15000 blocks, batch of 10
+                 blocks ~1140 rows, mean in-degree ~16
+  toy            small graph for tests
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .graph import Graph
+
+Dataset = namedtuple('Dataset', ['num_classes', 'g', 'par_li', 'name'])
+
+
+def sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed):
+    """Directed edge list (symmetrised + self loops) of a block model on n nodes."""
+    rs = np.random.RandomState(seed)
+    base, extra = divmod(n, n_blocks)
+    sizes = np.full(n_blocks, base, np.int64)
+    sizes[:extra] += 1
+    starts = np.zeros(n_blocks + 1, np.int64)
+    np.cumsum(sizes, out=starts[1:])
+    block_of = np.repeat(np.arange(n_blocks), sizes)
+    mult = np.ones(n, np.int64)
+    n_hub = int(n * hub_frac)
+    if n_hub:
+        mult[rs.choice(n, n_hub, replace=False)] = hub_mult
+    nodes = np.arange(n, dtype=np.int64)
+    src_i = np.repeat(nodes, intra_deg * mult)
+    b = block_of[src_i]
+    dst_i = starts[b] + (rs.random_sample(src_i.shape[0]) * sizes[b]).astype(np.int64)
+    src_o = np.repeat(nodes, inter_deg * mult)
+    dst_o = rs.randint(0, n, src_o.shape[0]).astype(np.int64)
+    src = np.concatenate([src_i, dst_i, src_o, dst_o, nodes])
+    dst = np.concatenate([dst_i, src_i, dst_o, src_o, nodes])
+    blocks = [np.arange(starts[k], starts[k + 1], dtype=np.int64) for k in range(n_blocks)]
+    return src, dst, blocks
+
+
+def make_block_dataset(name, n, n_blocks, n_feats, n_classes, intra_deg, inter_deg, seed,
+                       hub_frac=0.01, hub_mult=10, train_frac=1.0):
+    """Graph with ndata feat/label/{train,val,test}_mask on the host + partition list of
+    the TRAIN-induced graph (ids relative to the train graph, like METIS on
+    ClusterIter.g, sampler.py:34,50)."""
+    src, dst, blocks = sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed)
+    g = Graph.from_edges(src, dst, n)
+    gen = torch.Generator().manual_seed(seed)
+    g.ndata['feat'] = torch.randn(n, n_feats, generator=gen)            # post-StandardScaler stats
+    g.ndata['label'] = torch.randint(0, n_classes, (n,), generator=gen)
+    rs = np.random.RandomState(seed + 1)
+    if train_frac >= 1.0:
+        role = np.zeros(n)
+    else:
+        role = rs.rand(n)
+    train = role < train_frac
+    val = (role >= train_frac) & (role < train_frac + (1 - train_frac) * 0.3)
+    test = role >= train_frac + (1 - train_frac) * 0.3
+    g.ndata['train_mask'] = torch.from_numpy(train)
+    g.ndata['val_mask'] = torch.from_numpy(val)
+    g.ndata['test_mask'] = torch.from_numpy(test)
+    # partition list over the train-induced graph: block k -> its train nodes, relabelled
+    new_id = np.cumsum(train) - 1
+    par_li = [new_id[blk[train[blk]]].astype(np.int64) for blk in blocks]
+    par_li = [p for p in par_li if p.shape[0] > 0]
+    return Dataset(num_classes=n_classes, g=g, par_li=par_li, name=name)
+
+
+def reddit_synth(seed=0, n=153431, n_blocks=1500, train_frac=1.0):
+    return make_block_dataset('reddit-synth', n, n_blocks, 602, 41, intra_deg=28, inter_deg=20,
+                              seed=seed, train_frac=train_frac)
+
+
+def amazon_synth(seed=1, n=1709997, n_blocks=15000, train_frac=1.0):
+    return make_block_dataset('amazon-synth', n, n_blocks, 100, 47, intra_deg=7, inter_deg=4,
+                              seed=seed, hub_frac=0.005, train_frac=train_frac)
+
+
+def toy(seed=2, n=2400, n_blocks=24, n_feats=32, n_classes=5, train_frac=0.7):
+    return make_block_dataset('toy', n, n_blocks, n_feats, n_classes, intra_deg=5, inter_deg=2,
+                              seed=seed, train_frac=train_frac)
+
+
+def load_dataset(name):
+    if name in ('reddit-synth', 'reddit-self-loop', 'reddit'):
+        return reddit_synth(n=232965, train_frac=0.6586)      # 153431 / 232965 like Reddit
+    if name in ('amazon-synth', 'amazon2m'):
+        return amazon_synth(n=2449029, train_frac=0.6982)
+    if name == 'toy':
+        return toy()
+    raise ValueError('gist_amd: unknown dataset %r (no real datasets offline)' % name)

@@ -1,0 +1,270 @@
+"""SageEngine: the training step of GIST's hot path laid out for MI355X.
+
+One engine = one (sub-)GCN on one GPU.  Everything lives in HBM for the whole run:
+
+  * parameters, gradients and Adam moments are four flat fp32 arenas; layer k's
+    W_k [out, 2*in] and b_k [out] are views.  Adam is ONE kernel over the arena and
+    the IST sync all-gathers the arena as it stands (no packing copies).
+  * activations are preallocated for the largest batch: Z_k = [h | ah]  [n, 2*in_k]
+    (left half written by the previous layer's LN+ReLU epilogue or the feature
+    gather, right half by the SpMM: torch.cat of modules.py:227 never materialises),
+    Y_k [n, out_k] (pre-norm, overwritten by yhat, then by dY in the backward).
+  * the cluster batch (induced CSR + reversed CSR, norm, labels, features) is
+    extracted on the device from the resident training graph; the host only sends
+    the epoch's part order once per epoch.  No per-iteration H2D, no host sync.
+
+The step follows SURVEY.md appendix A / cluster_gcn_ist_distrib.py:408-417 exactly:
+forward, mean CE over the batch rows, backward, Adam (coupled L2).
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ParamArena(object):
+    """Flat parameter / gradient / Adam-moment storage with per-layer views."""
+
+    def __init__(self, dims, device):
+        self.dims = list(dims)
+        self.offsets = []
+        off = 0
+        for (i, o) in self.dims:
+            self.offsets.append((off, off + o * 2 * i))
+            off += o * 2 * i + o
+        self.numel = off
+        self.device = device
+        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+        self.W, self.b, self.dW, self.db = [], [], [], []
+        for (i, o), (w0, b0) in zip(self.dims, self.offsets):
+            self.W.append(self.params[w0:b0].view(o, 2 * i))
+            self.b.append(self.params[b0:b0 + o])
+            self.dW.append(self.grads[w0:b0].view(o, 2 * i))
+            self.db.append(self.grads[b0:b0 + o])
+        self.step = 0
+
+    def reset_optimizer(self):
+        """Fresh Adam state (cluster_gcn_ist_distrib.py:405-407 builds a new optimizer)."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step = 0
+
+    def load(self, params):
+        """params = [(W, b)] numpy arrays or tensors."""
+        for k, (W, b) in enumerate(params):
+            self.W[k].copy_(torch.as_tensor(W).to(self.device))
+            self.b[k].copy_(torch.as_tensor(b).to(self.device))
+
+    def export(self):
+        return [(W.detach().cpu().numpy().copy(), b.detach().cpu().numpy().copy())
+                for W, b in zip(self.W, self.b)]
+
+    def adopt_module(self, gcn):
+        """Re-home an nn.Module GCN's parameters into the arena (values preserved)."""
+        for k, layer in enumerate(gcn.layers):
+            self.W[k].copy_(layer.linear.weight.data.to(self.device))
+            self.b[k].copy_(layer.linear.bias.data.to(self.device))
+            layer.linear.weight.data = self.W[k]
+            layer.linear.bias.data = self.b[k]
+
+
+class Batch(object):
+    """Views into the batcher's buffers describing the current cluster batch."""
+    __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids')
+
+
+class ClusterBatcher(object):
+    """Device-resident training graph + on-device induced-subgraph extraction.
+
+    Replaces `get_subgraph` + `cluster.to(device)` (cluster_gcn/partition_utils.py:20-25,
+    cluster_gcn_ist_distrib.py:409).  `graph` is a gist_amd.graph.Graph already on the
+    GPU; feat [N, F] fp32 and labels [N] int32 live beside it.
+    """
+
+    def __init__(self, graph, feat, labels, n_max, nnz_max):
+        dev = graph.device
+        assert dev.type == 'cuda', 'ClusterBatcher needs the training graph on the GPU'
+        self.g, self.feat, self.labels = graph, feat, labels
+        self.n_max, self.nnz_max = int(n_max), int(max(nnz_max, 1))
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.remap = torch.empty(graph.number_of_nodes(), **i32)
+        hip.fill_i32_(self.remap, -1)
+        self.rowptr = torch.zeros(self.n_max + 1, **i32)
+        self.t_rowptr = torch.zeros(self.n_max + 1, **i32)
+        self.col = torch.zeros(self.nnz_max, **i32)
+        self.t_col = torch.zeros(self.nnz_max, **i32)
+        self.norm = torch.zeros(self.n_max, dtype=torch.float32, device=dev)
+        self.lab = torch.zeros(self.n_max, **i32)
+
+    def extract(self, ids, z0_left):
+        """ids: int32 device tensor (node ids in the training graph); z0_left: the [n, F]
+        left half of layer 0's [h | ah] buffer, filled with the gathered features."""
+        n = ids.numel()
+        if n > self.n_max:
+            raise ValueError('gist_amd: batch of %d rows exceeds n_max=%d' % (n, self.n_max))
+        g = self.g
+        rp, trp = self.rowptr[:n + 1], self.t_rowptr[:n + 1]
+        hip.induced_mark(ids, self.remap)
+        hip.induced_rowptr(g.rowptr, g.col, ids, self.remap, rp)
+        hip.induced_fill(g.rowptr, g.col, ids, self.remap, rp, self.col)
+        hip.induced_rowptr(g.t_rowptr, g.t_col, ids, self.remap, trp)
+        hip.induced_fill(g.t_rowptr, g.t_col, ids, self.remap, trp, self.t_col)
+        hip.induced_mark(ids, self.remap, unmark=True)
+        hip.in_degree_norm(rp, out=self.norm)
+        hip.gather_rows(self.feat, ids, z0_left)
+        hip.gather_i32(self.labels, ids, self.lab)
+        b = Batch()
+        b.n, b.rowptr, b.col, b.t_rowptr, b.t_col = n, rp, self.col, trp, self.t_col
+        b.norm, b.labels, b.ids = self.norm[:n], self.lab[:n], ids
+        return b
+
+
+class SageEngine(object):
+    def __init__(self, dims, use_layernorm, dropout, n_max, device, seed=0, arena=None):
+        """dims = [(in_k, out_k)] for the L+1 SAGE layers (modules.py:245-308)."""
+        self.dims = [(int(i), int(o)) for i, o in dims]
+        self.L1 = len(self.dims)
+        self.use_layernorm = bool(use_layernorm)
+        self.p_drop = float(dropout) if dropout else 0.0
+        self.n_max = int(n_max)
+        self.device = device
+        self.seed = int(seed)
+        self.drop_calls = 0
+        self.arena = arena if arena is not None else ParamArena(self.dims, device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.Z = [torch.zeros(self.n_max, 2 * i, **f32) for (i, o) in self.dims]
+        self.n_classes = self.dims[-1][1]
+        self.ldc = _round_up(self.n_classes, 4)
+        self.Y = [torch.zeros(self.n_max, o, **f32) for (i, o) in self.dims[:-1]]
+        self.Y.append(torch.zeros(self.n_max, self.ldc, **f32))      # logits, padded ld
+        self.dlogits = torch.zeros(self.n_max, self.ldc, **f32)
+        self.rstd = [torch.zeros(self.n_max, **f32) for _ in self.dims[:-1]]
+        wide = max([2 * i for (i, o) in self.dims[1:]] + [4])
+        self.dZ = torch.zeros(self.n_max * wide, **f32)
+        max_out = max(o for (i, o) in self.dims)
+        self.partials = torch.zeros(max(1, (self.n_max + 127) // 128) * max_out, **f32)
+        self.row_loss = torch.zeros(self.n_max, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.correct = torch.zeros(1, dtype=torch.int32, device=device)
+        # split-K workspace sized once for the largest request of any GEMM of the step
+        need = 0
+        L = hip._lib.load()
+        for (i, o) in self.dims:
+            for (m, n, k) in ((self.n_max, o, 2 * i), (self.n_max, 2 * i, o), (o, 2 * i, self.n_max)):
+                need = max(need, L.gist_gemm_workspace_bytes(m, n, k))
+        hip.workspace(need, device)
+        self._drop_offsets = []
+
+    # ------------------------------------------------------------------
+    def z0_left(self, n):
+        return self.Z[0][:n, :self.dims[0][0]]
+
+    def logits(self, n):
+        return self.Y[-1][:n, :self.n_classes]
+
+    def _drop_offset(self, numel):
+        off = self.drop_calls
+        self.drop_calls += numel + (numel & 1)
+        return off
+
+    def forward(self, b, training):
+        """GCN.forward (modules.py:310-314) on the batch whose features already sit in
+        Z[0][:, :F].  Returns the logits view [n, C]."""
+        n = b.n
+        A = self.arena
+        self._drop_offsets = []
+        for k, (i, o) in enumerate(self.dims):
+            z = self.Z[k][:n]
+            hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm)
+            if training and self.p_drop > 0.0:
+                off = self._drop_offset(n * 2 * i)
+                self._drop_offsets.append(off)
+                hip.dropout_(z, self.p_drop, self.seed, off)
+            last = k == self.L1 - 1
+            if last:
+                hip.gemm_nt(z, A.W[k], A.b[k], self.Y[k][:n, :o])
+            else:
+                y = self.Y[k][:n]
+                hip.gemm_nt(z, A.W[k], A.b[k], y)
+                i_next = self.dims[k + 1][0]
+                hip.ln_relu_fwd(y, self.Z[k + 1][:n, :i_next],
+                                self.rstd[k][:n] if self.use_layernorm else None,
+                                self.use_layernorm, True)
+        return self.logits(n)
+
+    def loss_and_backward(self, b, mask=None, count=None):
+        """CE (mean over masked rows) + full backward into the gradient arena."""
+        n = b.n
+        A = self.arena
+        hip.softmax_xent(self.logits(n), b.labels, mask, n if count is None else count,
+                         self.row_loss[:n], self.loss, self.dlogits[:n])
+        for k in range(self.L1 - 1, -1, -1):
+            i, o = self.dims[k]
+            z = self.Z[k][:n]
+            if k == self.L1 - 1:
+                dy = self.dlogits[:n, :o]
+            else:
+                # dO arrives in the left half of dZ (ld = 2*in_{k+1}); dY overwrites yhat
+                i_next = self.dims[k + 1][0]
+                d_out = self.dZ[:n * 2 * i_next].view(n, 2 * i_next)[:, :i_next]
+                dy = self.Y[k][:n]
+                hip.ln_relu_bwd(d_out, dy, self.rstd[k][:n] if self.use_layernorm else None, dy,
+                                self.use_layernorm, True)
+            hip.gemm_tn(dy, z, A.dW[k])
+            hip.colsum(dy, A.db[k], self.partials)
+            if k > 0:
+                dz = self.dZ[:n * 2 * i].view(n, 2 * i)
+                hip.gemm_nn(dy, A.W[k], dz)
+                if self._drop_offsets:
+                    hip.dropout_(dz, self.p_drop, self.seed, self._drop_offsets[k])
+                hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
+                         accumulate=True)
+        return self.loss
+
+    def adam_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        A = self.arena
+        A.step += 1
+        hip.adam_(A.params, A.grads, A.exp_avg, A.exp_avg_sq, A.step, lr, betas[0], betas[1], eps,
+                  weight_decay)
+
+    def train_step(self, b, lr, weight_decay=0.0, mask=None, count=None):
+        """One iteration of the reference loop (cluster_gcn_ist_distrib.py:408-417).
+        Returns the device loss tensor; nothing synchronises with the host."""
+        self.forward(b, training=True)
+        loss = self.loss_and_backward(b, mask, count)
+        self.adam_step(lr, weight_decay)
+        return loss
+
+    def count_correct(self, b, mask=None):
+        """Adds #correct argmax predictions of the current logits to self.correct."""
+        hip.argmax_correct(self.logits(b.n), b.labels, mask, self.correct)
+        return self.correct
+
+
+def dims_for(in_feats, n_hidden, n_classes, n_layers, split_output=False, num_subnet=1):
+    """Layer (in, out) sizes of the reference GCN for split_input=False (modules.py:245-308)."""
+    hs = n_hidden // num_subnet
+    dims = [(in_feats, n_hidden if (n_layers <= 1 and not split_output) else hs)]
+    for i in range(n_layers - 1):
+        dims.append((hs, n_hidden if (i == n_layers - 2 and not split_output) else hs))
+    dims.append((hs if split_output else n_hidden, n_classes))
+    return dims
+
+
+def batch_capacity(rowptr_host, par_li, batch_size):
+    """Host-side sizing: (max rows, max induced nnz bound) over any union of
+    `batch_size` parts.  The nnz bound is the sum of FULL degrees of the rows."""
+    deg = np.diff(np.asarray(rowptr_host, np.int64))
+    sizes = np.array([len(p) for p in par_li], np.int64)
+    degs = np.array([int(deg[np.asarray(p, np.int64)].sum()) for p in par_li], np.int64)
+    k = min(batch_size, len(par_li))
+    n_max = int(np.sort(sizes)[-k:].sum())
+    nnz_max = int(np.sort(degs)[-k:].sum())
+    return n_max, nnz_max

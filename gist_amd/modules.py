@@ -1,0 +1,100 @@
+"""GraphSAGE model with the reference's module API (cluster_gcn/modules.py:191-314).
+
+`ISTSAGELayer` and `GCN` take the same constructor arguments, expose the same
+attributes (`layers[i].linear.weight / .bias`, `dropout`, `lynorm`, `activation`)
+and initialise their parameters with the same torch RNG calls in the same order
+(modules.py:201-203,213-216), so a script written against the reference runs
+unchanged and same-seed weights are identical.  forward() runs entirely on the
+HIP kernels through gist_amd.autograd.sage_layer.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import autograd
+
+
+def _is_relu(fn):
+    return fn is F.relu or fn is torch.relu or isinstance(fn, nn.ReLU)
+
+
+class ISTSAGELayer(nn.Module):
+    """mean-aggregate -> concat -> dropout -> Linear(2*in, out) -> LayerNorm(no affine) -> act."""
+
+    def __init__(self, in_feats, out_feats, dropout, use_lynorm, activation=None):
+        super().__init__()
+        # the input feature size doubles: [h | mean of in-neighbours]  (modules.py:199-201)
+        self.linear = nn.Linear(2 * in_feats, out_feats)
+        self.activation = activation
+        self.init_layer()
+        self.p_drop = float(dropout) if dropout else 0.0
+        self.dropout = nn.Dropout(p=dropout) if dropout else 0.
+        self.use_lynorm = bool(use_lynorm)
+        self.lynorm = (nn.LayerNorm(out_feats, elementwise_affine=False) if use_lynorm
+                       else (lambda x: x))
+        self.drop_seed = 0
+
+    def init_layer(self):
+        stdv = 1. / math.sqrt(self.linear.weight.size(1))          # modules.py:213-216
+        self.linear.weight.data.uniform_(-stdv, stdv)
+        self.linear.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, g, h):
+        act = self.activation
+        fused_relu = act is not None and _is_relu(act)
+        p = self.p_drop if (self.training and self.p_drop > 0.0) else 0.0
+        out = autograd.sage_layer(g, h, self.linear.weight, self.linear.bias, self.use_lynorm,
+                                  fused_relu, p, self.drop_seed)
+        if act is not None and not fused_relu:
+            out = act(out)
+        return out
+
+    def get_norm(self, g):
+        return g.norm().unsqueeze(1)
+
+
+class GCN(nn.Module):
+    """Layer sizing of the reference's GCN (modules.py:245-308)."""
+
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout,
+                 use_layernorm=True, split_input=False, split_output=False, num_subnet=1,
+                 use_aggregation=False):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.use_layernorm = use_layernorm
+        self.split_input = split_input
+        self.split_output = split_output
+        if not use_aggregation:
+            raise NotImplementedError('You must use graph sage')
+        layer_type = ISTSAGELayer
+        hs = int(n_hidden // num_subnet)
+        first_in = int(in_feats // num_subnet) if split_input else in_feats
+        if n_layers <= 1 and not split_output:
+            self.layers.append(layer_type(first_in, n_hidden, dropout, use_layernorm,
+                                          activation=activation))
+        else:
+            self.layers.append(layer_type(first_in, hs, dropout, use_layernorm,
+                                          activation=activation))
+        for i in range(n_layers - 1):
+            if i == n_layers - 2 and not split_output:
+                self.layers.append(layer_type(hs, n_hidden, dropout, use_layernorm,
+                                              activation=activation))
+            else:
+                self.layers.append(layer_type(hs, hs, dropout, use_layernorm,
+                                              activation=activation))
+        if split_output:
+            self.layers.append(layer_type(hs, n_classes, dropout, False, activation=None))
+        else:
+            self.layers.append(layer_type(n_hidden, n_classes, dropout, False, activation=None))
+
+    def set_dropout_seed(self, seed):
+        for k, layer in enumerate(self.layers):
+            layer.drop_seed = int(seed) * 1000003 + k
+
+    def forward(self, g):
+        h = g.ndata['feat']
+        for layer in self.layers:
+            h = layer(g, h)
+        return h

@@ -1,0 +1,36 @@
+"""Loss with the torch.nn call signature, computed by the HIP kernels.
+
+`CrossEntropyLoss()(logits, labels)` replaces torch.nn.CrossEntropyLoss as used at
+cluster_gcn/cluster_gcn_ist_distrib.py:384,411-414 and cluster_gcn/cluster_gcn.py:76,98-99.
+"""
+import torch
+
+from . import hip
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        n, c = logits.shape
+        logits = logits if logits.stride(-1) == 1 else logits.contiguous()
+        lab = labels.to(torch.int32).contiguous()
+        dl = torch.empty(n, c, dtype=torch.float32, device=logits.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        row = torch.empty(n, dtype=torch.float32, device=logits.device)
+        hip.softmax_xent(logits, lab, None, n, row, loss, dl)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Mean cross entropy over the rows given (reduction='mean', no class weights)."""
+
+    def forward(self, logits, labels):
+        if logits.shape[0] == 0:
+            raise ValueError('gist_amd: CrossEntropyLoss over zero rows')
+        return _SoftmaxXent.apply(logits, labels)

@@ -1,0 +1,161 @@
+"""Cluster batch source with the reference's ClusterIter API (cluster_gcn/sampler.py:11-93,
+cluster_gcn/partition_utils.py:11-25), device resident.
+
+Same constructor arguments, same iteration protocol, and -- crucially -- the same
+consumption of python's global `random` stream (one shuffle at construction,
+sampler.py:55, one at the end of every epoch, :92), so batch order is identical to
+the reference for the same seed and partition list.
+
+Differences, all on the MI355X side of the boundary:
+  * the train-induced graph (sampler.py:34) is extracted ON the GPU and stays there
+    together with its features and labels;
+  * a batch is the node-induced subgraph of the union of `batch_size` parts
+    (partition_utils.py:20-25), built by HIP kernels from the resident graph -- the
+    reference does this on the CPU inside the timed loop and uploads the result;
+  * METIS is not bundled: partition lists come from the reference's own cache file
+    `../data/{dn}_{psize}.npy` (sampler.py:44-51 format) or from `par_li=`.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import hip
+from .graph import Graph
+
+
+def load_partition_cache(path):
+    """Reader for the reference's cache: object array of int64 node-id arrays."""
+    arr = np.load(path, allow_pickle=True)
+    return [np.asarray(p, np.int64).reshape(-1) for p in arr]
+
+
+def save_partition_cache(path, par_li):
+    """Writer producing the same on-disk format (wraps the ragged list as dtype=object,
+    which numpy >= 1.24 requires)."""
+    arr = np.empty(len(par_li), dtype=object)
+    for i, p in enumerate(par_li):
+        arr[i] = np.asarray(p, np.int64)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.save(path, arr, allow_pickle=True)
+
+
+def get_partition_list(g, psize):
+    """partition_utils.py:11-18 -- needs METIS through DGL, which is not bundled."""
+    from .dgl_compat.transform import metis_partition
+    return metis_partition(g, psize)
+
+
+def get_subgraph(g, par_arr, i, psize, batch_size):
+    """partition_utils.py:20-25, on the device graph."""
+    parts = [par_arr[s] for s in range(i * batch_size, (i + 1) * batch_size) if s < psize]
+    return g.subgraph(np.concatenate(parts).reshape(-1).astype(np.int64))
+
+
+class ClusterIter(object):
+    """The partition sampler given a graph and a partition number (sampler.py:11-56)."""
+
+    def __init__(self, dn, g, psize, batch_size, seed_nid, use_pp=False, par_li=None,
+                 device=None):
+        if use_pp:
+            raise NotImplementedError(
+                'gist_amd: use_pp doubles the feature width after in_feats was read and cannot '
+                'work with GCN/ISTSAGELayer in the reference either (SURVEY.md appendix C.8)')
+        self.use_pp = use_pp
+        if device is None:
+            device = g.device if g.device.type == 'cuda' else torch.device(
+                'cuda', torch.cuda.current_device())
+        gd = g if g.device == device else g.to(device)
+        if torch.is_tensor(seed_nid):
+            seed_nid = seed_nid.cpu().numpy()
+        self.g = gd.subgraph(np.asarray(seed_nid, np.int64))         # sampler.py:34
+        self.psize = psize
+        self.batch_size = batch_size
+        if par_li is not None:
+            self.par_li = [np.asarray(p, np.int64).reshape(-1) for p in par_li]
+        elif dn:
+            fn = os.path.join('../data/', dn + '_{}.npy'.format(psize))   # sampler.py:45
+            if os.path.exists(fn):
+                self.par_li = load_partition_cache(fn)
+            else:
+                self.par_li = get_partition_list(self.g, psize)
+                save_partition_cache(fn, self.par_li)
+        else:
+            self.par_li = get_partition_list(self.g, psize)
+        self.max = int((psize) // batch_size)                        # sampler.py:54
+        random.shuffle(self.par_li)                                  # sampler.py:55
+        self.get_fn = get_subgraph
+        self.n = 0
+
+    def __len__(self):
+        return self.max
+
+    def __iter__(self):
+        self.n = 0
+        return self
+
+    def batch_ids(self, i):
+        parts = [self.par_li[s] for s in range(i * self.batch_size, (i + 1) * self.batch_size)
+                 if s < self.psize]
+        return np.concatenate(parts).reshape(-1).astype(np.int64)
+
+    def __next__(self):
+        if self.n < self.max:
+            result = self.get_fn(self.g, self.par_li, self.n, self.psize, self.batch_size)
+            self.n += 1
+            return result
+        random.shuffle(self.par_li)                                  # sampler.py:92
+        raise StopIteration
+
+
+class EngineClusterIter(ClusterIter):
+    """ClusterIter that feeds a SageEngine: yields engine Batches built in preallocated
+    device buffers.  The epoch's part order is uploaded ONCE per epoch (one H2D of the
+    permuted node ids); every batch is then a slice of that device array, so the
+    training loop performs no per-iteration host<->device traffic."""
+
+    def __init__(self, dn, g, psize, batch_size, seed_nid, engine_in_feats=None, **kw):
+        super().__init__(dn, g, psize, batch_size, seed_nid, **kw)
+        from .engine import ClusterBatcher, batch_capacity
+        tg = self.g
+        rowptr_host = tg.rowptr.cpu().numpy()
+        self.n_max, self.nnz_max = batch_capacity(rowptr_host, self.par_li, batch_size)
+        feat = tg.ndata['feat']
+        lab = tg.ndata['label']
+        if lab.dtype != torch.int32:
+            lab = lab.to(torch.int32)
+        self.batcher = ClusterBatcher(tg, feat.contiguous(), lab.contiguous(), self.n_max,
+                                      self.nnz_max)
+        self.engine = None
+        self._epoch_ids = None
+        self._offsets = None
+
+    def bind(self, engine):
+        self.engine = engine
+        return self
+
+    def _upload_epoch(self):
+        used = self.par_li[:self.max * self.batch_size]
+        sizes = np.array([len(p) for p in used], np.int64)
+        ids = np.concatenate(used).astype(np.int32) if len(used) else np.zeros(0, np.int32)
+        off = np.zeros(self.max + 1, np.int64)
+        per_batch = sizes.reshape(self.max, self.batch_size).sum(1) if self.max else sizes[:0]
+        np.cumsum(per_batch, out=off[1:])
+        self._epoch_ids = torch.from_numpy(ids).to(self.g.device, non_blocking=False)
+        self._offsets = off
+
+    def __iter__(self):
+        self.n = 0
+        self._upload_epoch()
+        return self
+
+    def __next__(self):
+        if self.n < self.max:
+            a, b = int(self._offsets[self.n]), int(self._offsets[self.n + 1])
+            ids = self._epoch_ids[a:b]
+            batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
+            self.n += 1
+            return batch
+        random.shuffle(self.par_li)
+        raise StopIteration
