@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- epochs/sec of GIST's training hot path on MI355X, Reddit-like synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric: "epochs/sec + SpMM GB/s, Reddit 4096-wide GraphSAGE at
+1/2/4/8 GPUs"):
+  * graph: Reddit-like block model, N_train=153431, F=602, C=41, 1500 parts, batch = 20
+    parts (~2046 rows, ~1.3e5 in-batch edges), 75 steps per epoch; synthetic, seed 0
+  * model: GraphSAGE n_hidden=4096, n_layers=2 (3 SAGE layers), LayerNorm, dropout 0.2,
+    Adam lr 0.01 -- fp32 end to end
+  * N = 1: the full-width model on one GPU (the cluster_gcn.py path, which is what the
+    reference's sweeps use for the 1-GPU point)
+  * N > 1: GIST with S = N sub-GCNs of width 4096/N, one per GPU, weight sync every 100
+    iterations through one RCCL all-gather (cluster_gcn_ist_distrib.py path)
+A step = batch extraction (on device) + forward + CE + backward + Adam on one cluster
+batch, plus the sync/dispatch work that falls on that iteration.  An epoch = 75 steps;
+under GIST every rank trains n_epochs/S epochs (cluster_gcn_ist_distrib.py:385), so the
+job's throughput is the SUM of the ranks' epochs/sec ("weak": per-GPU batch stream fixed).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fp32-MFMA GEMM),
+`roofline_spmm` (the SpMM against HBM), `cpu_baseline` (the oracle timed on host cores).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_EPOCH = 75
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=150)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--n-hidden', type=int, default=4096)
+    ap.add_argument('--n-layers', type=int, default=2)
+    ap.add_argument('--dropout', type=float, default=0.2)
+    ap.add_argument('--iter-per-site', type=int, default=100)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--no-kernel-timing', action='store_true',
+                    help='skip HIP-event bracketing of SpMM/GEMM launches')
+    return ap.parse_args()
+
+
+def cpu_baseline(ds, par_order, dims, use_layernorm, n_steps, seed):
+    """The oracle (oracle/gist_oracle.py, numpy + OpenBLAS + OpenMP C SpMM) on the host
+    cores, same workload: first `n_steps` batches of the epoch, full step each."""
+    from oracle import gist_oracle as O
+    from oracle import train_oracle as TO
+    g = ds.g
+    rp = g.rowptr.numpy().astype(np.int64)
+    cl = g.col.numpy().astype(np.int64)
+    tg = TO.TrainGraph(rp, cl, g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
+    rs = np.random.RandomState(seed)
+    params = []
+    for (i, o) in dims:
+        stdv = 1.0 / np.sqrt(2 * i)
+        params.append((rs.uniform(-stdv, stdv, (o, 2 * i)).astype(np.float32),
+                       rs.uniform(-stdv, stdv, o).astype(np.float32)))
+    opt = O.new_opt_state(params)
+    times = []
+    for j in range(n_steps + 1):
+        ids = np.concatenate(par_order[j * 20:(j + 1) * 20]).astype(np.int64)
+        t0 = time.time()
+        rpb, clb, trp, tcl, x, y = tg.batch(ids)
+        O.train_step(rpb, clb, trp, tcl, x, y, params, opt, use_layernorm, 0.01)
+        times.append(time.time() - t0)
+    step = float(np.median(times[1:]))           # first step = warm-up
+    return step
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
+                             '--nproc-per-node %d' % (args.gpus, args.gpus))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+
+    from gist_amd import datasets, hip
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+
+    seed = 0
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    ds = datasets.reddit_synth(seed=0)
+    g = ds.g
+    in_feats, n_classes = g.ndata['feat'].shape[1], ds.num_classes
+    train_nid = np.arange(g.number_of_nodes(), dtype=np.int64)
+    psize, batch_size = len(ds.par_li), 20
+    S = world
+    H, L = args.n_hidden, args.n_layers
+    assert H % S == 0
+
+    it = EngineClusterIter('reddit-synth', g, psize, batch_size, train_nid,
+                           par_li=[p.copy() for p in ds.par_li], device=dev)
+    first_epoch_order = [p.copy() for p in it.par_li]
+    use_ln = True
+    if S == 1:
+        dims = dims_for(in_feats, H, n_classes, L)
+        engine = SageEngine(dims, use_ln, args.dropout, it.n_max, dev, seed=seed)
+        rs = np.random.RandomState(seed)
+        for k, (i, o) in enumerate(dims):
+            stdv = 1.0 / np.sqrt(2 * i)               # modules.py:213-216
+            engine.arena.W[k].copy_(torch.from_numpy(
+                rs.uniform(-stdv, stdv, (o, 2 * i)).astype(np.float32)))
+            engine.arena.b[k].copy_(torch.from_numpy(rs.uniform(-stdv, stdv, o).astype(np.float32)))
+        ist_model = None
+    else:
+        from gist_amd import ist
+        ns = argparse.Namespace(num_subnet=S, n_hidden=H, n_layers=L, rank=rank,
+                                dropout=args.dropout, use_layernorm=use_ln, lr=0.01,
+                                weight_decay=0.0, iter_per_site=args.iter_per_site)
+        base_init = None
+        if rank == 0:
+            rs = np.random.RandomState(seed)
+            base_init = []
+            for (i, o) in dims_for(in_feats, H, n_classes, L):
+                stdv = 1.0 / np.sqrt(2 * i)
+                base_init.append((rs.uniform(-stdv, stdv, (o, 2 * i)).astype(np.float32),
+                                  rs.uniform(-stdv, stdv, o).astype(np.float32)))
+        ist_model = ist.DistributedGNNWrapper(ns, None, in_feats, n_classes, dev,
+                                              base_init=base_init, n_max=it.n_max, seed=seed)
+        ist_model.ini_sync_dispatch_model()
+        engine = ist_model.engine
+        dims = ist_model.sub_dims
+    it.bind(engine)
+    lr = 0.01
+
+    nnz_log = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int32, device=dev)
+    n_log = []
+    state = dict(total_iter=0, epoch=0)
+
+    def batches():
+        while True:
+            for b in it:
+                yield b
+            state['epoch'] += 1
+
+    gen = batches()
+
+    def run_steps(count, log_from=None):
+        for s in range(count):
+            b = next(gen)
+            ti = state['total_iter']
+            if ist_model is not None and ti % args.iter_per_site == 0:
+                if state['epoch'] > 0:                       # no re-dispatch in epoch 0 (:401-403)
+                    ist_model.dispatch_model()
+                ist_model.sub.reset_optimizer()              # fresh Adam (:405-407)
+            engine.train_step(b, lr, 0.0)
+            if log_from is not None:
+                nnz_log[log_from + s:log_from + s + 1].copy_(b.rowptr[b.n:b.n + 1])
+                n_log.append(b.n)
+            state['total_iter'] = ti + 1
+            if ist_model is not None and state['total_iter'] % args.iter_per_site == 0:
+                ist_model.sync_model()                       # :422-427
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run_steps(args.warmup)
+    fence()
+    timing = not args.no_kernel_timing
+    if timing:
+        hip.profile_begin()
+    t0 = time.time()
+    run_steps(args.steps, log_from=0)
+    fence()
+    elapsed = time.time() - t0
+    prof = hip.profile_end() if timing else None
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    loss_val = float(engine.loss.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        # every rank runs `steps` iterations of its own sub-GCN: S * steps / 75 epochs of work
+        value = world * args.steps / STEPS_PER_EPOCH / elapsed
+        out = {
+            'metric': 'epochs/sec', 'value': round(value, 4), 'unit': 'epochs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': 'Reddit-like synthetic (N_train=153431, F=602, C=41, 1500 parts, '
+                            'batch=20 parts, 75 steps/epoch); GraphSAGE n_hidden=%d n_layers=%d '
+                            'LayerNorm dropout=%.2f Adam lr=0.01; %s' % (
+                                H, L, args.dropout,
+                                'full-width model on 1 GPU (cluster_gcn.py path)' if S == 1 else
+                                'GIST %d sub-GCNs of width %d, sync every %d iters via one RCCL '
+                                'all-gather (cluster_gcn_ist_distrib.py path)'
+                                % (S, H // S, args.iter_per_site)),
+                'n_hidden': H, 'n_layers': L, 'num_subnet': S, 'batch_parts': batch_size,
+                'psize': psize, 'steps_per_epoch': STEPS_PER_EPOCH,
+                'epochs_per_sec_per_rank': round(value / world, 4),
+            },
+            'final_loss': round(loss_val, 5),
+        }
+        if prof is not None:
+            nnz = nnz_log[:args.steps].cpu().numpy().astype(np.int64)
+            gem = prof['gemm']
+            g_ms = sum(ms for ms, _ in gem)
+            g_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in gem)
+            ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+            out['roofline'] = {
+                'kernel': 'gist::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; NT/NN/TN)',
+                'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                'traffic': None, 'launches': len(gem),
+                'avg_launch_ms': round(g_ms / max(len(gem), 1), 5),
+                'share_of_step': round(g_ms / (elapsed * 1e3), 4),
+            }
+            sp = prof['spmm']
+            per_step = len(sp) // max(args.steps, 1)
+            s_ms = sum(ms for ms, _ in sp)
+            s_bytes = 0.0
+            for idx, (ms, (n, n_src, d)) in enumerate(sp):
+                z = int(nnz[min(idx // max(per_step, 1), args.steps - 1)])
+                s_bytes += 4.0 * (n + 1) + 4.0 * z + 4.0 * n_src * d + 4.0 * n * d
+            s_ach = s_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
+            traffic = None
+            tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+                except Exception:
+                    traffic = None
+            out['roofline_spmm'] = {
+                'kernel': 'gist::spmm_csr_kernel', 'bound': 'hbm', 'achieved': round(s_ach, 2),
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
+                'traffic': traffic, 'launches': len(sp),
+                'avg_launch_ms': round(s_ms / max(len(sp), 1), 5),
+                'avg_algorithmic_bytes': round(s_bytes / max(len(sp), 1), 1),
+                'share_of_step': round(s_ms / (elapsed * 1e3), 4),
+                'mean_batch_rows': round(float(np.mean(n_log)), 1),
+                'mean_batch_nnz': round(float(nnz.mean()), 1),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                step_s = cpu_baseline(ds, first_epoch_order, dims, use_ln, args.cpu_steps, seed)
+                out['cpu_baseline'] = {
+                    'value': round(1.0 / (STEPS_PER_EPOCH * step_s), 6), 'unit': 'epochs/s',
+                    'cores': os.cpu_count(), 'kind': 'port',
+                    'sample': 'oracle (numpy/OpenBLAS + OpenMP C SpMM) full training step on the '
+                              'first %d batches of the same workload after 1 warm-up step, '
+                              'median %.3f s/step, dropout off' % (args.cpu_steps, step_s),
+                }
+            except Exception as e:                          # report, never fake
+                out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

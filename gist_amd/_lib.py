@@ -70,6 +70,11 @@ def load():
         raise GistLibraryError(
             'gist_amd: %s is missing. Build it with `python gist_amd/build.py` '
             '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of this process
+    # (buffers and streams come from torch), so make sure it is mapped before our library
+    # resolves the same soname -- loading ours first would pull in /opt/rocm's runtime and
+    # leave the process with a runtime torch's HSA layer cannot drive.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:

@@ -29,7 +29,7 @@ def _round_up(x, m):
 class ParamArena(object):
     """Flat parameter / gradient / Adam-moment storage with per-layer views."""
 
-    def __init__(self, dims, device):
+    def __init__(self, dims, device, with_grads=True):
         self.dims = list(dims)
         self.offsets = []
         off = 0
@@ -39,15 +39,18 @@ class ParamArena(object):
         self.numel = off
         self.device = device
         self.params = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
-        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
-        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.W, self.b, self.dW, self.db = [], [], [], []
         for (i, o), (w0, b0) in zip(self.dims, self.offsets):
             self.W.append(self.params[w0:b0].view(o, 2 * i))
             self.b.append(self.params[b0:b0 + o])
-            self.dW.append(self.grads[w0:b0].view(o, 2 * i))
-            self.db.append(self.grads[b0:b0 + o])
+        self.grads = self.exp_avg = self.exp_avg_sq = None
+        if with_grads:          # a base-model replica (IST) holds parameters only
+            self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+            self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
+            self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+            for (i, o), (w0, b0) in zip(self.dims, self.offsets):
+                self.dW.append(self.grads[w0:b0].view(o, 2 * i))
+                self.db.append(self.grads[b0:b0 + o])
         self.step = 0
 
     def reset_optimizer(self):

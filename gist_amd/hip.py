@@ -16,6 +16,42 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# -- optional per-kernel timing with HIP events on the launch stream (bench.py) ------
+_prof = None
+
+
+def profile_begin():
+    """Start recording (start, end) events around every SpMM / GEMM launch."""
+    global _prof
+    _prof = {'gemm': [], 'spmm': []}
+
+
+def profile_end():
+    """Stop recording; returns {'gemm': [(ms, meta)], 'spmm': [(ms, meta)]} (synchronises)."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return {k: [(a.elapsed_time(b), meta) for (a, b, meta) in v] for k, v in rec.items()}
+
+
+class _Timed(object):
+    def __init__(self, kind, meta):
+        self.kind, self.meta = kind, meta
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.b.record()
+            _prof[self.kind].append((self.a, self.b, self.meta))
+        return False
+
+
 def _dev(t, name, dtype):
     if not torch.is_tensor(t):
         raise TypeError('%s must be a tensor' % name)
@@ -74,11 +110,13 @@ def spmm(rowptr, col, x, y, out_scale=None, src_scale=None, accumulate=False):
     d = x.shape[1]
     if y.shape[0] != n or y.shape[1] != d:
         raise ValueError('gist_amd: spmm output shape %s != (%d, %d)' % (tuple(y.shape), n, d))
-    _lib.check(L.gist_spmm_csr_f32(_vec(rowptr, 'rowptr', torch.int32),
-                                   _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n, d,
-                                   _opt(out_scale, 'out_scale', torch.float32, n),
-                                   _opt(src_scale, 'src_scale', torch.float32, x.shape[0]),
-                                   int(bool(accumulate)), _stream()), 'gist_spmm_csr_f32')
+    with _Timed('spmm', (n, x.shape[0], d)):
+        rc = L.gist_spmm_csr_f32(_vec(rowptr, 'rowptr', torch.int32),
+                                 _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n, d,
+                                 _opt(out_scale, 'out_scale', torch.float32, n),
+                                 _opt(src_scale, 'src_scale', torch.float32, x.shape[0]),
+                                 int(bool(accumulate)), _stream())
+    _lib.check(rc, 'gist_spmm_csr_f32')
     return y
 
 
@@ -116,8 +154,10 @@ def gemm_nt(a, w, bias, y):
     if w.shape[1] != k or tuple(y.shape) != (m, n):
         raise ValueError('gist_amd: gemm_nt shape mismatch')
     wsp, wsb = _ws_for(m, n, k, a.device)
-    _lib.check(L.gist_gemm_nt_f32(ap, lda, wp, ldw, _opt(bias, 'bias', torch.float32, n), yp, ldy,
-                                  m, n, k, wsp, wsb, _stream()), 'gist_gemm_nt_f32')
+    with _Timed('gemm', ('nt', m, n, k)):
+        rc = L.gist_gemm_nt_f32(ap, lda, wp, ldw, _opt(bias, 'bias', torch.float32, n), yp, ldy,
+                                m, n, k, wsp, wsb, _stream())
+    _lib.check(rc, 'gist_gemm_nt_f32')
     return y
 
 
@@ -132,8 +172,9 @@ def gemm_nn(g, w, z):
     if w.shape[0] != k or tuple(z.shape) != (m, n):
         raise ValueError('gist_amd: gemm_nn shape mismatch')
     wsp, wsb = _ws_for(m, n, k, g.device)
-    _lib.check(L.gist_gemm_nn_f32(gp, ldg, wp, ldw, zp, ldz, m, n, k, wsp, wsb, _stream()),
-               'gist_gemm_nn_f32')
+    with _Timed('gemm', ('nn', m, n, k)):
+        rc = L.gist_gemm_nn_f32(gp, ldg, wp, ldw, zp, ldz, m, n, k, wsp, wsb, _stream())
+    _lib.check(rc, 'gist_gemm_nn_f32')
     return z
 
 
@@ -148,8 +189,9 @@ def gemm_tn(g, a, d):
     if a.shape[0] != k or tuple(d.shape) != (m, n):
         raise ValueError('gist_amd: gemm_tn shape mismatch')
     wsp, wsb = _ws_for(m, n, k, g.device)
-    _lib.check(L.gist_gemm_tn_f32(gp, ldg, ap, lda, dp, ldd, m, n, k, wsp, wsb, _stream()),
-               'gist_gemm_tn_f32')
+    with _Timed('gemm', ('tn', m, n, k)):
+        rc = L.gist_gemm_tn_f32(gp, ldg, ap, lda, dp, ldd, m, n, k, wsp, wsb, _stream())
+    _lib.check(rc, 'gist_gemm_tn_f32')
     return d
 
 
