@@ -44,37 +44,86 @@ struct GemmArgs {
     const float *bias;
     float *c; int64_t ldc;
     int m, n, k;
-    int a_vec, b_vec;      // 16-B loads allowed for the operand
     int tiles_m, tiles_n;
     int k_per_split;       // multiple of BK
     int64_t split_stride;  // elements between split slabs (0 = write C directly)
 };
 
 // ---- global -> register staging --------------------------------------------
+// Two loaders per image.  The ALIGNED one (16-B aligned base, ld % 4 == 0) is branch
+// free: hipcc turns a per-load `if (in range) load` into a branch plus an
+// s_waitcnt per load, which serialises the eight loads of a k tile.  Instead
+//   * the NON-reduction coordinate (row of a k-contiguous image, column of an
+//     m/n-contiguous image) is CLAMPED to a readable address: whatever is loaded
+//     there only ever reaches output rows/columns >= m/n, which are never stored;
+//   * the REDUCTION coordinate k is masked with selects (0 beyond k_end), so nothing
+//     out of range enters a dot product.
+// A 16-B chunk that straddles the end of a row is still inside the row's pitch
+// because ld >= round_up(extent, 4) whenever ld % 4 == 0.
+// The generic loader (any alignment) keeps per-element guards.
+
 // k-contiguous operand: element (r, kk) at p[r*ld + kk].  256 threads move
 // 128 rows x 32 k = 1024 float4: thread t -> rows t/8 + 32 i, k chunk t%8.
-__device__ __forceinline__ void load_kc(const float *__restrict__ p, int64_t ld, int rows, int kdim,
-                                        int row0, int k0, int vec, float4 (&st)[4]) {
+__device__ __forceinline__ void load_kc_aligned(const float *__restrict__ p, int64_t ld, int rows,
+                                                int kdim, int row0, int k0, float4 (&st)[4]) {
     const int t = threadIdx.x;
-    const int kq = (t & 7) * 4;
+    const int kk = k0 + (t & 7) * 4;
+    const int kc = min(kk, (int)ld - 4);           // stays inside the row pitch
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = min(row0 + (t >> 3) + 32 * i, rows - 1);
+        st[i] = *reinterpret_cast<const float4 *>(p + (int64_t)r * ld + kc);
+    }
+}
+
+// Reduction-dimension mask of the aligned loaders, applied when the registers are
+// written to LDS -- i.e. AFTER the MFMA block -- so that the loads stay in flight
+// under the MFMAs instead of being waited for right after issue.
+__device__ __forceinline__ void mask_kc(float4 (&st)[4], int kdim, int k0) {
+    const int kk = k0 + (threadIdx.x & 7) * 4;
+    if (kk + 3 < kdim) return;
+    const bool k0ok = kk + 0 < kdim, k1ok = kk + 1 < kdim, k2ok = kk + 2 < kdim;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        st[i].x = k0ok ? st[i].x : 0.f;
+        st[i].y = k1ok ? st[i].y : 0.f;
+        st[i].z = k2ok ? st[i].z : 0.f;
+        st[i].w = 0.f;
+    }
+}
+
+__device__ __forceinline__ void mask_mc(float4 (&st)[4], int kdim, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kk = k0 + (threadIdx.x >> 5) + 8 * i;
+        if (kk >= kdim) st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void load_kc_generic(const float *__restrict__ p, int64_t ld, int rows,
+                                                int kdim, int row0, int k0, float4 (&st)[4]) {
+    const int t = threadIdx.x;
+    const int kk = k0 + (t & 7) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + (t >> 3) + 32 * i;
-        const int kk = k0 + kq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows) {
             const float *src = p + (int64_t)r * ld + kk;
-            if (vec && kk + 3 < kdim) {
-                v = *reinterpret_cast<const float4 *>(src);
-            } else {
-                if (kk + 0 < kdim) v.x = src[0];
-                if (kk + 1 < kdim) v.y = src[1];
-                if (kk + 2 < kdim) v.z = src[2];
-                if (kk + 3 < kdim) v.w = src[3];
-            }
+            if (kk + 0 < kdim) v.x = src[0];
+            if (kk + 1 < kdim) v.y = src[1];
+            if (kk + 2 < kdim) v.z = src[2];
+            if (kk + 3 < kdim) v.w = src[3];
         }
         st[i] = v;
     }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void load_kc(const float *__restrict__ p, int64_t ld, int rows, int kdim,
+                                        int row0, int k0, float4 (&st)[4]) {
+    if constexpr (ALIGNED) load_kc_aligned(p, ld, rows, kdim, row0, k0, st);
+    else load_kc_generic(p, ld, rows, kdim, row0, k0, st);
 }
 
 __device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&st)[4]) {
@@ -89,8 +138,19 @@ __device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&s
 
 // m/n-contiguous operand: element (kk, c) at p[kk*ld + c].  32 k x 128 cols:
 // thread t -> k rows t/32 + 8 i, column chunk t%32.
-__device__ __forceinline__ void load_mc(const float *__restrict__ p, int64_t ld, int cols, int kdim,
-                                        int col0, int k0, int vec, float4 (&st)[4]) {
+__device__ __forceinline__ void load_mc_aligned(const float *__restrict__ p, int64_t ld, int cols,
+                                                int kdim, int col0, int k0, float4 (&st)[4]) {
+    const int t = threadIdx.x;
+    const int cq = min(col0 + (t & 31) * 4, (int)ld - 4);   // clamp inside the row pitch
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kk = k0 + (t >> 5) + 8 * i;
+        st[i] = *reinterpret_cast<const float4 *>(p + (int64_t)min(kk, kdim - 1) * ld + cq);
+    }
+}
+
+__device__ __forceinline__ void load_mc_generic(const float *__restrict__ p, int64_t ld, int cols,
+                                                int kdim, int col0, int k0, float4 (&st)[4]) {
     const int t = threadIdx.x;
     const int cq = col0 + (t & 31) * 4;
 #pragma unroll
@@ -99,17 +159,20 @@ __device__ __forceinline__ void load_mc(const float *__restrict__ p, int64_t ld,
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kk < kdim) {
             const float *src = p + (int64_t)kk * ld + cq;
-            if (vec && cq + 3 < cols) {
-                v = *reinterpret_cast<const float4 *>(src);
-            } else {
-                if (cq + 0 < cols) v.x = src[0];
-                if (cq + 1 < cols) v.y = src[1];
-                if (cq + 2 < cols) v.z = src[2];
-                if (cq + 3 < cols) v.w = src[3];
-            }
+            if (cq + 0 < cols) v.x = src[0];
+            if (cq + 1 < cols) v.y = src[1];
+            if (cq + 2 < cols) v.z = src[2];
+            if (cq + 3 < cols) v.w = src[3];
         }
         st[i] = v;
     }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void load_mc(const float *__restrict__ p, int64_t ld, int cols, int kdim,
+                                        int col0, int k0, float4 (&st)[4]) {
+    if constexpr (ALIGNED) load_mc_aligned(p, ld, cols, kdim, col0, k0, st);
+    else load_mc_generic(p, ld, cols, kdim, col0, k0, st);
 }
 
 __device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&st)[4]) {
@@ -140,7 +203,9 @@ __device__ __forceinline__ float f4(const float4 &v, int j) {
     return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
 }
 
-template <bool A_KC, bool B_KC>
+// ALIGNED: both operands have 16-B aligned bases and leading dimensions % 4 == 0
+// (every buffer the engine allocates); otherwise the generic guarded loader runs.
+template <bool A_KC, bool B_KC, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TA = A_KC ? TILE_KC : TILE_MC;
@@ -181,21 +246,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     float4 stA[4], stB[4];
     auto gload = [&](int kt) {
         const int k0 = k_begin + kt * BK;
-        if constexpr (A_KC) load_kc(g.a, g.lda, g.m, k_end, row0, k0, g.a_vec, stA);
-        else load_mc(g.a, g.lda, g.m, k_end, row0, k0, g.a_vec, stA);
-        if constexpr (B_KC) load_kc(g.b, g.ldb, g.n, k_end, col0, k0, g.b_vec, stB);
-        else load_mc(g.b, g.ldb, g.n, k_end, col0, k0, g.b_vec, stB);
+        if constexpr (A_KC) load_kc<ALIGNED>(g.a, g.lda, g.m, k_end, row0, k0, stA);
+        else load_mc<ALIGNED>(g.a, g.lda, g.m, k_end, row0, k0, stA);
+        if constexpr (B_KC) load_kc<ALIGNED>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
+        else load_mc<ALIGNED>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int kt) {
         float *sa = smem + buf * (TA + TB);
         float *sb = sa + TA;
+        if constexpr (ALIGNED) {
+            const int k0 = k_begin + kt * BK;
+            if (k0 + BK > k_end) {            // only the last k tile of a split can be ragged
+                if constexpr (A_KC) mask_kc(stA, k_end, k0); else mask_mc(stA, k_end, k0);
+                if constexpr (B_KC) mask_kc(stB, k_end, k0); else mask_mc(stB, k_end, k0);
+            }
+        }
         if constexpr (A_KC) store_kc(sa, stA); else store_mc(sa, stA);
         if constexpr (B_KC) store_kc(sb, stB); else store_mc(sb, stB);
     };
 
     if (n_kt > 0) {
         gload(0);
-        sstore(0);
+        sstore(0, 0);
     }
     __syncthreads();
 
@@ -203,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         const int cur = kt & 1;
         const bool more = kt + 1 < n_kt;
         if (more) gload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);      // loads are issued; keep their consumers below
         const float *a_s = smem + cur * (TA + TB);
         const float *b_s = a_s + TA;
 #pragma unroll
@@ -221,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             f4(af[i], s), f4(bf[j], s), acc[i][j], 0, 0, 0);
         }
-        if (more) sstore(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);      // nothing of the store phase moves above the MFMAs
+        if (more) sstore(cur ^ 1, kt + 1);
         __syncthreads();
     }
 
@@ -281,8 +355,8 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     GemmArgs g;
     g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.c = c; g.ldc = ldc;
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
-    g.a_vec = aligned16(a) && (lda % 4 == 0);
-    g.b_vec = aligned16(b) && (ldb % 4 == 0);
+    const bool aligned = aligned16(a) && (lda % 4 == 0) && lda >= 4 && aligned16(b) &&
+                         (ldb % 4 == 0) && ldb >= 4 && k > 0;
     g.tiles_m = (int)ceil_div(m, BM);
     g.tiles_n = (int)ceil_div(n, BN);
     int splits = choose_splits(m, n, k);
@@ -297,8 +371,12 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC>),
+            reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, false>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return GIST_ELAUNCH;
@@ -306,16 +384,22 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
         attr_set = true;
     }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
+    auto launch = [&]() {
+        if (aligned)
+            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, dim3(256), smem, st, g);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, dim3(256), smem, st, g);
+    };
     if (splits == 1) {
         g.split_stride = 0;
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), smem, st, g);
+        launch();
         return launch_status(name);
     }
     g.c = static_cast<float *>(ws);
     g.ldc = n;
     g.split_stride = m * n;
     g.bias = nullptr;
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), smem, st, g);
+    launch();
     int rc = launch_status(name);
     if (rc) return rc;
     const int64_t total = m * n;
