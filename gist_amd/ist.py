@@ -220,14 +220,19 @@ class DistributedGNNWrapper(object):
         self._gather_own()
 
     # -- sync --------------------------------------------------------------------------
-    def sync_model(self):
-        """:100-195.  One all-gather of the flat sub arenas, then index scatters into the
-        local base replica; the shared last bias becomes the mean over sites (:103)."""
+    def sync_gather(self):
+        """Phase 1 of sync_model: collect every site's flat sub arena (the one collective)."""
         P = self.sub.numel
         if self.comm.world_size() > 1:
             self.comm.all_gather_flat(self.gathered, self.sub.params)
         else:
             self.gathered[:P].copy_(self.sub.params)
+
+    def sync_apply(self):
+        """Phase 2: index-scatter all S sites' blocks into the local base replica; the
+        shared last bias becomes the mean over sites (:103) -- also in the sub-model,
+        as the reference's in-place all-reduce does."""
+        P = self.sub.numel
         L = self.L
         for s in range(self.S):
             site = self.gathered[s * P:(s + 1) * P]
@@ -244,51 +249,72 @@ class DistributedGNNWrapper(object):
         self.blocks.mean_rows(self.gathered[b0:], P, self.S, C, self.base.b[L])
         self.sub.b[L].copy_(self.base.b[L])
 
+    def sync_model(self):
+        """:100-195.  One all-gather of the flat sub arenas, then on-device scatters."""
+        self.sync_gather()
+        self.sync_apply()
+
 
 def train(ist_model, args, cluster_iterator, evaluator=None, log=print):
     """The GIST loop, cluster_gcn_ist_distrib.py:370-479, on the engine fast path.
 
-    `cluster_iterator` is an EngineClusterIter bound to ist_model.engine; `evaluator`
-    (rank 0 only) exposes accuracy(mask_name) on the base replica.  Returns a dict with
-    total_time, per-iteration device losses, val/test accuracies and the event log."""
-    comm = ist_model.comm
-    eng = ist_model.engine
-    multi = comm.world_size() > 1
+    `ist_model` is this rank's DistributedGNNWrapper -- or a LIST of S wrappers sharing a
+    LocalCommGroup, in which case all sites run in this one process on one GPU (the
+    reference's own launcher puts every rank on `--cuda-id 0`); the partition is then
+    sampled once per dispatch, exactly one `random` stream per process as in the reference.
+    `cluster_iterator` is an EngineClusterIter bound to the first wrapper's engine;
+    `evaluator` (rank 0) exposes accuracy(mask_name) on the base replica.
+    Returns total_time, per-site per-iteration device losses, accuracies, event log."""
+    models = list(ist_model) if isinstance(ist_model, (list, tuple)) else [ist_model]
+    local = len(models) > 1
+    comm = models[0].comm
+    multi = (not local) and comm.world_size() > 1
+    is_rank0 = models[0].rank == 0
     local_epochs = args.n_epochs // args.num_subnet                      # :385
-    losses, events, val_accs, test_accs = [], [], [], []
+    losses = [[] for _ in models]
+    events, val_accs, test_accs = [], [], []
     total_iter, total_time = 0, 0.0
     n_iters = len(cluster_iterator)
-    dev = ist_model.device
+    dev = models[0].device
     sync_dev = (lambda: torch.cuda.synchronize(dev)) if dev.type == 'cuda' else (lambda: None)
     sync_dev()
     start_time = time.time()
     for e in range(local_epochs):
-        log('%d: running epoch %d / %d' % (args.rank, e, local_epochs))
+        log('%d: running epoch %d / %d' % (models[0].rank, e, local_epochs))
         run_eval = True
         for j, batch in enumerate(cluster_iterator):
             if total_iter % args.iter_per_site == 0:                     # :400
                 if e > 0:
                     if multi:
                         comm.barrier()
-                    ist_model.dispatch_model()                           # :401-403
+                    part = models[0].sample_partitions() if local else None
+                    for m in models:
+                        m.dispatch_model(part)                           # :401-403
                     events.append('dispatch')
-                ist_model.sub.reset_optimizer()                          # :404-407
-            loss = eng.train_step(batch, args.lr, args.weight_decay)     # :408-417
-            losses.append(loss.clone())
+                for m in models:
+                    m.sub.reset_optimizer()                              # :404-407
+            for si, m in enumerate(models):                              # :408-417
+                if si > 0:
+                    cluster_iterator.fill_features(batch, m.engine)
+                loss = m.engine.train_step(batch, args.lr, args.weight_decay)
+                losses[si].append(loss.clone())
             events.append('step')
             total_iter += 1
             last = (j == n_iters - 1) and (e == local_epochs - 1)
             if total_iter % args.iter_per_site == 0 or last:             # :422-427
                 if multi:
                     comm.barrier()
-                ist_model.sync_model()
+                for m in models:
+                    m.sync_gather()
+                for m in models:
+                    m.sync_apply()
                 events.append('sync')
                 if run_eval or last:                                     # :431-450
                     sync_dev()
                     total_time += time.time() - start_time
                     run_eval = False
                     events.append('eval')
-                    if args.rank == 0 and evaluator is not None:
+                    if is_rank0 and evaluator is not None:
                         val_accs.append(evaluator.accuracy('val_mask'))
                         test_accs.append(evaluator.accuracy('test_mask'))
                     sync_dev()

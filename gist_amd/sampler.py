@@ -135,6 +135,11 @@ class EngineClusterIter(ClusterIter):
         self.engine = engine
         return self
 
+    def fill_features(self, batch, engine):
+        """Gather the current batch's features into ANOTHER engine's layer-0 buffer (several
+        sub-GCNs trained in one process share one extracted batch)."""
+        hip.gather_rows(self.batcher.feat, batch.ids, engine.z0_left(batch.n))
+
     def _upload_epoch(self):
         used = self.par_li[:self.max * self.batch_size]
         sizes = np.array([len(p) for p in used], np.int64)

@@ -1,0 +1,181 @@
+"""GPU end to end: whole training runs on the HIP path against runs of the REFERENCE's
+own loops recorded in tests/golden/G6_e2e_*.npz
+  * cluster_gcn/cluster_gcn.py main()                -> ClusterGCNTrainer
+  * cluster_gcn/cluster_gcn_ist_distrib.py train()   -> gist_amd.ist.train with all S
+    sites in one process on one GPU (LocalCommGroup), HIP block kernels for sync/dispatch
+Checks per-iteration losses, base model after every sync, the event schedule (epoch-0
+no-redispatch quirk), accuracies.  1e-4 fp32."""
+import argparse
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = torch.device('cuda', 0)
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _params(d, prefix, n):
+    return [(d['%sW%d' % (prefix, k)], d['%sb%d' % (prefix, k)]) for k in range(n)]
+
+
+def _graph(d):
+    from gist_amd.graph import Graph
+    g = Graph.from_edges(d['src'], d['dst'], int(d['n']))
+    g.ndata['feat'] = torch.from_numpy(d['feat'])
+    g.ndata['label'] = torch.from_numpy(d['label'])
+    for m in ('train_mask', 'val_mask', 'test_mask'):
+        g.ndata[m] = torch.from_numpy(d[m])
+    return g
+
+
+def _parts(d):
+    return [d['part%d' % i] for i in range(int(d['psize']))]
+
+
+def test_e2e_single_gpu_cluster_gcn():
+    from gist_amd.trainer import ClusterGCNTrainer
+    d = np.load(os.path.join(GOLD, 'G6_e2e_single.npz'))
+    g = _graph(d)
+    L = int(d['n_layers'])
+    random.seed(int(d['rnd_seed']))
+    tr = ClusterGCNTrainer('toy', g, _parts(d), int(d['psize']), int(d['batch_size']),
+                           int(d['n_hidden']), L, int(d['n_classes']), 0.0, True, float(d['lr']),
+                           0.0, DEV, init_params=_params(d, 'init_', L + 1))
+    val_accs, test_accs = [], []
+    for e in range(int(d['n_epochs'])):
+        tr.timed_epoch()
+        for k, (W, b) in enumerate(tr.engine.arena.export()):
+            assert np.abs(W - d['ep%d_W%d' % (e, k)]).max() < TOL, (e, k)
+            assert np.abs(b - d['ep%d_b%d' % (e, k)]).max() < TOL, (e, k)
+        val_accs.append(tr.evaluate('val_mask'))
+        test_accs.append(tr.evaluate('test_mask'))
+    assert np.allclose(val_accs, d['val_accs'], atol=1e-6)
+    assert abs(val_accs[-1] - float(d['last_val'])) < 1e-4
+    assert abs(max(val_accs) - float(d['best_val'])) < 1e-4
+    assert abs(test_accs[-1] - float(d['last_test'])) < 1e-4
+    assert abs(max(test_accs) - float(d['best_test'])) < 1e-4
+    assert tr.total_time > 0
+
+
+@pytest.mark.parametrize('S', [2, 4])
+def test_e2e_gist_in_process(S):
+    from gist_amd import ist
+    from gist_amd.sampler import EngineClusterIter
+    from gist_amd.trainer import FullGraphEvaluator
+    d = np.load(os.path.join(GOLD, 'G6_e2e_ist_S%d.npz' % S))
+    g = _graph(d)
+    L, H = int(d['n_layers']), int(d['n_hidden'])
+    fin, ncls = d['feat'].shape[1], int(d['n_classes'])
+    random.seed(int(d['rnd_seed']))
+    train_nid = np.nonzero(d['train_mask'])[0].astype(np.int64)
+    # same order as the reference's main(): ClusterIter first, then the wrapper
+    it = EngineClusterIter('toy', g, int(d['psize']), int(d['batch_size']), train_nid,
+                           par_li=_parts(d), device=DEV)
+    group = ist.LocalCommGroup(S)
+    models = []
+    for r in range(S):
+        args = argparse.Namespace(num_subnet=S, n_hidden=H, n_layers=L, rank=r, dropout=0.0,
+                                  use_layernorm=True, lr=float(d['lr']), weight_decay=0.0,
+                                  iter_per_site=int(d['iter_per_site']),
+                                  n_epochs=int(d['n_epochs']))
+        models.append(ist.DistributedGNNWrapper(
+            args, None, fin, ncls, DEV,
+            base_init=_params(d, 'r0_base_init_', L + 1) if r == 0 else None,
+            comm=group.handle(r), n_max=it.n_max))
+    part = models[0].sample_partitions()
+    for m in models:
+        m.ini_sync_dispatch_model(part)
+    for r, m in enumerate(models):
+        for k in range(L + 1):
+            assert np.array_equal(m.sub.W[k].cpu().numpy(), d['r%d_sub_init_W%d' % (r, k)])
+            assert np.array_equal(m.sub.b[k].cpu().numpy(), d['r%d_sub_init_b%d' % (r, k)])
+    it.bind(models[0].engine)
+    evaluator = FullGraphEvaluator(g, models[0].base_dims, True, models[0].base, DEV)
+    snaps = []
+    orig_apply = models[0].sync_apply
+
+    def spy_apply():
+        orig_apply()
+        snaps.append(models[0].base.export())
+    models[0].sync_apply = spy_apply
+    res = ist.train(models, models[0].args, it, evaluator=evaluator, log=lambda *a: None)
+    gold = [str(e) for e in d['r0_events']]
+    dedup = [e for i, e in enumerate(gold) if not (e == 'eval' and gold[i - 1] == 'eval')]
+    assert res['events'] == dedup
+    for r in range(S):
+        got = np.array([float(x.item()) for x in res['losses'][r]])
+        assert np.abs(got - d['r%d_losses' % r]).max() < TOL, r
+    assert len(snaps) == int(d['r0_n_syncs'])
+    for i, snap in enumerate(snaps):
+        for k, (W, b) in enumerate(snap):
+            assert np.abs(W - d['r0_sync%d_W%d' % (i, k)]).max() < TOL, (i, k)
+            assert np.abs(b - d['r0_sync%d_b%d' % (i, k)]).max() < TOL, (i, k)
+    # every site's base replica is identical
+    for m in models[1:]:
+        assert torch.equal(m.base.params, models[0].base.params)
+    tail = dict(zip([str(k) for k in d['r0_tail_keys']], d['r0_tail_vals']))
+    assert abs(res['val_accs'][-1] - tail['Last Val']) < 1e-4
+    assert abs(max(res['val_accs']) - tail['Best Val']) < 1e-4
+    assert abs(res['test_accs'][-1] - tail['Last Test']) < 1e-4
+    assert abs(max(res['test_accs']) - tail['Best Test']) < 1e-4
+    lines = []
+    ist.print_results(res, log=lines.append)
+    assert [l.split(':')[0] for l in lines] == [str(k) for k in d['r0_tail_keys']]
+
+
+def test_full_size_step_properties():
+    """BASELINE.json's full size (Reddit-like batch, H=4096): size-independent properties
+    instead of an oracle run -- (1) linearity of the SpMM in x, (2) gather/forward/backward
+    determinism (two identical steps from identical state give bitwise identical arenas),
+    (3) dropout off: loss equals the CE of the logits recomputed by torch on the device."""
+    from gist_amd import datasets, hip
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+    random.seed(0)
+    ds = datasets.reddit_synth(seed=0)
+    g = ds.g
+    it = EngineClusterIter('reddit-synth', g, len(ds.par_li), 20,
+                           np.arange(g.number_of_nodes(), dtype=np.int64),
+                           par_li=[p.copy() for p in ds.par_li], device=DEV)
+    dims = dims_for(602, 4096, 41, 2)
+    eng = SageEngine(dims, True, 0.0, it.n_max, DEV)
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    for k, (i, o) in enumerate(dims):
+        eng.arena.W[k].copy_((torch.rand(o, 2 * i, generator=gen) - 0.5) * (2.0 / np.sqrt(2 * i)))
+        eng.arena.b[k].copy_((torch.rand(o, generator=gen) - 0.5) * (2.0 / np.sqrt(2 * i)))
+    it.bind(eng)
+    start = eng.arena.params.clone()
+    batch = next(iter(it))
+    n = batch.n
+    assert 1900 < n <= it.n_max
+    # (1) SpMM linearity: A(2x + y) == 2 A x + A y (exactly representable scaling)
+    x = torch.randn(n, 256, device=DEV)
+    y = torch.randn(n, 256, device=DEV)
+    o1, o2, o3 = (torch.empty(n, 256, device=DEV) for _ in range(3))
+    hip.spmm(batch.rowptr, batch.col, 2 * x + y, o1)
+    hip.spmm(batch.rowptr, batch.col, x, o2)
+    hip.spmm(batch.rowptr, batch.col, y, o3)
+    assert (o1 - (2 * o2 + o3)).abs().max().item() < 1e-3
+    # row sums of A = in-degree
+    ones = torch.ones(n, 4, device=DEV)
+    deg = torch.empty(n, 4, device=DEV)
+    hip.spmm(batch.rowptr, batch.col, ones, deg)
+    assert torch.equal(deg[:, 0].to(torch.int32), batch.rowptr[1:n + 1] - batch.rowptr[:n])
+    # (3) loss == CE of the logits
+    loss = eng.train_step(batch, 0.01).clone()
+    logits = eng.logits(n).clone()
+    ref = torch.nn.functional.cross_entropy(logits, batch.labels.long())
+    assert abs(loss.item() - ref.item()) < 1e-4
+    after1 = eng.arena.params.clone()
+    # (2) determinism: rewind and repeat the identical step
+    eng.arena.params.copy_(start)
+    eng.arena.reset_optimizer()
+    hip.gather_rows(it.batcher.feat, batch.ids, eng.z0_left(n))
+    eng.train_step(batch, 0.01)
+    assert torch.equal(eng.arena.params, after1)
+    assert torch.isfinite(eng.arena.params).all()
