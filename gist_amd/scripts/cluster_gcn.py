@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Single-GPU Cluster-GCN training -- CLI and output contract of the reference's
+cluster_gcn/cluster_gcn.py (flags :145-180, five result lines :132-136), running on the
+gist_amd HIP path.
+
+    python -m gist_amd.scripts.cluster_gcn --dataset reddit-synth --lr 0.01 --n-epochs 80 \\
+        --batch-size 20 --n-hidden 256 --n-layers 4 --dropout 0.2 --use-layernorm --rnd-seed 0
+
+Datasets are the seeded synthetic stand-ins of gist_amd.datasets (no real data offline);
+their block structure supplies the partition list in place of METIS.
+"""
+import argparse
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='GCN')
+    from gist_amd.dgl_compat.data import register_data_args
+    register_data_args(parser)
+    parser.add_argument("--dropout", type=float, default=0.2, help="dropout probability")
+    parser.add_argument("--gpu", type=int, default=0, help="gpu")
+    parser.add_argument("--lr", type=float, default=3e-2, help="learning rate")
+    parser.add_argument("--n-epochs", type=int, default=40, help="number of training epochs")
+    parser.add_argument("--batch-size", type=int, default=20, help="batch size")
+    parser.add_argument("--psize", type=int, default=1500, help="partition number")
+    parser.add_argument("--test-batch-size", type=int, default=1000, help="test batch size")
+    parser.add_argument("--n-hidden", type=int, default=128, help="number of hidden gcn units")
+    parser.add_argument("--n-layers", type=int, default=1, help="number of hidden gcn layers")
+    parser.add_argument("--rnd-seed", type=int, default=3)
+    parser.add_argument("--use-pp", action='store_true', help="whether to use precomputation")
+    parser.add_argument("--normalize", action='store_true', help="whether to use normalized feature")
+    parser.add_argument("--weight-decay", type=float, default=0, help="Weight for L2 loss")
+    parser.add_argument("--model-type", type=str, default='sage')
+    parser.add_argument("--fig-dir", type=str, default='../report/example_pic/')
+    parser.add_argument("--fig-name", type=str, default='name')
+    parser.add_argument("--use-layernorm", action='store_true')
+    parser.add_argument("--use-f1", action='store_true')
+    parser.add_argument("--eval-cpu", action='store_true')
+    return parser
+
+
+def main(args, dataset=None, log=print):
+    from gist_amd.dgl_compat.data import load_data
+    from gist_amd.modules import GCN
+    from gist_amd.trainer import ClusterGCNTrainer
+    torch.manual_seed(args.rnd_seed)                       # cluster_gcn.py:20-22
+    np.random.seed(args.rnd_seed)
+    random.seed(args.rnd_seed)
+    if args.gpu < 0 or args.eval_cpu:
+        raise SystemExit('gist_amd runs on the GPU only (no CPU fallback): --gpu >= 0, no --eval-cpu')
+    if args.model_type != 'sage':
+        raise NotImplementedError(f'{args.model_type} is not a supported model type')
+    data = dataset if dataset is not None else load_data(args)
+    g = data.g
+    if args.normalize:                                     # :36-42 StandardScaler on train rows
+        feats = g.ndata['feat']
+        tm = g.ndata['train_mask']
+        mu = feats[tm].mean(0, keepdim=True)
+        sd = feats[tm].std(0, unbiased=False, keepdim=True)
+        sd[sd == 0] = 1.0
+        g.ndata['feat'] = ((feats - mu) / sd).float()
+    in_feats = g.ndata['feat'].shape[1]
+    n_classes = data.num_classes
+    device = torch.device('cuda', args.gpu)
+    torch.cuda.set_device(device)
+    par_li = getattr(data, 'par_li', None)
+    psize = len(par_li) if par_li is not None else args.psize
+    log('labels shape:', g.ndata['label'].shape)
+    log("features shape, ", g.ndata['feat'].shape)
+    # construction order as in the reference: ClusterIter (one shuffle) before the model
+    model_holder = {}
+
+    def make_model():
+        m = GCN(in_feats, args.n_hidden, n_classes, args.n_layers, F.relu, args.dropout,
+                args.use_layernorm, False, False, 1, True)          # :66-69
+        model_holder['m'] = m
+        return m
+    trainer = ClusterGCNTrainer(args.dataset, g, par_li, psize, args.batch_size, args.n_hidden,
+                                args.n_layers, n_classes, args.dropout, args.use_layernorm,
+                                args.lr, args.weight_decay, device, seed=args.rnd_seed)
+    trainer.engine.arena.adopt_module(make_model())        # same-seed init as the reference
+    val_accs, test_accs = [], []
+    for epoch in range(args.n_epochs):                     # :89-127
+        log(f'Running epoch {epoch} / {args.n_epochs}', flush=True)
+        trainer.timed_epoch()
+        val_accs.append(trainer.evaluate('val_mask'))
+        test_accs.append(trainer.evaluate('test_mask'))
+        log(f'Val acc {val_accs[-1]}', flush=True)
+    log(f'Training Time: {trainer.total_time:.4f}', flush=True)    # :132-136
+    log(f'Last Val: {val_accs[-1]:.4f}', flush=True)
+    log(f'Best Val: {max(val_accs):.4f}', flush=True)
+    log(f'Last Test: {test_accs[-1]:.4f}', flush=True)
+    log(f'Best Test: {max(test_accs):.4f}', flush=True)
+    return dict(total_time=trainer.total_time, val_accs=val_accs, test_accs=test_accs,
+                model=model_holder['m'])
+
+
+if __name__ == '__main__':
+    a = build_parser().parse_args()
+    print(a)
+    main(a)

@@ -1,0 +1,65 @@
+"""GPU: the CLI entry points mirror the reference's flags and stdout contract
+(cluster_gcn/cluster_gcn.py:132-136,145-180; cluster_gcn_ist_distrib.py:475-479,520-564),
+and the torch.distributed (RCCL) collectives used by the IST sync work on device tensors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TAIL = ['Training Time', 'Last Val', 'Best Val', 'Last Test', 'Best Test']
+
+
+def test_cluster_gcn_cli_contract():
+    from gist_amd import datasets
+    from gist_amd.scripts import cluster_gcn as cli
+    args = cli.build_parser().parse_args(
+        ['--dataset', 'toy', '--n-epochs', '3', '--batch-size', '4', '--n-hidden', '32',
+         '--n-layers', '2', '--lr', '0.01', '--use-layernorm', '--rnd-seed', '0', '--dropout', '0.2'])
+    # reference defaults preserved
+    d = cli.build_parser().parse_args([])
+    assert (d.dropout, d.lr, d.n_epochs, d.batch_size, d.psize, d.n_hidden, d.n_layers,
+            d.rnd_seed, d.weight_decay) == (0.2, 3e-2, 40, 20, 1500, 128, 1, 3, 0)
+    lines = []
+    res = cli.main(args, dataset=datasets.toy(), log=lambda *a, **k: lines.append(' '.join(map(str, a))))
+    assert [l.split(':')[0] for l in lines[-5:]] == TAIL
+    for l in lines[-5:]:
+        float(l.split(':')[1])                       # parseable like the sweep scripts do
+    assert len(res['val_accs']) == 3 and all(0 <= a <= 1 for a in res['val_accs'])
+    assert res['total_time'] > 0
+    # the nn.Module handed back shares storage with the trained arena
+    W0 = res['model'].layers[0].linear.weight
+    assert W0.is_cuda and torch.isfinite(W0).all()
+
+
+def test_ist_cli_world1_and_rccl_collectives():
+    import torch.distributed as dist
+    from gist_amd import datasets, ist
+    from gist_amd.scripts import cluster_gcn_ist_distrib as cli
+    d = cli.build_parser().parse_args([])
+    assert (d.iter_per_site, d.num_subnet, d.dropout, d.lr, d.n_epochs, d.n_hidden, d.n_layers,
+            d.weight_decay, d.dist_backend, d.dist_url, d.batch_size, d.psize, d.rnd_seed) == (
+        5, 2, 0.5, 0.01, 20, 16, 1, 5e-4, 'nccl', 'tcp://127.0.0.1:9971', 20, 1500, 3)
+    assert cli.build_parser().parse_args(['--use_layernorm', 'False']).use_layernorm is True  # quirk :538
+    args = cli.build_parser().parse_args(
+        ['--dataset', 'toy', '--num_subnet', '1', '--n-epochs', '2', '--batch-size', '4',
+         '--n-hidden', '32', '--n-layers', '2', '--iter_per_site', '3', '--use_layernorm', 'True',
+         '--dropout', '0.0', '--weight-decay', '0', '--dist-url', 'tcp://127.0.0.1:29877'])
+    lines = []
+    res = cli.main(args, dataset=datasets.toy(), log=lambda *a, **k: lines.append(' '.join(map(str, a))))
+    assert [l.split(':')[0] for l in lines[-5:]] == TAIL
+    assert res['events'].count('sync') >= 2
+    # RCCL path of the collectives the sync uses, on device tensors
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29878', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        comm = ist.TorchDistComm()
+        inp = torch.arange(1000, dtype=torch.float32, device='cuda')
+        out = torch.zeros(1000, device='cuda')
+        comm.all_gather_flat(out, inp)
+        comm.broadcast(inp, src=0)
+        comm.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(out, inp)
+    finally:
+        dist.destroy_process_group()
