@@ -107,3 +107,65 @@ class _SageLayer(torch.autograd.Function):
 def sage_layer(g, h, weight, bias, use_lynorm, relu, p_drop=0.0, seed=0):
     return _SageLayer.apply(h, weight, bias, g, bool(use_lynorm), bool(relu), float(p_drop),
                             int(seed))
+
+
+class _MatMul(torch.autograd.Function):
+    """y = x @ w on the fp32-MFMA GEMM (GraphConv's weight is [in, out], gcn/gcn.py:30-56)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        w = w if w.stride(-1) == 1 else w.contiguous()
+        y = torch.empty(x.shape[0], w.shape[1], dtype=torch.float32, device=x.device)
+        hip.gemm_nn(x, w, y)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            hip.gemm_nt(gy, w, None, gx)            # gy @ w.T
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            hip.gemm_tn(x, gy, gw)                  # x.T @ gy
+        return gx, gw
+
+
+def matmul(x, w):
+    return _MatMul.apply(x, w)
+
+
+class _LayerNormRows(torch.autograd.Function):
+    """LayerNorm without affine over the last dim of a 2-D view (eps 1e-5), optional relu."""
+
+    @staticmethod
+    def forward(ctx, x, relu):
+        y = x.contiguous().clone()
+        out = torch.empty_like(y)
+        rstd = torch.empty(y.shape[0], dtype=torch.float32, device=y.device)
+        hip.ln_relu_fwd(y, out, rstd, True, relu)
+        ctx.save_for_backward(y, rstd)
+        ctx.relu = relu
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        yhat, rstd = ctx.saved_tensors
+        g = g if g.stride(-1) == 1 else g.contiguous()
+        dy = torch.empty_like(yhat)
+        hip.ln_relu_bwd(g, yhat, rstd, dy, True, ctx.relu)
+        return dy, None
+
+
+def layer_norm_rows(x, relu=False):
+    return _LayerNormRows.apply(x, bool(relu))
+
+
+def whole_tensor_layer_norm(h):
+    """F.layer_norm(h, h.shape) as gcn/gcn.py:65-66 uses it: ONE mean/variance over the whole
+    [N, hidden] tensor."""
+    return layer_norm_rows(h.reshape(1, -1)).reshape(h.shape)

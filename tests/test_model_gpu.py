@@ -215,3 +215,39 @@ def test_dropout_statistics_and_backward_consistency():
     assert err(h.grad, dh) < TOL
     assert err(W.grad, dW) < TOL * max(1.0, np.abs(dW).max())
     assert err(bb.grad, db) < TOL * max(1.0, np.abs(db).max())
+
+
+def test_G5_cora_plumbing_graphconv():
+    """BASELINE config 1 (gcn/gcn.py on a small graph): GraphConv stack + whole-tensor layer
+    norm, forward vs the fixture and backward vs torch autograd of the same math."""
+    import torch.nn.functional as Fn
+    from gist_amd.gcn import GCN as SmallGCN
+    d = np.load(os.path.join(GOLD, 'G5_graphconv.npz'))
+    g = graph_of(d)
+    model = SmallGCN(g, 7, 6, 3, 1, Fn.relu, 0.0, True).to(DEV)
+    with torch.no_grad():
+        for k, layer in enumerate(model.layers):
+            layer.weight.copy_(T(d['W%d' % k]))
+            layer.bias.copy_(T(d['b%d' % k]))
+    model.eval()
+    x = T(d['x']).requires_grad_(True)
+    out = model(x)
+    assert err(out, d['out']) < TOL
+    out.sum().backward()
+    # reference gradient by dense torch math on the CPU
+    n = int(d['n'])
+    A = torch.zeros(n, n)
+    for s_, t_ in zip(d['src'], d['dst']):
+        A[t_, s_] += 1
+    ns = A.sum(0).clamp(min=1).pow(-0.5)
+    nd = A.sum(1).clamp(min=1).pow(-0.5)
+    An = nd[:, None] * A * ns[None, :]
+    xc = torch.from_numpy(d['x']).requires_grad_(True)
+    W0, b0 = torch.from_numpy(d['W0']), torch.from_numpy(d['b0'])
+    W1, b1 = torch.from_numpy(d['W1']), torch.from_numpy(d['b1'])
+    h = torch.relu(An @ (xc @ W0) + b0)          # in=7 > out=6: multiply by W first
+    h = Fn.layer_norm(h, h.shape)
+    o = (An @ (h @ W1) + b1)                     # in=6 > out=3
+    assert err(out, o.detach().numpy()) < TOL
+    o.sum().backward()
+    assert err(x.grad, xc.grad.numpy()) < TOL
