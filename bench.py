@@ -188,13 +188,24 @@ def main():
     run_steps(args.warmup)
     fence()
     timing = not args.no_kernel_timing
+    native = engine.plan is not None
     if timing:
-        hip.profile_begin()
+        if native:          # HIP events recorded by the native step driver on the launch stream
+            engine.enable_timer(args.steps * (5 * len(dims) + 2))
+        else:
+            hip.profile_begin()
     t0 = time.time()
     run_steps(args.steps, log_from=0)
     fence()
     elapsed = time.time() - t0
-    prof = hip.profile_end() if timing else None
+    prof = None
+    if timing and native:
+        rec = engine.read_timer()
+        prof = {'gemm': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 1],
+                'spmm': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 0]}
+        engine.disable_timer()
+    elif timing:
+        prof = hip.profile_end()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -225,6 +236,7 @@ def main():
                 'epochs_per_sec_per_rank': round(value / world, 4),
             },
             'final_loss': round(loss_val, 5),
+            'host_path': 'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',
         }
         if prof is not None:
             nnz = nnz_log[:args.steps].cpu().numpy().astype(np.int64)

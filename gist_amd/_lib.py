@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GistLibraryError(RuntimeError):
@@ -56,7 +56,38 @@ SIGNATURES = {
     'gist_block_gather_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
     'gist_block_scatter_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
     'gist_mean_rows_f32': (_int, [_p, _i64, _i64, _i64, _p, _p]),
+    'gist_timer_create': (_p, [_i64]),
+    'gist_timer_destroy': (None, [_p]),
+    'gist_timer_reset': (None, [_p]),
+    'gist_timer_count': (_i64, [_p]),
+    'gist_timer_read': (_int, [_p, _i64, _p, _p, _p, _p, _p]),
+    'gist_sage_step': (_int, [_p, _p, _i64, _u64, _f, _f, _f, _f, _f, _i64, _int, _p]),
 }
+
+GIST_MAX_LAYERS = 16
+GIST_STEP_EXTRACT = 1
+GIST_STEP_TRAIN = 2
+
+
+class LayerDesc(ctypes.Structure):
+    """struct gist_layer_desc (include/gist_hip.h)."""
+    _fields_ = [('n_in', _i64), ('n_out', _i64), ('W', _p), ('b', _p), ('dW', _p), ('db', _p),
+                ('Z', _p), ('ldz', _i64), ('Y', _p), ('ldy', _i64), ('rstd', _p)]
+
+
+class StepPlan(ctypes.Structure):
+    """struct gist_step_plan (include/gist_hip.h)."""
+    _fields_ = [('n_layers', _i32), ('use_layernorm', _i32), ('p_drop', _f), ('seed', _u64),
+                ('layer', LayerDesc * GIST_MAX_LAYERS),
+                ('dlogits', _p), ('ldc', _i64), ('dZ', _p), ('partials', _p),
+                ('row_loss', _p), ('loss', _p), ('workspace', _p), ('workspace_bytes', _i64),
+                ('params', _p), ('grads', _p), ('exp_avg', _p), ('exp_avg_sq', _p),
+                ('n_params', _i64),
+                ('g_rowptr', _p), ('g_col', _p), ('g_t_rowptr', _p), ('g_t_col', _p),
+                ('feat', _p), ('ld_feat', _i64), ('labels_all', _p), ('remap', _p),
+                ('rowptr', _p), ('col', _p), ('t_rowptr', _p), ('t_col', _p),
+                ('col_capacity', _i64), ('norm', _p), ('labels', _p), ('timer', _p)]
+
 
 _lib = None
 

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libgist_hip.so')
-SOURCES = ['capi.hip', 'spmm.hip', 'gemm.hip', 'rowops.hip', 'subgraph.hip']
+SOURCES = ['capi.hip', 'spmm.hip', 'gemm.hip', 'rowops.hip', 'subgraph.hip', 'step.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
          '-Wno-unused-function', '-fno-gpu-rdc']

@@ -80,7 +80,10 @@ class ParamArena(object):
 
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
-    __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids')
+    __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready')
+
+    def __init__(self):
+        self.ready = True
 
 
 class ClusterBatcher(object):
@@ -105,6 +108,19 @@ class ClusterBatcher(object):
         self.t_col = torch.zeros(self.nnz_max, **i32)
         self.norm = torch.zeros(self.n_max, dtype=torch.float32, device=dev)
         self.lab = torch.zeros(self.n_max, **i32)
+
+    def lazy(self, ids):
+        """Describe the batch WITHOUT launching anything: the native step driver
+        (gist_sage_step) performs the extraction itself as the first part of the step."""
+        n = ids.numel()
+        if n > self.n_max:
+            raise ValueError('gist_amd: batch of %d rows exceeds n_max=%d' % (n, self.n_max))
+        b = Batch()
+        b.n, b.rowptr, b.col = n, self.rowptr[:n + 1], self.col
+        b.t_rowptr, b.t_col = self.t_rowptr[:n + 1], self.t_col
+        b.norm, b.labels, b.ids = self.norm[:n], self.lab[:n], ids
+        b.ready = False
+        return b
 
     def extract(self, ids, z0_left):
         """ids: int32 device tensor (node ids in the training graph); z0_left: the [n, F]
@@ -162,8 +178,107 @@ class SageEngine(object):
         for (i, o) in self.dims:
             for (m, n, k) in ((self.n_max, o, 2 * i), (self.n_max, 2 * i, o), (o, 2 * i, self.n_max)):
                 need = max(need, L.gist_gemm_workspace_bytes(m, n, k))
-        hip.workspace(need, device)
+        self._ws = hip.workspace(need, device)
         self._drop_offsets = []
+        self.plan = None
+        self._plan_keep = None
+
+    # ------------------------------------------------------------------
+    def attach_batcher(self, batcher):
+        """Build the native step plan (struct gist_step_plan): after this, train_step is
+        ONE call into libgist_hip.so per iteration (gist_sage_step) instead of ~45."""
+        from . import _lib
+        A = self.arena
+        if A.grads is None:
+            raise ValueError('gist_amd: the native step needs an arena with gradients')
+        if self.L1 > _lib.GIST_MAX_LAYERS:
+            return None
+        P = _lib.StepPlan()
+        P.n_layers = self.L1
+        P.use_layernorm = int(self.use_layernorm)
+        P.p_drop = self.p_drop
+        P.seed = self.seed
+        for k, (i, o) in enumerate(self.dims):
+            l = P.layer[k]
+            l.n_in, l.n_out = i, o
+            l.W, l.b = A.W[k].data_ptr(), A.b[k].data_ptr()
+            l.dW, l.db = A.dW[k].data_ptr(), A.db[k].data_ptr()
+            l.Z, l.ldz = self.Z[k].data_ptr(), 2 * i
+            l.Y, l.ldy = self.Y[k].data_ptr(), self.Y[k].shape[1]
+            l.rstd = self.rstd[k].data_ptr() if k < self.L1 - 1 else None
+        P.dlogits, P.ldc = self.dlogits.data_ptr(), self.ldc
+        P.dZ, P.partials = self.dZ.data_ptr(), self.partials.data_ptr()
+        P.row_loss, P.loss = self.row_loss.data_ptr(), self.loss.data_ptr()
+        P.workspace, P.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        P.params, P.grads = A.params.data_ptr(), A.grads.data_ptr()
+        P.exp_avg, P.exp_avg_sq = A.exp_avg.data_ptr(), A.exp_avg_sq.data_ptr()
+        P.n_params = A.numel
+        g = batcher.g
+        P.g_rowptr, P.g_col = g.rowptr.data_ptr(), g.col.data_ptr()
+        P.g_t_rowptr, P.g_t_col = g.t_rowptr.data_ptr(), g.t_col.data_ptr()
+        P.feat, P.ld_feat = batcher.feat.data_ptr(), batcher.feat.stride(0)
+        P.labels_all, P.remap = batcher.labels.data_ptr(), batcher.remap.data_ptr()
+        P.rowptr, P.col = batcher.rowptr.data_ptr(), batcher.col.data_ptr()
+        P.t_rowptr, P.t_col = batcher.t_rowptr.data_ptr(), batcher.t_col.data_ptr()
+        P.col_capacity = batcher.col.numel()
+        P.norm, P.labels = batcher.norm.data_ptr(), batcher.lab.data_ptr()
+        self.plan = P
+        self._plan_keep = (batcher, g, self._ws)           # keep every buffer alive
+        return P
+
+    def enable_timer(self, capacity):
+        """HIP-event timing of every SpMM/GEMM issued by the native step (gist_timer_*)."""
+        from . import _lib
+        L = _lib.load()
+        if self.plan is None:
+            raise RuntimeError('gist_amd: enable_timer needs attach_batcher first')
+        self.disable_timer()
+        self._timer = L.gist_timer_create(int(capacity))
+        self.plan.timer = self._timer
+        return self._timer
+
+    def disable_timer(self):
+        from . import _lib
+        if getattr(self, '_timer', None):
+            _lib.load().gist_timer_destroy(self._timer)
+        self._timer = None
+        if self.plan is not None:
+            self.plan.timer = None
+
+    def read_timer(self):
+        """[(ms, kind, m, n, k)] -- synchronises the device first."""
+        import ctypes
+        from . import _lib
+        L = _lib.load()
+        torch.cuda.synchronize(self.device)
+        out = []
+        ms, kind = ctypes.c_float(), ctypes.c_int32()
+        m, n, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        for i in range(L.gist_timer_count(self._timer)):
+            _lib.check(L.gist_timer_read(self._timer, i, ctypes.byref(ms), ctypes.byref(kind),
+                                         ctypes.byref(m), ctypes.byref(n), ctypes.byref(k)),
+                       'gist_timer_read')
+            out.append((ms.value, kind.value, m.value, n.value, k.value))
+        return out
+
+    def _native_step(self, b, lr, weight_decay, train, betas=(0.9, 0.999), eps=1e-8):
+        import ctypes
+        from . import _lib
+        L = _lib.load()
+        flags = (_lib.GIST_STEP_TRAIN if train else 0) | (0 if b.ready else _lib.GIST_STEP_EXTRACT)
+        off = self.drop_calls
+        if train and self.p_drop > 0.0:
+            for (i, o) in self.dims:
+                numel = b.n * 2 * i
+                self.drop_calls += numel + (numel & 1)
+        if train:
+            self.arena.step += 1
+        ids_ptr = b.ids.data_ptr() if b.ids is not None else None
+        rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
+                              eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())
+        _lib.check(rc, 'gist_sage_step')
+        b.ready = True
+        return self.loss
 
     # ------------------------------------------------------------------
     def z0_left(self, n):
@@ -239,7 +354,12 @@ class SageEngine(object):
 
     def train_step(self, b, lr, weight_decay=0.0, mask=None, count=None):
         """One iteration of the reference loop (cluster_gcn_ist_distrib.py:408-417).
-        Returns the device loss tensor; nothing synchronises with the host."""
+        Returns the device loss tensor; nothing synchronises with the host.  With a native
+        plan attached (attach_batcher) and no mask this is a single gist_sage_step call."""
+        if self.plan is not None and mask is None and hip._prof is None:
+            return self._native_step(b, lr, weight_decay, train=True)
+        if not b.ready:
+            raise RuntimeError('gist_amd: lazy batch needs the native step plan')
         self.forward(b, training=True)
         loss = self.loss_and_backward(b, mask, count)
         self.adam_step(lr, weight_decay)

@@ -128,11 +128,17 @@ class EngineClusterIter(ClusterIter):
         self.batcher = ClusterBatcher(tg, feat.contiguous(), lab.contiguous(), self.n_max,
                                       self.nnz_max)
         self.engine = None
+        self.native = False
         self._epoch_ids = None
         self._offsets = None
 
-    def bind(self, engine):
+    def bind(self, engine, native=True):
+        """Feed `engine`.  native=True attaches the C++ step driver: batches are then only
+        DESCRIBED here (ids slice) and extracted inside gist_sage_step."""
         self.engine = engine
+        self.native = bool(native) and engine.arena.grads is not None
+        if self.native:
+            self.native = engine.attach_batcher(self.batcher) is not None
         return self
 
     def fill_features(self, batch, engine):
@@ -159,7 +165,11 @@ class EngineClusterIter(ClusterIter):
         if self.n < self.max:
             a, b = int(self._offsets[self.n]), int(self._offsets[self.n + 1])
             ids = self._epoch_ids[a:b]
-            batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
+            from . import hip as _hip
+            if self.native and _hip._prof is None:
+                batch = self.batcher.lazy(ids)
+            else:
+                batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
             self.n += 1
             return batch
         random.shuffle(self.par_li)

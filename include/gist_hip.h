@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);
+int gist_abi_version(void);   /* currently 2 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -220,6 +220,72 @@ int gist_block_scatter_f32(const float *src, int64_t lds, const int32_t *row_idx
  * all-gather, cluster_gcn_ist_distrib.py:38-41,103. */
 int gist_mean_rows_f32(const float *src, int64_t stride, int64_t n_src, int64_t n,
                        float *out, gist_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Whole training iteration in one call (native step driver)
+ * ------------------------------------------------------------------------- */
+
+#define GIST_MAX_LAYERS 16
+
+/* One SAGE layer's buffers (all device pointers, all preallocated by the caller). */
+typedef struct gist_layer_desc {
+    int64_t n_in, n_out;
+    float *W, *b;          /* [n_out, 2*n_in], [n_out]                      */
+    float *dW, *db;        /* gradients, same shapes                       */
+    float *Z; int64_t ldz; /* [n_max, 2*n_in] = [h | ah]                   */
+    float *Y; int64_t ldy; /* [n_max, n_out] pre-norm -> yhat -> dY        */
+    float *rstd;           /* [n_max] (unused by the last layer)           */
+} gist_layer_desc;
+
+struct gist_timer;
+typedef struct gist_step_plan {
+    int32_t n_layers;              /* L+1 SAGE layers                               */
+    int32_t use_layernorm;
+    float p_drop;                  /* 0 = no dropout                                */
+    uint64_t seed;
+    gist_layer_desc layer[GIST_MAX_LAYERS];
+    float *dlogits; int64_t ldc;   /* [n_max, ldc], ldc >= n_classes (padded)       */
+    float *dZ;                     /* scratch [n_max * max_k(2*n_in_k, k>=1)]       */
+    float *partials;               /* colsum scratch                                */
+    float *row_loss, *loss;        /* [n_max], [1]                                  */
+    void *workspace; int64_t workspace_bytes;   /* split-K scratch                  */
+    float *params, *grads, *exp_avg, *exp_avg_sq; int64_t n_params;   /* flat arenas */
+    /* resident training graph + the batch buffers the extraction fills */
+    const int32_t *g_rowptr, *g_col, *g_t_rowptr, *g_t_col;
+    const float *feat; int64_t ld_feat;
+    const int32_t *labels_all;
+    int32_t *remap;
+    int32_t *rowptr, *col, *t_rowptr, *t_col; int64_t col_capacity;
+    float *norm; int32_t *labels;
+    struct gist_timer *timer;      /* NULL = no timing */
+} gist_step_plan;
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream by the step
+ * driver around every SpMM and GEMM call (what bench.py's `roofline` is computed from).
+ * kind: 0 = SpMM (m = rows, n = source rows, k = width), 1 = GEMM (m, n, k). */
+typedef struct gist_timer gist_timer;
+gist_timer *gist_timer_create(int64_t capacity);
+void gist_timer_destroy(gist_timer *t);
+void gist_timer_reset(gist_timer *t);
+int64_t gist_timer_count(const gist_timer *t);
+/* Valid after the stream has been synchronised. Returns 0 or a negative code. */
+int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t *m, int64_t *n,
+                    int64_t *k);
+
+#define GIST_STEP_EXTRACT 1   /* build the batch from ids (else: batch buffers already valid) */
+#define GIST_STEP_TRAIN 2     /* dropout on, backward + Adam (else: forward + loss only)      */
+
+/* One iteration of the reference's training loop on the batch whose node ids (in the
+ * training graph) are ids[0..n): induced subgraph + feature/label gather
+ * (cluster_gcn/partition_utils.py:20-25, cluster_gcn_ist_distrib.py:409), GCN.forward
+ * (cluster_gcn/modules.py:310-314), mean CE over the batch rows, backward, Adam
+ * (cluster_gcn_ist_distrib.py:410-417 / cluster_gcn/cluster_gcn.py:98-105).
+ * `plan` is HOST memory; drop_offset is the dropout counter base for this step
+ * (layer k uses drop_offset + sum_{j<k} round_up(n*2*n_in_j, 2)); adam_step is 1-based.
+ * ~45 kernel launches, no host synchronisation. */
+int gist_sage_step(const gist_step_plan *plan, const int32_t *ids, int64_t n,
+                   uint64_t drop_offset, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t adam_step, int flags, gist_stream_t stream);
 
 #ifdef __cplusplus
 }
