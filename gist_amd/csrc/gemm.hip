@@ -6,8 +6,9 @@
 //   NN  Z[m,n] = G[m,k] . W[k,n]            dZ = dY . W
 //   TN  D[m,n] = G[k,m]^T . A[k,n]          dW = dY^T . Z
 //
-// Block tile 128x128x32, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA
-// tiles of 32x32 (64 accumulator VGPRs).  Global -> registers -> LDS staging,
+// Block tile 128x128x32 (or 64x64x32 when the output has too few 128x128 tiles to fill and
+// balance 256 CUs), 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles of
+// 32x32 (64 accumulator VGPRs; one tile for the 64x64 block).  Global -> registers -> LDS staging,
 // double buffered (the next tile's loads are issued before the MFMA block and
 // written to the other LDS buffer after it; one barrier per k tile).
 //
@@ -26,17 +27,23 @@
 // k across blockIdx.z into a workspace and reduced deterministically.
 // Blocks are dealt to XCDs in 8x8 super-tiles so that the 64 blocks sharing an L2
 // touch 8 A panels + 8 B panels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gist {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+// Block tiles: 128x128 (each wave 64x64 = 2x2 MFMA tiles) and 64x64 (each wave one 32x32
+// MFMA tile) for outputs whose 128x128 tile count cannot fill / balance 256 CUs.
+constexpr int BK = 32;
 constexpr int LDS_KC = BK + 4;   // k-contiguous image: row stride (floats)
-constexpr int LDS_MC = BM;       // m/n-contiguous image: k-row stride (floats)
-constexpr int TILE_KC = BM * LDS_KC;
-constexpr int TILE_MC = BK * LDS_MC;
+template <int R> struct Img {    // R = rows of a k-contiguous image = columns of an m/n image
+    static constexpr int KC = R * LDS_KC;   // floats
+    static constexpr int MC = BK * R;
+    static constexpr int ITERS = R / 32;    // float4 per thread per k tile (256 threads)
+};
 
 struct GemmArgs {
     const float *a; int64_t lda;
@@ -44,7 +51,7 @@ struct GemmArgs {
     const float *bias;
     float *c; int64_t ldc;
     int m, n, k;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n;  // filled by the launcher for the chosen tile edge
     int k_per_split;       // multiple of BK
     int64_t split_stride;  // elements between split slabs (0 = write C directly)
 };
@@ -64,13 +71,14 @@ struct GemmArgs {
 
 // k-contiguous operand: element (r, kk) at p[r*ld + kk].  256 threads move
 // 128 rows x 32 k = 1024 float4: thread t -> rows t/8 + 32 i, k chunk t%8.
+template <int IT>
 __device__ __forceinline__ void load_kc_aligned(const float *__restrict__ p, int64_t ld, int rows,
-                                                int kdim, int row0, int k0, float4 (&st)[4]) {
+                                                int kdim, int row0, int k0, float4 (&st)[IT]) {
     const int t = threadIdx.x;
     const int kk = k0 + (t & 7) * 4;
     const int kc = min(kk, (int)ld - 4);           // stays inside the row pitch
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IT; ++i) {
         const int r = min(row0 + (t >> 3) + 32 * i, rows - 1);
         st[i] = *reinterpret_cast<const float4 *>(p + (int64_t)r * ld + kc);
     }
@@ -79,12 +87,13 @@ __device__ __forceinline__ void load_kc_aligned(const float *__restrict__ p, int
 // Reduction-dimension mask of the aligned loaders, applied when the registers are
 // written to LDS -- i.e. AFTER the MFMA block -- so that the loads stay in flight
 // under the MFMAs instead of being waited for right after issue.
-__device__ __forceinline__ void mask_kc(float4 (&st)[4], int kdim, int k0) {
+template <int IT>
+__device__ __forceinline__ void mask_kc(float4 (&st)[IT], int kdim, int k0) {
     const int kk = k0 + (threadIdx.x & 7) * 4;
     if (kk + 3 < kdim) return;
     const bool k0ok = kk + 0 < kdim, k1ok = kk + 1 < kdim, k2ok = kk + 2 < kdim;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IT; ++i) {
         st[i].x = k0ok ? st[i].x : 0.f;
         st[i].y = k1ok ? st[i].y : 0.f;
         st[i].z = k2ok ? st[i].z : 0.f;
@@ -92,20 +101,23 @@ __device__ __forceinline__ void mask_kc(float4 (&st)[4], int kdim, int k0) {
     }
 }
 
-__device__ __forceinline__ void mask_mc(float4 (&st)[4], int kdim, int k0) {
+template <int IT>
+__device__ __forceinline__ void mask_mc(float4 (&st)[IT], int kdim, int k0) {
+    constexpr int CPR = IT * 8;                     // float4 chunks per k row (cols / 4)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kk = k0 + (threadIdx.x >> 5) + 8 * i;
+    for (int i = 0; i < IT; ++i) {
+        const int kk = k0 + threadIdx.x / CPR + (256 / CPR) * i;
         if (kk >= kdim) st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
+template <int IT>
 __device__ __forceinline__ void load_kc_generic(const float *__restrict__ p, int64_t ld, int rows,
-                                                int kdim, int row0, int k0, float4 (&st)[4]) {
+                                                int kdim, int row0, int k0, float4 (&st)[IT]) {
     const int t = threadIdx.x;
     const int kk = k0 + (t & 7) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IT; ++i) {
         const int r = row0 + (t >> 3) + 32 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows) {
@@ -119,43 +131,48 @@ __device__ __forceinline__ void load_kc_generic(const float *__restrict__ p, int
     }
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, int IT>
 __device__ __forceinline__ void load_kc(const float *__restrict__ p, int64_t ld, int rows, int kdim,
-                                        int row0, int k0, float4 (&st)[4]) {
-    if constexpr (ALIGNED) load_kc_aligned(p, ld, rows, kdim, row0, k0, st);
-    else load_kc_generic(p, ld, rows, kdim, row0, k0, st);
+                                        int row0, int k0, float4 (&st)[IT]) {
+    if constexpr (ALIGNED) load_kc_aligned<IT>(p, ld, rows, kdim, row0, k0, st);
+    else load_kc_generic<IT>(p, ld, rows, kdim, row0, k0, st);
 }
 
-__device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&st)[4]) {
+template <int IT>
+__device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&st)[IT]) {
     const int t = threadIdx.x;
     const int kq = (t & 7) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IT; ++i) {
         const int r = (t >> 3) + 32 * i;
         *reinterpret_cast<float4 *>(s + r * LDS_KC + kq) = st[i];
     }
 }
 
-// m/n-contiguous operand: element (kk, c) at p[kk*ld + c].  32 k x 128 cols:
-// thread t -> k rows t/32 + 8 i, column chunk t%32.
+// m/n-contiguous operand: element (kk, c) at p[kk*ld + c].  32 k x C cols (C = 32*IT):
+// thread t -> k rows t/CPR + (256/CPR) i, column chunk t % CPR, CPR = C/4.
+template <int IT>
 __device__ __forceinline__ void load_mc_aligned(const float *__restrict__ p, int64_t ld, int cols,
-                                                int kdim, int col0, int k0, float4 (&st)[4]) {
+                                                int kdim, int col0, int k0, float4 (&st)[IT]) {
+    constexpr int CPR = IT * 8;
     const int t = threadIdx.x;
-    const int cq = min(col0 + (t & 31) * 4, (int)ld - 4);   // clamp inside the row pitch
+    const int cq = min(col0 + (t % CPR) * 4, (int)ld - 4);   // clamp inside the row pitch
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kk = k0 + (t >> 5) + 8 * i;
+    for (int i = 0; i < IT; ++i) {
+        const int kk = k0 + t / CPR + (256 / CPR) * i;
         st[i] = *reinterpret_cast<const float4 *>(p + (int64_t)min(kk, kdim - 1) * ld + cq);
     }
 }
 
+template <int IT>
 __device__ __forceinline__ void load_mc_generic(const float *__restrict__ p, int64_t ld, int cols,
-                                                int kdim, int col0, int k0, float4 (&st)[4]) {
+                                                int kdim, int col0, int k0, float4 (&st)[IT]) {
+    constexpr int CPR = IT * 8;
     const int t = threadIdx.x;
-    const int cq = col0 + (t & 31) * 4;
+    const int cq = col0 + (t % CPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kk = k0 + (t >> 5) + 8 * i;
+    for (int i = 0; i < IT; ++i) {
+        const int kk = k0 + t / CPR + (256 / CPR) * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kk < kdim) {
             const float *src = p + (int64_t)kk * ld + cq;
@@ -168,34 +185,36 @@ __device__ __forceinline__ void load_mc_generic(const float *__restrict__ p, int
     }
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, int IT>
 __device__ __forceinline__ void load_mc(const float *__restrict__ p, int64_t ld, int cols, int kdim,
-                                        int col0, int k0, float4 (&st)[4]) {
-    if constexpr (ALIGNED) load_mc_aligned(p, ld, cols, kdim, col0, k0, st);
-    else load_mc_generic(p, ld, cols, kdim, col0, k0, st);
+                                        int col0, int k0, float4 (&st)[IT]) {
+    if constexpr (ALIGNED) load_mc_aligned<IT>(p, ld, cols, kdim, col0, k0, st);
+    else load_mc_generic<IT>(p, ld, cols, kdim, col0, k0, st);
 }
 
-__device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&st)[4]) {
+template <int IT>
+__device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&st)[IT]) {
+    constexpr int CPR = IT * 8, C = IT * 32;
     const int t = threadIdx.x;
-    const int cq = (t & 31) * 4;
+    const int cq = (t % CPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kk = (t >> 5) + 8 * i;
-        *reinterpret_cast<float4 *>(s + kk * LDS_MC + cq) = st[i];
+    for (int i = 0; i < IT; ++i) {
+        const int kk = t / CPR + (256 / CPR) * i;
+        *reinterpret_cast<float4 *>(s + kk * C + cq) = st[i];
     }
 }
 
 // ---- LDS -> fragment ---------------------------------------------------------
 // Returns the 4 values a lane feeds to MFMA steps j = 0..3 of k block q for the
 // 32-row (or 32-column) slab starting at `base`.
-template <bool KC>
+template <bool KC, int C>
 __device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int base, int q, int r,
                                             int hh) {
     if constexpr (KC) {
         return *reinterpret_cast<const float4 *>(s + (base + r) * LDS_KC + 8 * q + 4 * hh);
     } else {
-        const float *p = s + (8 * q + 4 * hh) * LDS_MC + base + r;
-        return make_float4(p[0], p[LDS_MC], p[2 * LDS_MC], p[3 * LDS_MC]);
+        const float *p = s + (8 * q + 4 * hh) * C + base + r;
+        return make_float4(p[0], p[C], p[2 * C], p[3 * C]);
     }
 }
 
@@ -205,11 +224,15 @@ __device__ __forceinline__ float f4(const float4 &v, int j) {
 
 // ALIGNED: both operands have 16-B aligned bases and leading dimensions % 4 == 0
 // (every buffer the engine allocates); otherwise the generic guarded loader runs.
-template <bool A_KC, bool B_KC, bool ALIGNED>
+// T = block tile edge (128 or 64); 4 waves in 2x2, each wave (T/2)x(T/2) = (T/64)^2 MFMA tiles.
+template <bool A_KC, bool B_KC, bool ALIGNED, int T>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TA = A_KC ? TILE_KC : TILE_MC;
-    constexpr int TB = B_KC ? TILE_KC : TILE_MC;
+    constexpr int TA = A_KC ? Img<T>::KC : Img<T>::MC;
+    constexpr int TB = B_KC ? Img<T>::KC : Img<T>::MC;
+    constexpr int IT = Img<T>::ITERS;
+    constexpr int W = T / 2;          // wave tile edge
+    constexpr int NT = W / 32;        // MFMA tiles per wave per dimension
     // buffer b: A image at smem + b*(TA+TB), B image right behind it
 
     // ---- block -> output tile, 8x8 super-tiles per XCD ------------------------
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int gsz = min(g.tiles_m - first_m, GM);
     const int bm = first_m + (L % width) % gsz;
     const int bn = (L % width) / gsz;
-    const int row0 = bm * BM, col0 = bn * BN;
+    const int row0 = bm * T, col0 = bn * T;
 
     const int k_begin = blockIdx.z * g.k_per_split;
     const int k_end = min(g.k, k_begin + g.k_per_split);
@@ -235,21 +258,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 stA[4], stB[4];
+    float4 stA[IT], stB[IT];
     auto gload = [&](int kt) {
         const int k0 = k_begin + kt * BK;
-        if constexpr (A_KC) load_kc<ALIGNED>(g.a, g.lda, g.m, k_end, row0, k0, stA);
-        else load_mc<ALIGNED>(g.a, g.lda, g.m, k_end, row0, k0, stA);
-        if constexpr (B_KC) load_kc<ALIGNED>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
-        else load_mc<ALIGNED>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
+        if constexpr (A_KC) load_kc<ALIGNED, IT>(g.a, g.lda, g.m, k_end, row0, k0, stA);
+        else load_mc<ALIGNED, IT>(g.a, g.lda, g.m, k_end, row0, k0, stA);
+        if constexpr (B_KC) load_kc<ALIGNED, IT>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
+        else load_mc<ALIGNED, IT>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
     };
     auto sstore = [&](int buf, int kt) {
         float *sa = smem + buf * (TA + TB);
@@ -257,12 +280,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         if constexpr (ALIGNED) {
             const int k0 = k_begin + kt * BK;
             if (k0 + BK > k_end) {            // only the last k tile of a split can be ragged
-                if constexpr (A_KC) mask_kc(stA, k_end, k0); else mask_mc(stA, k_end, k0);
-                if constexpr (B_KC) mask_kc(stB, k_end, k0); else mask_mc(stB, k_end, k0);
+                if constexpr (A_KC) mask_kc<IT>(stA, k_end, k0); else mask_mc<IT>(stA, k_end, k0);
+                if constexpr (B_KC) mask_kc<IT>(stB, k_end, k0); else mask_mc<IT>(stB, k_end, k0);
             }
         }
-        if constexpr (A_KC) store_kc(sa, stA); else store_mc(sa, stA);
-        if constexpr (B_KC) store_kc(sb, stB); else store_mc(sb, stB);
+        if constexpr (A_KC) store_kc<IT>(sa, stA); else store_mc<IT>(sa, stA);
+        if constexpr (B_KC) store_kc<IT>(sb, stB); else store_mc<IT>(sb, stB);
     };
 
     if (n_kt > 0) {
@@ -280,17 +303,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         const float *b_s = a_s + TA;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 af[2], bf[2];
+            float4 af[NT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = read_frag<A_KC>(a_s, wm * 64 + i * 32, q, r, hh);
+            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T>(a_s, wm * W + i * 32, q, r, hh);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = read_frag<B_KC>(b_s, wn * 64 + j * 32, q, r, hh);
+            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T>(b_s, wn * W + j * 32, q, r, hh);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             f4(af[i], s), f4(bf[j], s), acc[i][j], 0, 0, 0);
         }
@@ -303,15 +326,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
     const bool add_bias = g.bias != nullptr && g.split_stride == 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cc = col0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < NT; ++j) {
+        const int cc = col0 + wn * W + j * 32 + r;
         if (cc >= g.n) continue;
         const float bv = add_bias ? g.bias[cc] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NT; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rr = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int rr = row0 + wm * W + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 if (rr < g.m) cbase[(int64_t)rr * g.ldc + cc] = acc[i][j][e] + bv;
             }
         }
@@ -331,15 +354,78 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int64_t slab,
     c[(int64_t)rr * ldc + cc] = s;
 }
 
-// Split k only when the output grid cannot fill the chip.
-static int choose_splits(int64_t m, int64_t n, int64_t k) {
-    const int64_t tiles = ceil_div(m, BM) * ceil_div(n, BN);
+// ---- tile / split-K choice ---------------------------------------------------------------
+// Everything here is fp32 MFMA work, so time ~ MFMA work of the busiest SIMD.  A block is 4
+// waves (one per SIMD of a CU); blocks are dealt round-robin to 256 CUs, a CU keeps up to
+// `cap` of them resident (128-tile: 2, 64-tile: 4) and fewer co-resident waves hide less
+// latency.  Model, in units of one 64x64x32 MFMA block (16 MFMAs, ~0.43 us), calibrated on
+// scripts/gemm_sweep.py measurements (MI355X, 34 shapes, within ~10% of the best config):
+//   per_cu  = ceil(blocks / 256)
+//   cost    = per_cu * unit(tile) * (k_tiles_per_split + 3) / eff(min(cap, per_cu))
+//           + [splits > 1] * (12 + 6.5 * splits * m*n/1e6)      (slab traffic + reduce launch)
+struct GemmCfg { int tile; int splits; };
+
+static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
     const int64_t kt = ceil_div(k, BK);
-    if (tiles >= 192 || kt < 8) return 1;
-    int64_t s = 512 / tiles;           // aim at ~2 blocks per CU
-    s = s < kt / 4 ? s : kt / 4;       // keep >= 4 k tiles per split
-    if (s > 32) s = 32;
-    return s < 1 ? 1 : (int)s;
+    // developer override for tuning sweeps (scripts/gemm_sweep.py); not used in production
+    static const char *env_tile = getenv("GIST_GEMM_TILE");
+    static const char *env_split = getenv("GIST_GEMM_SPLITS");
+    if (env_tile && env_split) {
+        int sp = atoi(env_split);
+        while (sp > 1 && kt / sp < 1) sp >>= 1;
+        return GemmCfg{atoi(env_tile) == 64 ? 64 : 128, sp < 1 ? 1 : sp};
+    }
+    static const double eff128[3] = {0.0, 0.90, 1.00};
+    static const double eff64[5] = {0.0, 0.60, 0.80, 0.92, 1.00};
+    GemmCfg best{128, 1};
+    double best_cost = 1e300;
+    const double mn = (double)m * (double)n / 1e6;
+    for (int tile : {128, 64}) {
+        const int64_t tiles = ceil_div(m, tile) * ceil_div(n, tile);
+        const int cap = tile == 128 ? 2 : 4;
+        const double unit = tile == 128 ? 4.0 : 1.12;
+        for (int sp : {1, 2, 4, 8, 16, 32}) {
+            if (sp > 1 && kt / sp < 2) break;
+            const int64_t per_cu = ceil_div(tiles * sp, 256);
+            const int64_t kt_per = ceil_div(kt, sp);
+            const int conc = (int)(per_cu < cap ? per_cu : cap);
+            const double eff = tile == 128 ? eff128[conc] : eff64[conc];
+            double cost = (double)per_cu * unit * (double)(kt_per + 3) / eff;
+            if (sp > 1) cost += 12.0 + 6.5 * sp * mn;
+            if (cost < best_cost) { best_cost = cost; best = GemmCfg{tile, sp}; }
+        }
+    }
+    return best;
+}
+
+template <bool A_KC, bool B_KC, int T>
+static int launch_tile(const char *name, GemmArgs &g, bool aligned, int splits, hipStream_t st) {
+    constexpr int TA = A_KC ? Img<T>::KC : Img<T>::MC;
+    constexpr int TB = B_KC ? Img<T>::KC : Img<T>::MC;
+    const size_t smem = (size_t)2 * (TA + TB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, true, T>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, false, T>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return GIST_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    g.tiles_m = (int)ceil_div(g.m, T);
+    g.tiles_n = (int)ceil_div(g.n, T);
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
+    if (aligned)
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, T>), grid, dim3(256), smem, st, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, T>), grid, dim3(256), smem, st, g);
+    return launch_status(name);
 }
 
 template <bool A_KC, bool B_KC>
@@ -357,51 +443,24 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
     const bool aligned = aligned16(a) && (lda % 4 == 0) && lda >= 4 && aligned16(b) &&
                          (ldb % 4 == 0) && ldb >= 4 && k > 0;
-    g.tiles_m = (int)ceil_div(m, BM);
-    g.tiles_n = (int)ceil_div(n, BN);
-    int splits = choose_splits(m, n, k);
+    GemmCfg cfg = choose_cfg(m, n, k);
+    int splits = cfg.splits;
     if (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits = 1;
     g.k_per_split = (int)(ceil_div(ceil_div(k, BK), splits) * BK);
     splits = (int)ceil_div(k, g.k_per_split > 0 ? g.k_per_split : 1);
     if (splits < 1) splits = 1;
     if (k == 0) { g.k_per_split = BK; splits = 1; }
-    constexpr int TA = A_KC ? TILE_KC : TILE_MC;
-    constexpr int TB = B_KC ? TILE_KC : TILE_MC;
-    const size_t smem = (size_t)2 * (TA + TB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, true>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-            return GIST_ELAUNCH;
-        }
-        attr_set = true;
-    }
-    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
-    auto launch = [&]() {
-        if (aligned)
-            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, dim3(256), smem, st, g);
-        else
-            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, dim3(256), smem, st, g);
-    };
     if (splits == 1) {
         g.split_stride = 0;
-        launch();
-        return launch_status(name);
+    } else {
+        g.c = static_cast<float *>(ws);
+        g.ldc = n;
+        g.split_stride = m * n;
+        g.bias = nullptr;
     }
-    g.c = static_cast<float *>(ws);
-    g.ldc = n;
-    g.split_stride = m * n;
-    g.bias = nullptr;
-    launch();
-    int rc = launch_status(name);
-    if (rc) return rc;
+    int rc = cfg.tile == 128 ? launch_tile<A_KC, B_KC, 128>(name, g, aligned, splits, st)
+                             : launch_tile<A_KC, B_KC, 64>(name, g, aligned, splits, st);
+    if (rc || splits == 1) return rc;
     const int64_t total = m * n;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
                        st, static_cast<const float *>(ws), m * n, splits, bias, c, ldc, (int)m,
@@ -413,7 +472,7 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
 
 extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const int s = gist::choose_splits(m, n, k);
+    const int s = gist::choose_cfg(m, n, k).splits;
     return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }
 
