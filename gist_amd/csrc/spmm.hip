@@ -16,6 +16,8 @@
 // HBM-bound: per launch the algorithmic traffic is rowptr + col + X once + Y once
 // (DESIGN.md).  Column tiles are dealt to XCDs (blockIdx % 8 shares an L2) so that
 // one tile of X (n_rows x 1 KiB) is gathered out of ONE L2 instead of eight.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gist {
@@ -162,6 +164,255 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide rows (d/VEC >= 64 lanes): ONE WORKGROUP PER ROW.  A single wave walking a row is a
+// chain of dependent L2 round trips (4 loads per trip): a 330-neighbour hub row of a
+// power-law graph takes ~80 trips and sets the kernel's duration.  Here the row's
+// neighbour list is dealt to the 4 waves in interleaved slices of 16 (wave w takes
+// neighbours [16w, 16w+16) of every 64), 8 row reads in flight per wave (16 in flight cost
+// 158 VGPRs and ran slower), and the four partial sums are combined through LDS in wave
+// order (deterministic).  A 64-neighbour row costs 2 trips per wave instead of 16; a hub
+// row 11 instead of 83.
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
+    int n_rows, int d, const float *__restrict__ out_scale,
+    const float *__restrict__ src_scale, int accumulate, int n_col_tiles, int chunk_rows) {
+    __shared__ float part[3][kWave * VEC];
+    // Row chunks (~ one METIS part: consecutive batch rows whose neighbours are mostly in the
+    // same chunk) are dealt to XCDs -- workgroups b, b+8, b+16, ... share an L2 -- so the
+    // rows an XCD gathers are the ones its own L2 already holds, instead of every L2
+    // missing on all of X.  (Speed only: the result does not depend on placement.)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, i = b >> 3;
+    const int per = chunk_rows * n_col_tiles;
+    const int rem = i % per;
+    const int row = (xcd + 8 * (i / per)) * chunk_rows + rem / n_col_tiles;
+    const int ct = rem % n_col_tiles;
+    if (row >= n_rows) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c0 = (ct * kWave + lane) * VEC;
+    const bool active = c0 < d;
+    const int beg = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    const float *xc = x + c0;
+    // lanes 0..15 of wave w hold the ids of neighbours base + 16w + lane
+    for (int base = beg + 16 * wave; base < end; base += kWave) {
+        const int e = base + (lane & 15);
+        const bool ok = (lane < 16) && (e < end);
+        const int my = ok ? col[e] : 0;
+        float mys = 1.f;
+        if (src_scale) mys = ok ? src_scale[my] : 0.f;
+        const int cnt = min(16, end - base);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (8 * h < cnt) {                            // wave-uniform
+                float v[8][VEC];
+                float s[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int jj = min(8 * h + t, cnt - 1);
+                    const int u = __builtin_amdgcn_readlane(my, jj);
+                    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                                    __builtin_bit_cast(int, mys), jj));
+                    s[t] = (8 * h + t < cnt) ? s0 : 0.f;   // clamped duplicates contribute 0
+                    if (active) vload<VEC>(xc + (int64_t)u * ldx, v[t]);
+                }
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(s[t], v[t][k], acc[k]);
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) part[wave - 1][lane * VEC + k] = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += part[w][lane * VEC + k];
+        const float os = out_scale ? out_scale[row] : 1.f;
+        float *yp = y + (int64_t)row * ldy + c0;
+        float o[VEC];
+        if (accumulate) {
+            vload<VEC>(yp, o);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = fmaf(os, acc[k], o[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
+        }
+        vstore<VEC>(yp, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-staged variant for cluster batches.  Rows come in LOCALITY BLOCKS (a METIS part of a
+// Cluster-GCN batch: ~100 consecutive rows whose neighbours are ~97% inside the same part).
+// One 1024-thread workgroup (16 waves) owns (row block, column tile).  It stages, with
+// coalesced loads, everything the block needs into LDS ONCE:
+//   * the block's X tile [<=128 rows x 64*VEC floats]  (every element of X leaves L2/HBM once)
+//   * its row pointers and its column indices (one contiguous CSR range, up to 8192 ids)
+//   * the source scales of its rows (backward form)
+// Each wave then walks rows wave, wave+16, ...: row extent and neighbour ids come from LDS
+// (no dependent global-load chain), a neighbour inside the block is an LDS row read -- the
+// id is a scalar, so "all 8 of this group are local" is ONE wave-uniform branch followed
+// by 8 independent LDS reads -- and only cross-block neighbours fall back to the global
+// gather.  nnz*D*4 bytes of L2 gather traffic become LDS traffic.
+constexpr int kSpmmRB = 128;        // rows staged per block
+constexpr int kSpmmColCap = 8192;   // column ids staged per block
+constexpr int kSpmmBlockedThreads = 1024;
+
+template <int VEC>
+__global__ __launch_bounds__(1024) void spmm_csr_blocked_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
+    int n_rows, int d, const float *__restrict__ out_scale,
+    const float *__restrict__ src_scale, int accumulate,
+    const int32_t *__restrict__ row_blocks, int n_col_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int CW = kWave * VEC;                 // floats per row of the tile
+    constexpr int NW = kSpmmBlockedThreads / kWave;
+    float *tile = smem_f;                                        // [kSpmmRB][CW]
+    int32_t *cols = reinterpret_cast<int32_t *>(tile + kSpmmRB * CW);   // [kSpmmColCap]
+    int32_t *rp = cols + kSpmmColCap;                            // [kSpmmRB + 1]
+    float *scl = reinterpret_cast<float *>(rp + kSpmmRB + 4);    // [kSpmmRB]
+
+    const int ct = blockIdx.x % n_col_tiles;
+    const int rbk = blockIdx.x / n_col_tiles;
+    int r0, r1;
+    if (row_blocks) { r0 = row_blocks[rbk]; r1 = row_blocks[rbk + 1]; }
+    else { r0 = rbk * kSpmmRB; r1 = min(n_rows, r0 + kSpmmRB); }
+    r1 = min(r1, n_rows);
+    const int nloc = min(r1 - r0, kSpmmRB);
+    if (nloc <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = ct * CW + lane * VEC;
+    const bool active = c0 < d;
+
+    // ---- stage ------------------------------------------------------------------------
+    const int cbeg = rowptr[r0];
+    const int ncol = min(rowptr[r0 + nloc] - cbeg, kSpmmColCap);
+    for (int i = threadIdx.x; i <= nloc; i += kSpmmBlockedThreads) rp[i] = rowptr[r0 + i];
+    for (int i = threadIdx.x; i < ncol; i += kSpmmBlockedThreads) cols[i] = col[cbeg + i];
+    if (src_scale)
+        for (int i = threadIdx.x; i < nloc; i += kSpmmBlockedThreads) scl[i] = src_scale[r0 + i];
+    for (int rr = wave; rr < nloc; rr += NW) {
+        float v[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+        if (active) vload<VEC>(x + (int64_t)(r0 + rr) * ldx + c0, v);
+        vstore<VEC>(tile + rr * CW + lane * VEC, v);
+    }
+    __syncthreads();
+
+    const float *xc = x + c0;
+    const float *tl = tile + lane * VEC;
+    for (int row = r0 + wave; row < r1; row += NW) {
+        const int lr = row - r0;
+        int beg, end;
+        if (lr < nloc) { beg = rp[lr]; end = rp[lr + 1]; }
+        else { beg = rowptr[row]; end = rowptr[row + 1]; }       // oversize block tail
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int base = beg; base < end; base += kWave) {
+            const int e = base + lane;
+            int my = 0;
+            if (e < end) {
+                const int ci = e - cbeg;
+                my = (ci < ncol) ? cols[ci] : col[e];
+            }
+            float mys = 1.f;
+            if (src_scale) {
+                const unsigned ml = (unsigned)(my - r0);
+                mys = (e < end) ? (ml < (unsigned)nloc ? scl[ml] : src_scale[my]) : 0.f;
+            }
+            const int cnt = min(kWave, end - base);
+            const bool is_remote = (e < end) && ((unsigned)(my - r0) >= (unsigned)nloc);
+            unsigned long long rem = __ballot(is_remote);
+            // ---- pass A: every neighbour of the chunk out of LDS, branch free.  A remote
+            // neighbour reads row 0 of the tile with scale 0 (3% wasted reads) so that the
+            // eight reads of a group are independent and pipeline.
+            for (int j = 0; j < cnt; j += 8) {
+                float v[8][VEC];
+                float sc[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int jj = min(j + t, cnt - 1);
+                    const int u = __builtin_amdgcn_readlane(my, jj);
+                    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                                    __builtin_bit_cast(int, mys), jj));
+                    const unsigned lu = (unsigned)(u - r0);
+                    const bool ok = (j + t < cnt) && (lu < (unsigned)nloc);
+                    sc[t] = ok ? s0 : 0.f;
+                    vload<VEC>(tl + (ok ? lu : 0u) * CW, v[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(sc[t], v[t][k], acc[k]);
+            }
+            // ---- pass B: the few cross-block neighbours, four global row reads in flight
+            while (rem) {
+                int u[4];
+                float sc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (rem) {
+                        const int jj = __builtin_ctzll(rem);
+                        rem &= rem - 1;
+                        u[t] = __builtin_amdgcn_readlane(my, jj);
+                        sc[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                               __builtin_bit_cast(int, mys), jj));
+                    } else {
+                        u[t] = row;          // any readable row; contributes 0
+                        sc[t] = 0.f;
+                    }
+                }
+                if (active) {
+                    float v[4][VEC];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) vload<VEC>(xc + (int64_t)u[t] * ldx, v[t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(sc[t], v[t][k], acc[k]);
+                }
+            }
+        }
+        if (active) {
+            const float os = out_scale ? out_scale[row] : 1.f;
+            float *yp = y + (int64_t)row * ldy + c0;
+            float o[VEC];
+            if (accumulate) {
+                vload<VEC>(yp, o);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = fmaf(os, acc[k], o[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
+            }
+            vstore<VEC>(yp, o);
+        }
+    }
+}
+
 __global__ void in_degree_norm_kernel(const int32_t *__restrict__ rowptr, int64_t n,
                                       float *__restrict__ norm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,6 +432,19 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
     const int n_col_tiles = (int)ceil_div(lanes, lpr);
     const int n_row_blocks = (int)ceil_div(n_rows, kSpmmWavesPerBlock);
     const int xcd_tiles = n_col_tiles >= 8 ? 1 : 0;
+    if (lpr == 64) {   // wide rows: one workgroup per (row, column tile), waves share the row
+        static const int chunk_rows = getenv("GIST_SPMM_CHUNK") ? atoi(getenv("GIST_SPMM_CHUNK")) : 128;
+        const int64_t n_chunks = ceil_div(n_rows, chunk_rows);
+        const int64_t g2 = 8 * ceil_div(n_chunks, 8) * chunk_rows * n_col_tiles;
+        if (g2 > 0x7fffffffLL) {
+            set_error("gist_spmm_csr_f32: grid too large");
+            return GIST_EINVAL;
+        }
+        hipLaunchKernelGGL((spmm_csr_rowsplit_kernel<VEC>), dim3((unsigned)g2), dim3(256), 0, st,
+                           rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale, src_scale,
+                           accumulate, n_col_tiles, chunk_rows);
+        return launch_status("gist_spmm_csr_f32");
+    }
     const int64_t grid = xcd_tiles ? (int64_t)8 * ceil_div(n_col_tiles, 8) * n_row_blocks
                                    : (int64_t)n_row_blocks * n_col_tiles;
     if (grid > 0x7fffffffLL) {
@@ -199,6 +463,35 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
     }
 #undef GIST_SPMM_LAUNCH
     return launch_status("gist_spmm_csr_f32");
+}
+
+template <int VEC>
+static int launch_spmm_blocked(const int32_t *rowptr, const int32_t *col, const float *x,
+                               int64_t ldx, float *y, int64_t ldy, int64_t n_rows, int64_t d,
+                               const float *out_scale, const float *src_scale, int accumulate,
+                               const int32_t *row_blocks, int64_t n_row_blocks, hipStream_t st) {
+    const int n_col_tiles = (int)ceil_div(d, kWave * VEC);
+    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, kSpmmRB);
+    const int64_t grid = nb * n_col_tiles;
+    if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
+    const size_t smem = (size_t)kSpmmRB * kWave * VEC * sizeof(float) +
+                        (size_t)(kSpmmColCap + kSpmmRB + 4 + kSpmmRB) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&spmm_csr_blocked_kernel<VEC>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return GIST_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((spmm_csr_blocked_kernel<VEC>), dim3((unsigned)grid),
+                       dim3(kSpmmBlockedThreads), smem, st,
+                       rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale, src_scale,
+                       accumulate, row_blocks, n_col_tiles);
+    return launch_status("gist_spmm_csr_blocked_f32");
 }
 
 }  // namespace gist
@@ -232,4 +525,31 @@ extern "C" int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, cons
                               accumulate, st);
     return launch_spmm<1>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                           accumulate, st);
+}
+
+extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col, const float *x,
+                                         int64_t ldx, float *y, int64_t ldy, int64_t n_rows,
+                                         int64_t d, const float *out_scale,
+                                         const float *src_scale, int accumulate,
+                                         const int32_t *row_blocks, int64_t n_row_blocks,
+                                         gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_spmm_csr_blocked_f32: negative size");
+    if (n_rows == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && x && y, "gist_spmm_csr_blocked_f32: null pointer");
+    GIST_REQUIRE(ldx >= d && ldy >= d, "gist_spmm_csr_blocked_f32: leading dimension < d");
+    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_spmm_csr_blocked_f32: size >= 2^31");
+    GIST_REQUIRE(row_blocks == nullptr || n_row_blocks > 0,
+                 "gist_spmm_csr_blocked_f32: row_blocks given but n_row_blocks <= 0");
+    // narrow rows keep every lane busy only in the lane-group kernel
+    if (d < 128)
+        return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                 accumulate, stream);
+    hipStream_t st = as_stream(stream);
+    const bool a8 = d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y);
+    if (a8)   // 8 B per lane: 64 KiB of LDS per workgroup -> two workgroups per CU
+        return launch_spmm_blocked<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale,
+                                      src_scale, accumulate, row_blocks, n_row_blocks, st);
+    return launch_spmm_blocked<1>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                  accumulate, row_blocks, n_row_blocks, st);
 }

@@ -69,6 +69,19 @@ int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col,
                       const float *out_scale, const float *src_scale,
                       int accumulate, gist_stream_t stream);
 
+/* Same result as gist_spmm_csr_f32, for row sets made of LOCALITY BLOCKS -- the METIS
+ * parts a Cluster-GCN batch is the union of (cluster_gcn/partition_utils.py:21-24): rows
+ * [row_blocks[b], row_blocks[b+1]) form block b (row_blocks = NULL: uniform 128-row blocks).
+ * Each workgroup stages its block's X tile in LDS once and reads in-block neighbours from
+ * LDS; only cross-block neighbours are gathered from L2/HBM.  Blocks larger than 128 rows
+ * stay correct (rows beyond the first 128 are gathered globally). */
+int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col,
+                              const float *x, int64_t ldx, float *y, int64_t ldy,
+                              int64_t n_rows, int64_t d,
+                              const float *out_scale, const float *src_scale, int accumulate,
+                              const int32_t *row_blocks, int64_t n_row_blocks,
+                              gist_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Dense projection (fp32 MFMA, exact fp32 arithmetic)
  * ------------------------------------------------------------------------- */

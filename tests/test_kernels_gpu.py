@@ -402,3 +402,46 @@ print('WORST', worst)
     assert out.returncode == 0, out.stderr[-800:]
     worst = float([l for l in out.stdout.split('\n') if l.startswith('WORST')][0].split()[1])
     assert worst < 5e-4, worst          # |sum of 2046 N(0,1) products| ~ 45, fp32 accumulation
+
+
+@pytest.mark.parametrize('n,d,deg,hub', [(300, 602, 8, 0), (513, 256, 16, 700), (1000, 1024, 20, 0),
+                                         (2046, 4096, 64, 3000), (700, 130, 5, 0), (90, 12, 7, 0)])
+@pytest.mark.parametrize('blocks', ['uniform', 'parts', 'oversize'])
+def test_spmm_blocked_lds(hip, n, d, deg, hub, blocks):
+    """LDS-staged kernel == plain kernel semantics, for uniform 128-row blocks, ragged
+    'METIS part' blocks and blocks larger than the 128 rows that fit in LDS; graph with
+    strong in-block locality plus remote edges and a hub."""
+    rs = np.random.RandomState(n + d)
+    # locality: most edges inside chunks of ~100 rows
+    m = n * deg
+    dst = rs.randint(0, max(n - 1, 1), m)
+    near = (dst // 100) * 100 + rs.randint(0, 100, m)
+    src = np.where(rs.rand(m) < 0.9, np.minimum(near, n - 1), rs.randint(0, n, m))
+    if hub:
+        src = np.concatenate([src, rs.randint(0, n, hub)])
+        dst = np.concatenate([dst, np.full(hub, 1)])
+    rowptr, col = O.csr_from_edges(src, dst, n)
+    x = rs.randn(n, 2 * d).astype(np.float32)
+    norm = O.in_degree_norm(rowptr)
+    if blocks == 'uniform':
+        rb = None
+    else:
+        step = 100 if blocks == 'parts' else 300
+        cuts = list(range(0, n, step)) + [n]
+        cuts = sorted(set(cuts + ([57] if n > 57 else [])))
+        rb = dev(np.array(cuts), torch.int32)
+    rp, cl = dev(rowptr, torch.int32), dev(col, torch.int32)
+    xt = dev(x)
+    hip.spmm(rp, cl, xt[:, :d], xt[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True)
+    ref = x.copy()
+    ref[:, d:] = O.spmm_sum(rowptr, col, np.ascontiguousarray(x[:, :d]), out_scale=norm)
+    close(xt, ref)
+    # backward form: src_scale + accumulate, reversed graph
+    t_rp, t_cl = O.transpose_csr(rowptr, col)
+    g = rs.randn(n, 2 * d).astype(np.float32)
+    gt = dev(g)
+    hip.spmm(dev(t_rp, torch.int32), dev(t_cl, torch.int32), gt[:, d:], gt[:, :d],
+             src_scale=dev(norm), accumulate=True, row_blocks=rb, blocked=True)
+    dh = np.ascontiguousarray(g[:, :d])
+    O.spmm_sum(t_rp, t_cl, g[:, d:], src_scale=norm, out=dh, accumulate=True)
+    close(gt[:, :d], dh)
