@@ -93,11 +93,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
                              '--nproc-per-node %d' % (args.gpus, args.gpus))
-    dev = torch.device('cuda', local_rank)
+    # GIST_BENCH_SHARED_GPU=1 (validation only, never a reported number): every rank uses
+    # cuda:0 and the collectives are staged through the host over gloo, so the N>1 logic can
+    # be exercised on a 1-GPU box.  The product path is RCCL (backend "nccl").
+    shared_gpu = os.environ.get('GIST_BENCH_SHARED_GPU') == '1'
+    dev = torch.device('cuda', 0 if shared_gpu else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
 
     from gist_amd import datasets, hip
     from gist_amd.engine import SageEngine, dims_for
@@ -143,8 +150,22 @@ def main():
                 stdv = 1.0 / np.sqrt(2 * i)
                 base_init.append((rs.uniform(-stdv, stdv, (o, 2 * i)).astype(np.float32),
                                   rs.uniform(-stdv, stdv, o).astype(np.float32)))
+        comm = None
+        if shared_gpu:
+            class HostStagedComm(ist.TorchDistComm):       # validation shim, see above
+                def all_gather_flat(self, out, inp):
+                    o = torch.empty(out.shape, dtype=out.dtype)
+                    dist.all_gather_into_tensor(o, inp.cpu())
+                    out.copy_(o)
+
+                def broadcast(self, t, src=0):
+                    c = t.cpu()
+                    dist.broadcast(c, src=src)
+                    t.copy_(c)
+            comm = HostStagedComm()
         ist_model = ist.DistributedGNNWrapper(ns, None, in_feats, n_classes, dev,
-                                              base_init=base_init, n_max=it.n_max, seed=seed)
+                                              base_init=base_init, n_max=it.n_max, seed=seed,
+                                              comm=comm)
         ist_model.ini_sync_dispatch_model()
         engine = ist_model.engine
         dims = ist_model.sub_dims
@@ -207,7 +228,7 @@ def main():
     elif timing:
         prof = hip.profile_end()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if shared_gpu else dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -236,6 +257,7 @@ def main():
                 'epochs_per_sec_per_rank': round(value / world, 4),
             },
             'final_loss': round(loss_val, 5),
+            **({'INVALID': 'GIST_BENCH_SHARED_GPU validation run: ranks share one GPU, host-staged gloo'} if shared_gpu else {}),
             'host_path': 'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',
         }
         if prof is not None:
