@@ -52,6 +52,7 @@ SIGNATURES = {
     'gist_fill_i32': (_int, [_p, _i64, _i32, _p]),
     'gist_induced_rowptr': (_int, [_p, _p, _p, _i64, _p, _p, _p]),
     'gist_induced_fill': (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+    'gist_extract_batch': (_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
     'gist_gather_rows_f32': (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p]),
     'gist_gather_i32': (_int, [_p, _p, _i64, _p, _p]),
     'gist_block_gather_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),

@@ -176,6 +176,29 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p
     return u >= p ? scale : 0.f;
 }
 
+// Fast path (d % 4 == 0, 16-B aligned rows, even offset): one thread = 4 consecutive
+// elements of one row = two hashes, one 16-B load and store, one 64-bit division.
+__global__ void dropout_vec4_kernel(float *__restrict__ z, int64_t ldz, int64_t n_rows, int64_t d,
+                                    float p, float scale, uint64_t seed, uint64_t offset) {
+    const int64_t quads = n_rows * (d >> 2);
+    const uint64_t sm = seed * 0x9E3779B97F4A7C15ULL;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = q << 2;
+        const int64_t r = e0 / d, c = e0 - r * d;
+        float4 *ptr = reinterpret_cast<float4 *>(z + r * ldz + c);
+        float4 v = *ptr;
+        const uint64_t pair = (offset + (uint64_t)e0) >> 1;
+        const uint64_t h0 = splitmix64(pair + sm), h1 = splitmix64(pair + 1 + sm);
+        const float inv = 1.0f / 16777216.0f;
+        v.x *= ((float)((uint32_t)h0 >> 8) * inv >= p) ? scale : 0.f;
+        v.y *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv >= p) ? scale : 0.f;
+        v.z *= ((float)((uint32_t)h1 >> 8) * inv >= p) ? scale : 0.f;
+        v.w *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv >= p) ? scale : 0.f;
+        *ptr = v;
+    }
+}
+
 __global__ void dropout_kernel(float *__restrict__ z, int64_t ldz, int64_t n_rows, int64_t d,
                                float p, float scale, uint64_t seed, uint64_t offset) {
     const int64_t total = n_rows * d;
@@ -190,26 +213,52 @@ __global__ void dropout_kernel(float *__restrict__ z, int64_t ldz, int64_t n_row
 // ---------------------------------------------------------------------------
 // column sum (bias gradient), two deterministic stages
 // ---------------------------------------------------------------------------
-constexpr int kColsumRows = 128;
+constexpr int kColsumRows = 64;
 
-__global__ void colsum_stage1_kernel(const float *__restrict__ g, int64_t ldg, int n_rows, int d,
-                                     float *__restrict__ partials) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
+// stage 1: workgroup = 64 columns x 4 row lanes over a chunk of 64 rows; a wave reads 64
+// consecutive floats of one row (256 B), four independent row reads in flight per thread,
+// row lanes combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float *__restrict__ g,
+                                                            int64_t ldg, int n_rows, int d,
+                                                            float *__restrict__ partials) {
+    __shared__ float red[3][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * kColsumRows;
     const int r1 = min(n_rows, r0 + kColsumRows);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += g[(int64_t)r * ldg + c];
-    partials[(int64_t)blockIdx.y * d + c] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < d) {
+        const float *p = g + c;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            s0 += p[(int64_t)r * ldg];
+            s1 += p[(int64_t)(r + 4) * ldg];
+            s2 += p[(int64_t)(r + 8) * ldg];
+            s3 += p[(int64_t)(r + 12) * ldg];
+        }
+        for (; r < r1; r += 4) s0 += p[(int64_t)r * ldg];
+    }
+    const float s = (s0 + s1) + (s2 + s3);
+    if (rl > 0) red[rl - 1][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < d)
+        partials[(int64_t)blockIdx.y * d + c] = ((s + red[0][cl]) + red[1][cl]) + red[2][cl];
 }
 
 __global__ void colsum_stage2_kernel(const float *__restrict__ partials, int chunks, int d,
                                      float *__restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partials[(int64_t)k * d + c];
-    out[c] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < chunks; k += 4) {
+        s0 += partials[(int64_t)k * d + c];
+        s1 += partials[(int64_t)(k + 1) * d + c];
+        s2 += partials[(int64_t)(k + 2) * d + c];
+        s3 += partials[(int64_t)(k + 3) * d + c];
+    }
+    for (; k < chunks; ++k) s0 += partials[(int64_t)k * d + c];
+    out[c] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------
@@ -369,6 +418,13 @@ extern "C" int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d
     if (n_rows == 0 || d == 0 || p == 0.f) return GIST_OK;
     GIST_REQUIRE(z && ldz >= d, "gist_dropout_f32: bad buffer");
     const int64_t total = n_rows * d;
+    if (d % 4 == 0 && ldz % 4 == 0 && aligned16(z) && (offset & 1) == 0) {
+        const int64_t quads = total / 4;
+        const unsigned grid = (unsigned)(ceil_div(quads, 256) < 16384 ? ceil_div(quads, 256) : 16384);
+        hipLaunchKernelGGL(dropout_vec4_kernel, dim3(grid), dim3(256), 0, as_stream(stream), z, ldz,
+                           n_rows, d, p, 1.0f / (1.0f - p), seed, offset);
+        return launch_status("gist_dropout_f32");
+    }
     const unsigned grid = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(256), 0, as_stream(stream), z, ldz, n_rows,
                        d, p, 1.0f / (1.0f - p), seed, offset);
@@ -389,10 +445,10 @@ extern "C" int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int6
     if (chunks > 0) {
         GIST_REQUIRE(g && partials && ldg >= d, "gist_colsum_f32: bad buffer");
         GIST_REQUIRE(chunks <= 65535, "gist_colsum_f32: too many rows");
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)chunks),
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)ceil_div(d, 64), (unsigned)chunks),
                            dim3(256), 0, st, g, ldg, (int)n_rows, (int)d, partials);
     }
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(d, 64)), dim3(64), 0, st,
                        partials, chunks, (int)d, out);
     return launch_status("gist_colsum_f32");
 }

@@ -102,18 +102,11 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
 
     if (flags & GIST_STEP_EXTRACT) {
         GIST_REQUIRE(ids != nullptr, "gist_sage_step: null ids");
-        GIST_TRY(gist_induced_mark(ids, n, p->remap, s));
-        GIST_TRY(gist_induced_rowptr(p->g_rowptr, p->g_col, ids, n, p->remap, p->rowptr, s));
-        GIST_TRY(gist_induced_fill(p->g_rowptr, p->g_col, ids, n, p->remap, p->rowptr, p->col,
-                                   p->col_capacity, s));
-        GIST_TRY(gist_induced_rowptr(p->g_t_rowptr, p->g_t_col, ids, n, p->remap, p->t_rowptr, s));
-        GIST_TRY(gist_induced_fill(p->g_t_rowptr, p->g_t_col, ids, n, p->remap, p->t_rowptr,
-                                   p->t_col, p->col_capacity, s));
-        GIST_TRY(gist_induced_unmark(ids, n, p->remap, s));
-        GIST_TRY(gist_in_degree_norm_f32(p->rowptr, n, p->norm, s));
-        GIST_TRY(gist_gather_rows_f32(p->feat, p->ld_feat, ids, n, p->layer[0].n_in,
-                                      p->layer[0].Z, p->layer[0].ldz, s));
-        GIST_TRY(gist_gather_i32(p->labels_all, ids, n, p->labels, s));
+        GIST_TRY(gist_extract_batch(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n,
+                                    p->remap, p->rowptr, p->col, p->t_rowptr, p->t_col,
+                                    p->col_capacity, p->norm, p->feat, p->ld_feat,
+                                    p->layer[0].n_in, p->layer[0].Z, p->layer[0].ldz,
+                                    p->labels_all, p->labels, s));
     }
 
     // ---- forward (modules.py:310-314 / :218-237) ---------------------------------

@@ -96,6 +96,121 @@ __global__ __launch_bounds__(256) void induced_fill_kernel(
     }
 }
 
+// ---- fused batch extraction (5 launches instead of 11) -----------------------------------
+// blockIdx.y selects the structure: 0 = in-edge CSR (also writes norm = 1/in-degree),
+// 1 = out-edge CSR.
+struct CsrPair {
+    const int32_t *rowptr[2];
+    const int32_t *col[2];
+    int32_t *sub_rowptr[2];
+    int32_t *sub_col[2];
+};
+
+__global__ __launch_bounds__(256) void induced_count2_kernel(CsrPair p,
+                                                             const int32_t *__restrict__ ids,
+                                                             int n_ids,
+                                                             const int32_t *__restrict__ remap,
+                                                             float *__restrict__ norm) {
+    const int which = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t *rowptr = p.rowptr[which], *col = p.col[which];
+    const int v = ids[i];
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    int cnt = 0;
+    for (int base = beg; base < end; base += kWave) {
+        const int e = base + lane;
+        const bool keep = (e < end) && (remap[col[e]] >= 0);
+        cnt += __popcll(__ballot(keep));
+    }
+    if (lane == 0) {
+        p.sub_rowptr[which][i + 1] = cnt;
+        if (which == 0) norm[i] = cnt > 0 ? 1.f / (float)cnt : 0.f;
+    }
+}
+
+// one 1024-thread workgroup per structure
+__global__ __launch_bounds__(1024) void scan_rowptr2_kernel(int32_t *p0, int32_t *p1, int n) {
+    int32_t *__restrict__ p = blockIdx.x == 0 ? p0 : p1;
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) { p[0] = 0; carry_s = 0; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + t;
+        int v = (i < n) ? p[i + 1] : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(v, off);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int pre = carry_s;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (i < n) p[i + 1] = v + pre;
+        __syncthreads();
+        if (t == 1023) carry_s = v + pre;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void induced_fill2_kernel(CsrPair p,
+                                                            const int32_t *__restrict__ ids,
+                                                            int n_ids,
+                                                            const int32_t *__restrict__ remap,
+                                                            int64_t capacity) {
+    const int which = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t *rowptr = p.rowptr[which], *col = p.col[which];
+    int32_t *sub_col = p.sub_col[which];
+    const int v = ids[i];
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    int64_t w = p.sub_rowptr[which][i];
+    for (int base = beg; base < end; base += kWave) {
+        const int e = base + lane;
+        int r = -1;
+        if (e < end) r = remap[col[e]];
+        const unsigned long long m = __ballot(r >= 0);
+        if (r >= 0) {
+            const int64_t pos = w + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < capacity) sub_col[pos] = r;
+        }
+        w += __popcll(m);
+    }
+}
+
+// features + label of batch row i, and remap[ids[i]] back to -1 (runs after both fills)
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restrict__ feat,
+                                                           int64_t ld_feat,
+                                                           const int32_t *__restrict__ ids,
+                                                           int n_ids, int d,
+                                                           float *__restrict__ z0, int64_t ldz0,
+                                                           const int32_t *__restrict__ labels_all,
+                                                           int32_t *__restrict__ labels,
+                                                           int32_t *__restrict__ remap) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_ids) return;
+    const int lane = threadIdx.x & 63;
+    const int v = ids[i];
+    const float *s = feat + (int64_t)v * ld_feat;
+    float *o = z0 + (int64_t)i * ldz0;
+    for (int c = lane * VEC; c < d; c += kWave * VEC) {
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + c) = *reinterpret_cast<const float4 *>(s + c);
+        else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o + c) = *reinterpret_cast<const float2 *>(s + c);
+        else o[c] = s[c];
+    }
+    if (lane == 0) {
+        if (labels_all) labels[i] = labels_all[v];
+        remap[v] = -1;
+    }
+}
+
 // dst[i, :] = src[ids[i], :]; one wave per row
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src,
@@ -285,4 +400,41 @@ extern "C" int gist_mean_rows_f32(const float *src, int64_t stride, int64_t n_sr
     hipLaunchKernelGGL(mean_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
                        as_stream(stream), src, stride, (int)n_src, n, out);
     return launch_status("gist_mean_rows_f32");
+}
+
+extern "C" int gist_extract_batch(const int32_t *g_rowptr, const int32_t *g_col,
+                                  const int32_t *g_t_rowptr, const int32_t *g_t_col,
+                                  const int32_t *ids, int64_t n, int32_t *remap, int32_t *rowptr,
+                                  int32_t *col, int32_t *t_rowptr, int32_t *t_col,
+                                  int64_t col_capacity, float *norm, const float *feat,
+                                  int64_t ld_feat, int64_t n_feat, float *z0, int64_t ldz0,
+                                  const int32_t *labels_all, int32_t *labels,
+                                  gist_stream_t stream) {
+    GIST_REQUIRE(n > 0 && n < (1LL << 31) - 8, "gist_extract_batch: bad n");
+    GIST_REQUIRE(g_rowptr && g_col && g_t_rowptr && g_t_col && ids && remap && rowptr && col &&
+                     t_rowptr && t_col && norm && feat && z0,
+                 "gist_extract_batch: null pointer");
+    GIST_REQUIRE(n_feat > 0 && ld_feat >= n_feat && ldz0 >= n_feat && n_feat < (1LL << 31),
+                 "gist_extract_batch: bad feature shape");
+    GIST_REQUIRE(col_capacity >= 0, "gist_extract_batch: negative capacity");
+    hipStream_t st = as_stream(stream);
+    CsrPair p;
+    p.rowptr[0] = g_rowptr; p.col[0] = g_col; p.sub_rowptr[0] = rowptr; p.sub_col[0] = col;
+    p.rowptr[1] = g_t_rowptr; p.col[1] = g_t_col; p.sub_rowptr[1] = t_rowptr; p.sub_col[1] = t_col;
+    const unsigned nb4 = (unsigned)ceil_div(n, 4);
+    hipLaunchKernelGGL(mark_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, ids, n, remap, 0);
+    hipLaunchKernelGGL(induced_count2_kernel, dim3(nb4, 2), dim3(256), 0, st, p, ids, (int)n, remap, norm);
+    hipLaunchKernelGGL(scan_rowptr2_kernel, dim3(2), dim3(1024), 0, st, rowptr, t_rowptr, (int)n);
+    hipLaunchKernelGGL(induced_fill2_kernel, dim3(nb4, 2), dim3(256), 0, st, p, ids, (int)n, remap,
+                       col_capacity);
+    if (n_feat % 4 == 0 && ld_feat % 4 == 0 && ldz0 % 4 == 0 && aligned16(feat) && aligned16(z0))
+        hipLaunchKernelGGL(gather_batch_kernel<4>, dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
+                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap);
+    else if (n_feat % 2 == 0 && ld_feat % 2 == 0 && ldz0 % 2 == 0 && aligned8(feat) && aligned8(z0))
+        hipLaunchKernelGGL(gather_batch_kernel<2>, dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
+                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap);
+    else
+        hipLaunchKernelGGL(gather_batch_kernel<1>, dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
+                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap);
+    return launch_status("gist_extract_batch");
 }

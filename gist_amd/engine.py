@@ -130,15 +130,8 @@ class ClusterBatcher(object):
             raise ValueError('gist_amd: batch of %d rows exceeds n_max=%d' % (n, self.n_max))
         g = self.g
         rp, trp = self.rowptr[:n + 1], self.t_rowptr[:n + 1]
-        hip.induced_mark(ids, self.remap)
-        hip.induced_rowptr(g.rowptr, g.col, ids, self.remap, rp)
-        hip.induced_fill(g.rowptr, g.col, ids, self.remap, rp, self.col)
-        hip.induced_rowptr(g.t_rowptr, g.t_col, ids, self.remap, trp)
-        hip.induced_fill(g.t_rowptr, g.t_col, ids, self.remap, trp, self.t_col)
-        hip.induced_mark(ids, self.remap, unmark=True)
-        hip.in_degree_norm(rp, out=self.norm)
-        hip.gather_rows(self.feat, ids, z0_left)
-        hip.gather_i32(self.labels, ids, self.lab)
+        hip.extract_batch(g, ids, self.remap, rp, self.col, trp, self.t_col, self.norm, self.feat,
+                          z0_left, self.labels, self.lab)
         b = Batch()
         b.n, b.rowptr, b.col, b.t_rowptr, b.t_col = n, rp, self.col, trp, self.t_col
         b.norm, b.labels, b.ids = self.norm[:n], self.lab[:n], ids
@@ -168,7 +161,8 @@ class SageEngine(object):
         wide = max([2 * i for (i, o) in self.dims[1:]] + [4])
         self.dZ = torch.zeros(self.n_max * wide, **f32)
         max_out = max(o for (i, o) in self.dims)
-        self.partials = torch.zeros(max(1, (self.n_max + 127) // 128) * max_out, **f32)
+        self.partials = torch.zeros(
+            max(1, hip._lib.load().gist_colsum_partials(self.n_max)) * max_out, **f32)
         self.row_loss = torch.zeros(self.n_max, **f32)
         self.loss = torch.zeros(1, **f32)
         self.correct = torch.zeros(1, dtype=torch.int32, device=device)

@@ -335,6 +335,29 @@ def induced_fill(rowptr, col, ids, remap, sub_rowptr, sub_col):
     return sub_col
 
 
+def extract_batch(g, ids, remap, rowptr, col, t_rowptr, t_col, norm, feat, z0_left, labels_all,
+                  labels):
+    """Fused cluster-batch extraction (gist_extract_batch): induced in-/out-edge CSR, norm,
+    feature + label gather, remap reset."""
+    L = _lib.load()
+    n = ids.numel()
+    fp, ldf = _mat(feat, 'feat')
+    zp, ldz = _mat(z0_left, 'z0')
+    if tuple(z0_left.shape) != (n, feat.shape[1]):
+        raise ValueError('gist_amd: extract_batch z0 shape mismatch')
+    if col.numel() != t_col.numel():
+        raise ValueError('gist_amd: extract_batch needs equal col capacities')
+    _lib.check(L.gist_extract_batch(
+        _vec(g.rowptr, 'g.rowptr', torch.int32), _vec(g.col, 'g.col', torch.int32),
+        _vec(g.t_rowptr, 'g.t_rowptr', torch.int32), _vec(g.t_col, 'g.t_col', torch.int32),
+        _vec(ids, 'ids', torch.int32), n, _vec(remap, 'remap', torch.int32),
+        _vec(rowptr, 'rowptr', torch.int32, n + 1), _vec(col, 'col', torch.int32),
+        _vec(t_rowptr, 't_rowptr', torch.int32, n + 1), _vec(t_col, 't_col', torch.int32),
+        col.numel(), _vec(norm, 'norm', torch.float32, n), fp, ldf, feat.shape[1], zp, ldz,
+        _opt(labels_all, 'labels_all', torch.int32), _opt(labels, 'labels', torch.int32, n),
+        _stream()), 'gist_extract_batch')
+
+
 def gather_rows(src, ids, dst):
     L = _lib.load()
     sp, lds = _mat(src, 'src')

@@ -202,6 +202,21 @@ int gist_induced_fill(const int32_t *rowptr, const int32_t *col, const int32_t *
                       int64_t n_ids, const int32_t *remap, const int32_t *sub_rowptr,
                       int32_t *sub_col, int64_t sub_col_capacity, gist_stream_t stream);
 
+/* The whole cluster-batch extraction in ONE call (5 launches): mark, induced row
+ * pointers of the in-edge AND out-edge CSR (+ norm = 1/in-degree, modules.py:239-243),
+ * scans, fills, then feature/label gather into z0 (the left half of layer 0's [h | ah]
+ * buffer) and remap reset.  Same result as the fine-grained calls above.  Replaces
+ * get_subgraph + cluster.to(device), cluster_gcn/partition_utils.py:20-25 and
+ * cluster_gcn_ist_distrib.py:409.  labels_all may be NULL. */
+int gist_extract_batch(const int32_t *g_rowptr, const int32_t *g_col,
+                       const int32_t *g_t_rowptr, const int32_t *g_t_col,
+                       const int32_t *ids, int64_t n, int32_t *remap,
+                       int32_t *rowptr, int32_t *col, int32_t *t_rowptr, int32_t *t_col,
+                       int64_t col_capacity, float *norm,
+                       const float *feat, int64_t ld_feat, int64_t n_feat,
+                       float *z0, int64_t ldz0,
+                       const int32_t *labels_all, int32_t *labels, gist_stream_t stream);
+
 /* dst[i, 0:d] = src[ids[i], 0:d]  -- the ndata['feat'] gather of g.subgraph
  * (partition_utils.py:23) written straight into the left half of layer 0's
  * [h | ah] buffer (ldd). */

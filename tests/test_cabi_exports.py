@@ -38,7 +38,7 @@ def test_host_only_entry_points():
     assert L.gist_gemm_workspace_bytes(0, 5, 5) == 0
     assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) == 0          # enough tiles
     assert L.gist_gemm_workspace_bytes(2046, 41, 8192) > 0             # split-K
-    assert L.gist_colsum_partials(0) == 0 and L.gist_colsum_partials(129) == 2
+    assert L.gist_colsum_partials(0) == 0 and L.gist_colsum_partials(129) == 3
     # argument validation happens before any device work
     assert L.gist_spmm_csr_f32(None, None, None, 4, None, 4, 3, 4, None, None, 0, None) == -1
     assert b'null pointer' in L.gist_last_error()
