@@ -37,12 +37,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Block tiles: 128x128 (each wave 64x64 = 2x2 MFMA tiles) and 64x64 (each wave one 32x32
 // MFMA tile) for outputs whose 128x128 tile count cannot fill / balance 256 CUs.
-constexpr int BK = 32;
-constexpr int LDS_KC = BK + 4;   // k-contiguous image: row stride (floats)
-template <int R> struct Img {    // R = rows of a k-contiguous image = columns of an m/n image
-    static constexpr int KC = R * LDS_KC;   // floats
+// k depth of a tile: 32 for the 128x128 block, 64 for the 64x64 block (half the barriers
+// per flop where a SIMD holds a single wave and nothing hides them).
+template <int R, int BK> struct Img {   // R = rows of a k-contiguous image = columns of an m/n image
+    static constexpr int LDK = BK + 4;      // k-contiguous image: row stride (floats)
+    static constexpr int KC = R * LDK;      // floats
     static constexpr int MC = BK * R;
-    static constexpr int ITERS = R / 32;    // float4 per thread per k tile (256 threads)
+    static constexpr int ITERS = R * BK / 1024;   // float4 per thread per k tile (256 threads)
 };
 
 struct GemmArgs {
@@ -52,8 +53,9 @@ struct GemmArgs {
     float *c; int64_t ldc;
     int m, n, k;
     int tiles_m, tiles_n;  // filled by the launcher for the chosen tile edge
-    int k_per_split;       // multiple of BK
+    int k_per_split;       // multiple of 64 (both k depths divide it)
     int64_t split_stride;  // elements between split slabs (0 = write C directly)
+    int setprio;
 };
 
 // ---- global -> register staging --------------------------------------------
@@ -71,15 +73,16 @@ struct GemmArgs {
 
 // k-contiguous operand: element (r, kk) at p[r*ld + kk].  256 threads move
 // 128 rows x 32 k = 1024 float4: thread t -> rows t/8 + 32 i, k chunk t%8.
-template <int IT>
+template <int IT, int BK>
 __device__ __forceinline__ void load_kc_aligned(const float *__restrict__ p, int64_t ld, int rows,
                                                 int kdim, int row0, int k0, float4 (&st)[IT]) {
+    constexpr int CPR = BK / 4;                    // float4 chunks per row
     const int t = threadIdx.x;
-    const int kk = k0 + (t & 7) * 4;
+    const int kk = k0 + (t % CPR) * 4;
     const int kc = min(kk, (int)ld - 4);           // stays inside the row pitch
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int r = min(row0 + (t >> 3) + 32 * i, rows - 1);
+        const int r = min(row0 + t / CPR + (256 / CPR) * i, rows - 1);
         st[i] = *reinterpret_cast<const float4 *>(p + (int64_t)r * ld + kc);
     }
 }
@@ -87,9 +90,9 @@ __device__ __forceinline__ void load_kc_aligned(const float *__restrict__ p, int
 // Reduction-dimension mask of the aligned loaders, applied when the registers are
 // written to LDS -- i.e. AFTER the MFMA block -- so that the loads stay in flight
 // under the MFMAs instead of being waited for right after issue.
-template <int IT>
+template <int IT, int BK>
 __device__ __forceinline__ void mask_kc(float4 (&st)[IT], int kdim, int k0) {
-    const int kk = k0 + (threadIdx.x & 7) * 4;
+    const int kk = k0 + (threadIdx.x % (BK / 4)) * 4;
     if (kk + 3 < kdim) return;
     const bool k0ok = kk + 0 < kdim, k1ok = kk + 1 < kdim, k2ok = kk + 2 < kdim;
 #pragma unroll
@@ -101,9 +104,9 @@ __device__ __forceinline__ void mask_kc(float4 (&st)[IT], int kdim, int k0) {
     }
 }
 
-template <int IT>
+template <int IT, int R>
 __device__ __forceinline__ void mask_mc(float4 (&st)[IT], int kdim, int k0) {
-    constexpr int CPR = IT * 8;                     // float4 chunks per k row (cols / 4)
+    constexpr int CPR = R / 4;                      // float4 chunks per k row (cols / 4)
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int kk = k0 + threadIdx.x / CPR + (256 / CPR) * i;
@@ -111,14 +114,15 @@ __device__ __forceinline__ void mask_mc(float4 (&st)[IT], int kdim, int k0) {
     }
 }
 
-template <int IT>
+template <int IT, int BK>
 __device__ __forceinline__ void load_kc_generic(const float *__restrict__ p, int64_t ld, int rows,
                                                 int kdim, int row0, int k0, float4 (&st)[IT]) {
+    constexpr int CPR = BK / 4;
     const int t = threadIdx.x;
-    const int kk = k0 + (t & 7) * 4;
+    const int kk = k0 + (t % CPR) * 4;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int r = row0 + (t >> 3) + 32 * i;
+        const int r = row0 + t / CPR + (256 / CPR) * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows) {
             const float *src = p + (int64_t)r * ld + kk;
@@ -131,30 +135,31 @@ __device__ __forceinline__ void load_kc_generic(const float *__restrict__ p, int
     }
 }
 
-template <bool ALIGNED, int IT>
+template <bool ALIGNED, int IT, int BK>
 __device__ __forceinline__ void load_kc(const float *__restrict__ p, int64_t ld, int rows, int kdim,
                                         int row0, int k0, float4 (&st)[IT]) {
-    if constexpr (ALIGNED) load_kc_aligned<IT>(p, ld, rows, kdim, row0, k0, st);
-    else load_kc_generic<IT>(p, ld, rows, kdim, row0, k0, st);
+    if constexpr (ALIGNED) load_kc_aligned<IT, BK>(p, ld, rows, kdim, row0, k0, st);
+    else load_kc_generic<IT, BK>(p, ld, rows, kdim, row0, k0, st);
 }
 
-template <int IT>
+template <int IT, int BK>
 __device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&st)[IT]) {
+    constexpr int CPR = BK / 4;
     const int t = threadIdx.x;
-    const int kq = (t & 7) * 4;
+    const int kq = (t % CPR) * 4;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int r = (t >> 3) + 32 * i;
-        *reinterpret_cast<float4 *>(s + r * LDS_KC + kq) = st[i];
+        const int r = t / CPR + (256 / CPR) * i;
+        *reinterpret_cast<float4 *>(s + r * (BK + 4) + kq) = st[i];
     }
 }
 
-// m/n-contiguous operand: element (kk, c) at p[kk*ld + c].  32 k x C cols (C = 32*IT):
-// thread t -> k rows t/CPR + (256/CPR) i, column chunk t % CPR, CPR = C/4.
-template <int IT>
+// m/n-contiguous operand: element (kk, c) at p[kk*ld + c].  BK k rows x R cols:
+// thread t -> k rows t/CPR + (256/CPR) i, column chunk t % CPR, CPR = R/4.
+template <int IT, int R>
 __device__ __forceinline__ void load_mc_aligned(const float *__restrict__ p, int64_t ld, int cols,
                                                 int kdim, int col0, int k0, float4 (&st)[IT]) {
-    constexpr int CPR = IT * 8;
+    constexpr int CPR = R / 4;
     const int t = threadIdx.x;
     const int cq = min(col0 + (t % CPR) * 4, (int)ld - 4);   // clamp inside the row pitch
 #pragma unroll
@@ -164,10 +169,10 @@ __device__ __forceinline__ void load_mc_aligned(const float *__restrict__ p, int
     }
 }
 
-template <int IT>
+template <int IT, int R>
 __device__ __forceinline__ void load_mc_generic(const float *__restrict__ p, int64_t ld, int cols,
                                                 int kdim, int col0, int k0, float4 (&st)[IT]) {
-    constexpr int CPR = IT * 8;
+    constexpr int CPR = R / 4;
     const int t = threadIdx.x;
     const int cq = col0 + (t % CPR) * 4;
 #pragma unroll
@@ -185,16 +190,16 @@ __device__ __forceinline__ void load_mc_generic(const float *__restrict__ p, int
     }
 }
 
-template <bool ALIGNED, int IT>
+template <bool ALIGNED, int IT, int R>
 __device__ __forceinline__ void load_mc(const float *__restrict__ p, int64_t ld, int cols, int kdim,
                                         int col0, int k0, float4 (&st)[IT]) {
-    if constexpr (ALIGNED) load_mc_aligned<IT>(p, ld, cols, kdim, col0, k0, st);
-    else load_mc_generic<IT>(p, ld, cols, kdim, col0, k0, st);
+    if constexpr (ALIGNED) load_mc_aligned<IT, R>(p, ld, cols, kdim, col0, k0, st);
+    else load_mc_generic<IT, R>(p, ld, cols, kdim, col0, k0, st);
 }
 
-template <int IT>
+template <int IT, int R>
 __device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&st)[IT]) {
-    constexpr int CPR = IT * 8, C = IT * 32;
+    constexpr int CPR = R / 4, C = R;
     const int t = threadIdx.x;
     const int cq = (t % CPR) * 4;
 #pragma unroll
@@ -207,11 +212,11 @@ __device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&s
 // ---- LDS -> fragment ---------------------------------------------------------
 // Returns the 4 values a lane feeds to MFMA steps j = 0..3 of k block q for the
 // 32-row (or 32-column) slab starting at `base`.
-template <bool KC, int C>
+template <bool KC, int C, int BK>
 __device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int base, int q, int r,
                                             int hh) {
     if constexpr (KC) {
-        return *reinterpret_cast<const float4 *>(s + (base + r) * LDS_KC + 8 * q + 4 * hh);
+        return *reinterpret_cast<const float4 *>(s + (base + r) * (BK + 4) + 8 * q + 4 * hh);
     } else {
         const float *p = s + (8 * q + 4 * hh) * C + base + r;
         return make_float4(p[0], p[C], p[2 * C], p[3 * C]);
@@ -228,9 +233,10 @@ __device__ __forceinline__ float f4(const float4 &v, int j) {
 template <bool A_KC, bool B_KC, bool ALIGNED, int T>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TA = A_KC ? Img<T>::KC : Img<T>::MC;
-    constexpr int TB = B_KC ? Img<T>::KC : Img<T>::MC;
-    constexpr int IT = Img<T>::ITERS;
+    constexpr int BK = T == 128 ? 32 : 64;
+    constexpr int TA = A_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
+    constexpr int TB = B_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
+    constexpr int IT = Img<T, BK>::ITERS;
     constexpr int W = T / 2;          // wave tile edge
     constexpr int NT = W / 32;        // MFMA tiles per wave per dimension
     // buffer b: A image at smem + b*(TA+TB), B image right behind it
@@ -269,10 +275,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     float4 stA[IT], stB[IT];
     auto gload = [&](int kt) {
         const int k0 = k_begin + kt * BK;
-        if constexpr (A_KC) load_kc<ALIGNED, IT>(g.a, g.lda, g.m, k_end, row0, k0, stA);
-        else load_mc<ALIGNED, IT>(g.a, g.lda, g.m, k_end, row0, k0, stA);
-        if constexpr (B_KC) load_kc<ALIGNED, IT>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
-        else load_mc<ALIGNED, IT>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
+        if constexpr (A_KC) load_kc<ALIGNED, IT, BK>(g.a, g.lda, g.m, k_end, row0, k0, stA);
+        else load_mc<ALIGNED, IT, T>(g.a, g.lda, g.m, k_end, row0, k0, stA);
+        if constexpr (B_KC) load_kc<ALIGNED, IT, BK>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
+        else load_mc<ALIGNED, IT, T>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
     };
     auto sstore = [&](int buf, int kt) {
         float *sa = smem + buf * (TA + TB);
@@ -280,12 +286,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         if constexpr (ALIGNED) {
             const int k0 = k_begin + kt * BK;
             if (k0 + BK > k_end) {            // only the last k tile of a split can be ragged
-                if constexpr (A_KC) mask_kc<IT>(stA, k_end, k0); else mask_mc<IT>(stA, k_end, k0);
-                if constexpr (B_KC) mask_kc<IT>(stB, k_end, k0); else mask_mc<IT>(stB, k_end, k0);
+                if constexpr (A_KC) mask_kc<IT, BK>(stA, k_end, k0); else mask_mc<IT, T>(stA, k_end, k0);
+                if constexpr (B_KC) mask_kc<IT, BK>(stB, k_end, k0); else mask_mc<IT, T>(stB, k_end, k0);
             }
         }
-        if constexpr (A_KC) store_kc<IT>(sa, stA); else store_mc<IT>(sa, stA);
-        if constexpr (B_KC) store_kc<IT>(sb, stB); else store_mc<IT>(sb, stB);
+        if constexpr (A_KC) store_kc<IT, BK>(sa, stA); else store_mc<IT, T>(sa, stA);
+        if constexpr (B_KC) store_kc<IT, BK>(sb, stB); else store_mc<IT, T>(sb, stB);
     };
 
     if (n_kt > 0) {
@@ -301,13 +307,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);      // loads are issued; keep their consumers below
         const float *a_s = smem + cur * (TA + TB);
         const float *b_s = a_s + TA;
+        if (g.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < BK / 8; ++q) {
             float4 af[NT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T>(a_s, wm * W + i * 32, q, r, hh);
+            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T, BK>(a_s, wm * W + i * 32, q, r, hh);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T>(b_s, wn * W + j * 32, q, r, hh);
+            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T, BK>(b_s, wn * W + j * 32, q, r, hh);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             f4(af[i], s), f4(bf[j], s), acc[i][j], 0, 0, 0);
         }
+        if (g.setprio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);      // nothing of the store phase moves above the MFMAs
         if (more) sstore(cur ^ 1, kt + 1);
         __syncthreads();
@@ -366,7 +374,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int64_t slab,
 struct GemmCfg { int tile; int splits; };
 
 static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
-    const int64_t kt = ceil_div(k, BK);
+    const int64_t kt = ceil_div(k, 32);      // the model counts k in units of 32
     // developer override for tuning sweeps (scripts/gemm_sweep.py); not used in production
     static const char *env_tile = getenv("GIST_GEMM_TILE");
     static const char *env_split = getenv("GIST_GEMM_SPLITS");
@@ -400,8 +408,9 @@ static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
 
 template <bool A_KC, bool B_KC, int T>
 static int launch_tile(const char *name, GemmArgs &g, bool aligned, int splits, hipStream_t st) {
-    constexpr int TA = A_KC ? Img<T>::KC : Img<T>::MC;
-    constexpr int TB = B_KC ? Img<T>::KC : Img<T>::MC;
+    constexpr int BK = T == 128 ? 32 : 64;
+    constexpr int TA = A_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
+    constexpr int TB = B_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
     const size_t smem = (size_t)2 * (TA + TB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -443,13 +452,15 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
     const bool aligned = aligned16(a) && (lda % 4 == 0) && lda >= 4 && aligned16(b) &&
                          (ldb % 4 == 0) && ldb >= 4 && k > 0;
+    static const int env_prio = getenv("GIST_GEMM_SETPRIO") ? atoi(getenv("GIST_GEMM_SETPRIO")) : 1;
+    g.setprio = env_prio;
     GemmCfg cfg = choose_cfg(m, n, k);
     int splits = cfg.splits;
     if (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits = 1;
-    g.k_per_split = (int)(ceil_div(ceil_div(k, BK), splits) * BK);
+    g.k_per_split = (int)(ceil_div(ceil_div(k, 64), splits) * 64);   // multiple of either BK
     splits = (int)ceil_div(k, g.k_per_split > 0 ? g.k_per_split : 1);
     if (splits < 1) splits = 1;
-    if (k == 0) { g.k_per_split = BK; splits = 1; }
+    if (k == 0) { g.k_per_split = 64; splits = 1; }
     if (splits == 1) {
         g.split_stride = 0;
     } else {
