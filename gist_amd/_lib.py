@@ -69,6 +69,7 @@ SIGNATURES = {
 GIST_MAX_LAYERS = 16
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
+GIST_STEP_OVERLAP_ADAM = 4
 
 
 class LayerDesc(ctypes.Structure):

@@ -142,6 +142,22 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     if (!train) return GIST_OK;
 
     // ---- backward --------------------------------------------
+    // Adam is HBM-bound, the backward GEMMs are MFMA-bound: with GIST_STEP_OVERLAP_ADAM each
+    // layer's parameter slice [W_k | b_k] is updated on a side stream as soon as dW_k, db_k
+    // exist and W_k has been read for the last time (dZ = dY.W_k), concurrently with the
+    // rest of the backward; the step joins the side stream before it returns.
+    const bool overlap = (flags & GIST_STEP_OVERLAP_ADAM) != 0 && L1 > 1;
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_ready[GIST_MAX_LAYERS], ev_done = nullptr;
+    if (overlap && side == nullptr) {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) {
+            set_error("gist_sage_step: cannot create the Adam side stream");
+            return GIST_ELAUNCH;
+        }
+        for (int k = 0; k < GIST_MAX_LAYERS; ++k)
+            (void)hipEventCreateWithFlags(&ev_ready[k], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ev_done, hipEventDisableTiming);
+    }
     for (int k = L1 - 1; k >= 0; --k) {
         const gist_layer_desc &l = p->layer[k];
         const float *dy;
@@ -157,18 +173,27 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             dy = l.Y;
             lddy = l.ldy;
         }
+        if (k > 0) {      // dZ first: it is the last reader of W_k
+            Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
+            GIST_TRY(gist_gemm_nn_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n, 2 * l.n_in,
+                                      l.n_out, p->workspace, p->workspace_bytes, s));
+        }
         {
             Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
             GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in,
                                       n, p->workspace, p->workspace_bytes, s));
         }
         GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
+        if (overlap) {
+            const int64_t off = l.W - p->params;                 // [W_k | b_k] is contiguous
+            const int64_t cnt = l.n_out * 2 * l.n_in + l.n_out;
+            (void)hipEventRecord(ev_ready[k], st);
+            (void)hipStreamWaitEvent(side, ev_ready[k], 0);
+            GIST_TRY(gist_adam_f32(p->params + off, p->grads + off, p->exp_avg + off,
+                                   p->exp_avg_sq + off, cnt, lr, beta1, beta2, eps, weight_decay,
+                                   adam_step, (gist_stream_t)side));
+        }
         if (k > 0) {
-            {
-                Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
-                GIST_TRY(gist_gemm_nn_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
-                                          2 * l.n_in, l.n_out, p->workspace, p->workspace_bytes, s));
-            }
             if (drop)
                 GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
                                           offs[k], s));
@@ -178,6 +203,11 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                            2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
             }
         }
+    }
+    if (overlap) {
+        (void)hipEventRecord(ev_done, side);
+        (void)hipStreamWaitEvent(st, ev_done, 0);
+        return launch_status("gist_sage_step");
     }
     GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
                            beta2, eps, weight_decay, adam_step, s));

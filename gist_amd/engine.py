@@ -176,6 +176,9 @@ class SageEngine(object):
         self._drop_offsets = []
         self.plan = None
         self._plan_keep = None
+        # measured NEGATIVE on MI355X (H=4096: 4.47 -> 4.60 ms/step, h=512: 0.47 -> 0.57): the
+        # concurrent Adam traffic slows the L2-bound SpMM and the stream joins add latency
+        self.overlap_adam = False
 
     # ------------------------------------------------------------------
     def attach_batcher(self, batcher):
@@ -260,6 +263,8 @@ class SageEngine(object):
         from . import _lib
         L = _lib.load()
         flags = (_lib.GIST_STEP_TRAIN if train else 0) | (0 if b.ready else _lib.GIST_STEP_EXTRACT)
+        if self.overlap_adam:
+            flags |= _lib.GIST_STEP_OVERLAP_ADAM
         off = self.drop_calls
         if train and self.p_drop > 0.0:
             for (i, o) in self.dims:

@@ -302,6 +302,9 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
 
 #define GIST_STEP_EXTRACT 1   /* build the batch from ids (else: batch buffers already valid) */
 #define GIST_STEP_TRAIN 2     /* dropout on, backward + Adam (else: forward + loss only)      */
+#define GIST_STEP_OVERLAP_ADAM 4 /* per-layer Adam on a side stream under the backward GEMMs;
+                                    same result (each slice is updated exactly once, after
+                                    its last reader), joined before the call's work ends     */
 
 /* One iteration of the reference's training loop on the batch whose node ids (in the
  * training graph) are ids[0..n): induced subgraph + feature/label gather
