@@ -257,13 +257,24 @@ __global__ __launch_bounds__(256) void block_move_kernel(const float *__restrict
     }
 }
 
+// Pairwise (tree) summation over the sources: for identical copies and a power-of-two
+// count every partial sum is exact, so "dispatch -> sync without training" leaves the shared
+// bias bit-identical (a sequential sum rounds at 3x).  Deterministic for any count.
 __global__ void mean_rows_kernel(const float *__restrict__ src, int64_t stride, int n_src, int64_t n,
                                  float *__restrict__ out) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < n_src; ++k) s += src[(int64_t)k * stride + j];
-    out[j] = s / (float)n_src;
+    constexpr int kMax = 64;
+    float v[kMax];
+    float tail = 0.f;
+    const int m = n_src < kMax ? n_src : kMax;
+    for (int k = 0; k < kMax; ++k) v[k] = k < m ? src[(int64_t)k * stride + j] : 0.f;
+    for (int k = kMax; k < n_src; ++k) tail += src[(int64_t)k * stride + j];
+#pragma unroll
+    for (int w = 1; w < kMax; w <<= 1)
+#pragma unroll
+        for (int k = 0; k + w < kMax; k += 2 * w) v[k] += v[k + w];
+    out[j] = (v[0] + tail) / (float)n_src;
 }
 
 }  // namespace gist

@@ -220,3 +220,95 @@ def test_native_step_equals_op_by_op():
         results.append((eng.arena.params.clone(), torch.stack(losses)))
     assert torch.equal(results[0][0], results[1][0])
     assert torch.equal(results[0][1], results[1][1])
+
+
+def test_ist_wide_block_algebra_properties():
+    """Ultra-wide-style IST (cluster_gcn_ist_ultra_wide.py path, base model resident in HBM)
+    at H=8192, S=8: (1) every rank's sub-model blocks are disjoint and tile the 'diagonal',
+    (2) dispatch -> sync with no training leaves the base model BIT-identical, (3) after a
+    perturbation only the S diagonal blocks (next_s x full_prev_s) change -- the S^2-S
+    off-diagonal blocks keep their old values, (4) the shared
+    last bias becomes the mean of the S copies."""
+    from gist_amd import ist
+    S, H, L, F, C = 8, 8192, 2, 602, 41
+    random.seed(5)
+    group = ist.LocalCommGroup(S)
+    models = []
+    gen = torch.Generator().manual_seed(0)
+    base_init = None
+    for r in range(S):
+        args = argparse.Namespace(num_subnet=S, n_hidden=H, n_layers=L, rank=r, dropout=0.0,
+                                  use_layernorm=True)
+        if r == 0:
+            from gist_amd.engine import dims_for
+            base_init = [(torch.rand(o, 2 * i, generator=gen), torch.rand(o, generator=gen))
+                         for (i, o) in dims_for(F, H, C, L)]
+        models.append(ist.DistributedGNNWrapper(args, None, F, C, DEV,
+                                                base_init=base_init if r == 0 else None,
+                                                comm=group.handle(r)))
+    part = models[0].sample_partitions()
+    for m in models:
+        m.ini_sync_dispatch_model(part)
+    base0 = models[0].base.params.clone()
+    for m in models[1:]:
+        assert torch.equal(m.base.params, base0)           # replicas
+    # (1) index sets are a partition of [0, H)
+    for l in range(L):
+        allidx = torch.cat([part[l][s][0] for s in range(S)])
+        assert torch.equal(torch.sort(allidx).values, torch.arange(H))
+    # (2) identity
+    for m in models:
+        m.sync_gather()
+    for m in models:
+        m.sync_apply()
+    assert torch.equal(models[0].base.params, base0)
+    # (3) perturb every sub-model, sync, compare block structure on W1 [H, 2H]
+    for r, m in enumerate(models):
+        m.sub.params.add_(1.0 + r)
+    for m in models:
+        m.sync_gather()
+    for m in models:
+        m.sync_apply()
+    W1_old = base0[models[0].base.offsets[1][0]:models[0].base.offsets[1][1]].view(H, 2 * H)
+    W1_new = models[0].base.W[1]
+    changed = (W1_new != W1_old)
+    expect = torch.zeros(H, 2 * H, dtype=torch.bool, device=DEV)
+    for s in range(S):
+        rows = part[1][s][0].to(DEV)
+        cols = part[0][s][1].to(DEV)
+        expect[rows[:, None], cols[None, :]] = True
+        blk = W1_new[rows[:, None], cols[None, :]] - W1_old[rows[:, None], cols[None, :]]
+        assert torch.allclose(blk, torch.full_like(blk, 1.0 + s))
+    assert torch.equal(changed, expect)
+    assert int(expect.sum().item()) == S * (H // S) * (2 * H // S)
+    # (4) shared bias = mean over sites of (old + 1 + s)
+    bL_old = base0[models[0].base.offsets[L][1]:models[0].base.offsets[L][1] + C]
+    assert torch.allclose(models[0].base.b[L], bL_old + 1.0 + (S - 1) / 2.0, atol=1e-5)
+    for m in models:
+        assert torch.equal(m.sub.b[L], models[0].base.b[L])
+
+
+def test_drop_in_evaluate_matches_engine_evaluator():
+    """gist_amd.utils.evaluate(model, g, labels, mask) (cluster_gcn/utils.py:70-80 signature)
+    on the nn.Module path == FullGraphEvaluator on the engine path, same parameters."""
+    import torch.nn.functional as F
+    from gist_amd import datasets
+    from gist_amd.modules import GCN
+    from gist_amd.trainer import FullGraphEvaluator
+    from gist_amd.utils import evaluate
+    from gist_amd.engine import ParamArena, dims_for
+    ds = datasets.toy(seed=3)
+    g = ds.g
+    torch.manual_seed(1)
+    model = GCN(g.ndata['feat'].shape[1], 48, ds.num_classes, 2, F.relu, 0.3, True, False, False,
+                1, True).to(DEV)
+    gd = g.to(DEV)
+    dims = dims_for(g.ndata['feat'].shape[1], 48, ds.num_classes, 2)
+    arena = ParamArena(dims, DEV, with_grads=False)
+    arena.adopt_module(model)
+    ev = FullGraphEvaluator(g, dims, True, arena, DEV)
+    for mask in ('val_mask', 'test_mask', 'train_mask'):
+        a = evaluate(model, gd, gd.ndata['label'], gd.ndata[mask], 'f1')
+        b = ev.accuracy(mask)
+        assert abs(a - b) < 1e-9, (mask, a, b)
+    assert not model.training                           # evaluate() put the model in eval mode
