@@ -290,7 +290,7 @@ def main():
                 except Exception:
                     traffic = None
             out['roofline_spmm'] = {
-                'kernel': 'gist::spmm_csr_kernel', 'bound': 'hbm', 'achieved': round(s_ach, 2),
+                'kernel': 'gist::spmm_csr_rowsplit_kernel', 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
                 'traffic': traffic, 'launches': len(sp),
                 'avg_launch_ms': round(s_ms / max(len(sp), 1), 5),
