@@ -259,136 +259,232 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// LDS-staged variant for cluster batches.  Rows come in LOCALITY BLOCKS (a METIS part of a
-// Cluster-GCN batch: ~100 consecutive rows whose neighbours are ~97% inside the same part).
-// One 1024-thread workgroup (16 waves) owns (row block, column tile).  It stages, with
-// coalesced loads, everything the block needs into LDS ONCE:
-//   * the block's X tile [<=128 rows x 64*VEC floats]  (every element of X leaves L2/HBM once)
-//   * its row pointers and its column indices (one contiguous CSR range, up to 8192 ids)
-//   * the source scales of its rows (backward form)
-// Each wave then walks rows wave, wave+16, ...: row extent and neighbour ids come from LDS
-// (no dependent global-load chain), a neighbour inside the block is an LDS row read -- the
-// id is a scalar, so "all 8 of this group are local" is ONE wave-uniform branch followed
-// by 8 independent LDS reads -- and only cross-block neighbours fall back to the global
-// gather.  nnz*D*4 bytes of L2 gather traffic become LDS traffic.
-constexpr int kSpmmRB = 128;        // rows staged per block
-constexpr int kSpmmColCap = 8192;   // column ids staged per block
-constexpr int kSpmmBlockedThreads = 1024;
+// LDS-staged kernel for cluster batches.  Rows come in LOCALITY BLOCKS (a METIS part of a
+// Cluster-GCN batch: ~100 consecutive rows whose neighbours are mostly in the same part).
+// A 512-thread workgroup (8 waves) owns (row block, row split, column tile) and stages, with
+// coalesced loads, into LDS:
+//   * the block's X tile [<=128 rows x 64*VEC floats], PRE-SCALED by src_scale (backward
+//     form), plus one all-zero row;
+//   * for the rows it computes: a 1-BYTE local row index per neighbour (zero row for a
+//     cross-block neighbour or padding), and up to 8 (global id, scale) pairs of its
+//     cross-block neighbours per row.
+// Per neighbour the inner loop is then v_readlane + shift + v_add + ds_read_b128 + adds --
+// no scale, no branch, no global memory; the few cross-block rows are prefetched from
+// global memory BEFORE the LDS pass and consumed after it.  Every element of X leaves
+// L2/HBM once per workgroup; nnz*D*4 bytes of L2 gather traffic become LDS reads.
+// Rows whose lists do not fit (hubs) take a per-row generic path; results never depend on
+// how rows are split into blocks.
+constexpr int kLdsRB = 128;          // rows staged per block
+constexpr int kLdsListCap = 8192;    // neighbour entries (1 byte each) per workgroup
+constexpr int kLdsRemCap = 8;        // cross-block neighbours kept per row
+constexpr int kLdsThreads = 512;
 
 template <int VEC>
-__global__ __launch_bounds__(1024) void spmm_csr_blocked_kernel(
+struct LdsLayout {
+    static constexpr int CW = kWave * VEC;
+    static constexpr size_t tile_bytes = (size_t)(kLdsRB + 1) * CW * 4;
+    static constexpr size_t idx_off = tile_bytes;
+    static constexpr size_t rp_off = idx_off + kLdsListCap;
+    static constexpr size_t rid_off = rp_off + (kLdsRB + 4) * 4;
+    static constexpr size_t rsc_off = rid_off + (size_t)kLdsRB * kLdsRemCap * 4;
+    static constexpr size_t rcn_off = rsc_off + (size_t)kLdsRB * kLdsRemCap * 4;
+    static constexpr size_t total = rcn_off + kLdsRB * 4;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(512) void spmm_csr_lds_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int n_rows, int d, const float *__restrict__ out_scale,
     const float *__restrict__ src_scale, int accumulate,
-    const int32_t *__restrict__ row_blocks, int n_col_tiles) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int CW = kWave * VEC;                 // floats per row of the tile
-    constexpr int NW = kSpmmBlockedThreads / kWave;
-    float *tile = smem_f;                                        // [kSpmmRB][CW]
-    int32_t *cols = reinterpret_cast<int32_t *>(tile + kSpmmRB * CW);   // [kSpmmColCap]
-    int32_t *rp = cols + kSpmmColCap;                            // [kSpmmRB + 1]
-    float *scl = reinterpret_cast<float *>(rp + kSpmmRB + 4);    // [kSpmmRB]
+    const int32_t *__restrict__ row_blocks, int n_col_tiles, int row_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    using LL = LdsLayout<VEC>;
+    constexpr int CW = LL::CW;
+    constexpr int NW = kLdsThreads / kWave;
+    constexpr int SH = VEC == 4 ? 10 : (VEC == 2 ? 9 : 8);        // log2(CW * 4)
+    float *tile = reinterpret_cast<float *>(smem_b);
+    unsigned char *idx8 = smem_b + LL::idx_off;
+    int32_t *rp = reinterpret_cast<int32_t *>(smem_b + LL::rp_off);
+    int32_t *rid = reinterpret_cast<int32_t *>(smem_b + LL::rid_off);
+    float *rsc = reinterpret_cast<float *>(smem_b + LL::rsc_off);
+    int32_t *rcn = reinterpret_cast<int32_t *>(smem_b + LL::rcn_off);
 
     const int ct = blockIdx.x % n_col_tiles;
-    const int rbk = blockIdx.x / n_col_tiles;
+    const int rest = blockIdx.x / n_col_tiles;
+    const int half = rest % row_split;
+    const int rbk = rest / row_split;
     int r0, r1;
     if (row_blocks) { r0 = row_blocks[rbk]; r1 = row_blocks[rbk + 1]; }
-    else { r0 = rbk * kSpmmRB; r1 = min(n_rows, r0 + kSpmmRB); }
+    else { r0 = rbk * kLdsRB; r1 = min(n_rows, r0 + kLdsRB); }
     r1 = min(r1, n_rows);
-    const int nloc = min(r1 - r0, kSpmmRB);
-    if (nloc <= 0) return;
+    const int nrow = r1 - r0;
+    if (nrow <= 0) return;
+    const int nloc = min(nrow, kLdsRB);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = ct * CW + lane * VEC;
     const bool active = c0 < d;
 
-    // ---- stage ------------------------------------------------------------------------
-    const int cbeg = rowptr[r0];
-    const int ncol = min(rowptr[r0 + nloc] - cbeg, kSpmmColCap);
-    for (int i = threadIdx.x; i <= nloc; i += kSpmmBlockedThreads) rp[i] = rowptr[r0 + i];
-    for (int i = threadIdx.x; i < ncol; i += kSpmmBlockedThreads) cols[i] = col[cbeg + i];
-    if (src_scale)
-        for (int i = threadIdx.x; i < nloc; i += kSpmmBlockedThreads) scl[i] = src_scale[r0 + i];
-    for (int rr = wave; rr < nloc; rr += NW) {
-        float v[VEC];
+    // ---- stage 1: row pointers, X tile (pre-scaled), zero row ----------------------------
+    for (int i = threadIdx.x; i <= nloc; i += kLdsThreads) rp[i] = rowptr[r0 + i];
+    {
+        float z[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) v[k] = 0.f;
-        if (active) vload<VEC>(x + (int64_t)(r0 + rr) * ldx + c0, v);
-        vstore<VEC>(tile + rr * CW + lane * VEC, v);
+        for (int k = 0; k < VEC; ++k) z[k] = 0.f;
+        if (wave == 0) vstore<VEC>(tile + kLdsRB * CW + lane * VEC, z);
+    }
+    for (int rr = wave; rr < nloc; rr += 8 * NW) {       // eight row loads in flight per wave
+        float v[8][VEC];
+        float sc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = rr + t * NW;
+            const int rc = min(r, nloc - 1);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[t][k] = 0.f;
+            if (active) vload<VEC>(x + (int64_t)(r0 + rc) * ldx + c0, v[t]);
+            sc[t] = src_scale ? src_scale[r0 + rc] : 1.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = rr + t * NW;
+            if (r < nloc) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[t][k] *= sc[t];
+                vstore<VEC>(tile + r * CW + lane * VEC, v[t]);
+            }
+        }
     }
     __syncthreads();
 
+    // ---- stage 2: classify the neighbours of the rows THIS workgroup computes ----------------
+    const int cbeg = rp[0];
+    for (int lr = half + row_split * wave; lr < nloc; lr += row_split * NW) {
+        const int beg = rp[lr], end = rp[lr + 1];
+        int nrem = 0;
+        const bool fits = (end - cbeg) <= kLdsListCap;
+        for (int base = beg; base < end && fits; base += kWave) {
+            const int e = base + lane;
+            const bool in = e < end;
+            const int u = in ? col[e] : r0;
+            const unsigned lu = (unsigned)(u - r0);
+            const bool local = lu < (unsigned)nloc;
+            if (in) idx8[e - cbeg] = (unsigned char)(local ? lu : kLdsRB);
+            const unsigned long long m = __ballot(in && !local);
+            if (in && !local) {
+                const int pos = nrem + __popcll(m & ((1ULL << lane) - 1ULL));
+                if (pos < kLdsRemCap) {
+                    rid[lr * kLdsRemCap + pos] = u;
+                    rsc[lr * kLdsRemCap + pos] = src_scale ? src_scale[u] : 1.f;
+                }
+            }
+            nrem += __popcll(m);
+        }
+        if (lane == 0) rcn[lr] = fits ? nrem : -1;       // -1 / > cap: generic path for the row
+    }
+    __syncthreads();
+
+    // ---- compute -----------------------------------------------------------------------------
     const float *xc = x + c0;
-    const float *tl = tile + lane * VEC;
-    for (int row = r0 + wave; row < r1; row += NW) {
-        const int lr = row - r0;
-        int beg, end;
-        if (lr < nloc) { beg = rp[lr]; end = rp[lr + 1]; }
-        else { beg = rowptr[row]; end = rowptr[row + 1]; }       // oversize block tail
-        beg = __builtin_amdgcn_readfirstlane(beg);
-        end = __builtin_amdgcn_readfirstlane(end);
+    const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile) + lane * VEC * 4;
+    for (int lr = half + row_split * wave; lr < nrow; lr += row_split * NW) {
+        const int row = r0 + lr;
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        for (int base = beg; base < end; base += kWave) {
-            const int e = base + lane;
-            int my = 0;
-            if (e < end) {
-                const int ci = e - cbeg;
-                my = (ci < ncol) ? cols[ci] : col[e];
+        const int nrem = lr < nloc ? rcn[lr] : -1;
+        if (nrem >= 0 && nrem <= kLdsRemCap) {
+            const int beg = __builtin_amdgcn_readfirstlane(rp[lr]);
+            const int end = __builtin_amdgcn_readfirstlane(rp[lr + 1]);
+            // cross-block rows first: their global loads fly under the LDS pass
+            float rv[kLdsRemCap][VEC];
+            float rs[kLdsRemCap];
+            const int rc = __builtin_amdgcn_readfirstlane(nrem);
+            const int my_id = lane < kLdsRemCap ? rid[lr * kLdsRemCap + lane] : row;
+            const float my_sc = lane < kLdsRemCap ? rsc[lr * kLdsRemCap + lane] : 0.f;
+            if (rc > 0) {
+#pragma unroll
+                for (int t = 0; t < kLdsRemCap; ++t) {
+                    const bool on = t < rc;                                  // wave-uniform
+                    const int u = on ? __builtin_amdgcn_readlane(my_id, t) : row;
+                    rs[t] = on ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                               __builtin_bit_cast(int, my_sc), t))
+                               : 0.f;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) rv[t][k] = 0.f;
+                    if (on && active) vload<VEC>(xc + (int64_t)u * ldx, rv[t]);
+                }
             }
-            float mys = 1.f;
-            if (src_scale) {
-                const unsigned ml = (unsigned)(my - r0);
-                mys = (e < end) ? (ml < (unsigned)nloc ? scl[ml] : src_scale[my]) : 0.f;
-            }
-            const int cnt = min(kWave, end - base);
-            const bool is_remote = (e < end) && ((unsigned)(my - r0) >= (unsigned)nloc);
-            unsigned long long rem = __ballot(is_remote);
-            // ---- pass A: every neighbour of the chunk out of LDS, branch free.  A remote
-            // neighbour reads row 0 of the tile with scale 0 (3% wasted reads) so that the
-            // eight reads of a group are independent and pipeline.
-            for (int j = 0; j < cnt; j += 8) {
-                float v[8][VEC];
-                float sc[8];
+            for (int base = beg; base < end; base += kWave) {
+                const int e = base + lane;
+                const int mine = (e < end) ? (int)idx8[e - cbeg] : kLdsRB;   // pad -> zero row
+                const int cnt = min(kWave, end - base);
+                // groups of 8 LDS row reads, software pipelined: group g+1 is issued before
+                // group g is summed, so the LDS pipe always has work queued
+                float va[8][VEC], vb[8][VEC];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int jj = min(j + t, cnt - 1);
-                    const int u = __builtin_amdgcn_readlane(my, jj);
-                    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                                                    __builtin_bit_cast(int, mys), jj));
-                    const unsigned lu = (unsigned)(u - r0);
-                    const bool ok = (j + t < cnt) && (lu < (unsigned)nloc);
-                    sc[t] = ok ? s0 : 0.f;
-                    vload<VEC>(tl + (ok ? lu : 0u) * CW, v[t]);
+                    const int li = __builtin_amdgcn_readlane(mine, t);
+                    vload<VEC>(reinterpret_cast<const float *>(tb + ((unsigned)li << SH)), va[t]);
                 }
+                for (int j = 0; j < cnt; j += 16) {
+                    if (j + 8 < cnt) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+                        for (int t = 0; t < 8; ++t) {
+                            const int li = __builtin_amdgcn_readlane(mine, (j + 8 + t) & 63);
+                            vload<VEC>(reinterpret_cast<const float *>(tb + ((unsigned)li << SH)), vb[t]);
+                        }
+                    }
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(sc[t], v[t][k], acc[k]);
-            }
-            // ---- pass B: the few cross-block neighbours, four global row reads in flight
-            while (rem) {
-                int u[4];
-                float sc[4];
+                    for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (rem) {
-                        const int jj = __builtin_ctzll(rem);
-                        rem &= rem - 1;
-                        u[t] = __builtin_amdgcn_readlane(my, jj);
-                        sc[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                                               __builtin_bit_cast(int, mys), jj));
-                    } else {
-                        u[t] = row;          // any readable row; contributes 0
-                        sc[t] = 0.f;
+                        for (int k = 0; k < VEC; ++k) acc[k] += va[t][k];
+                    if (j + 8 < cnt) {
+                        if (j + 16 < cnt) {
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) {
+                                const int li = __builtin_amdgcn_readlane(mine, (j + 16 + t) & 63);
+                                vload<VEC>(reinterpret_cast<const float *>(tb + ((unsigned)li << SH)), va[t]);
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[k] += vb[t][k];
                     }
                 }
-                if (active) {
-                    float v[4][VEC];
+            }
+            if (rc > 0) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) vload<VEC>(xc + (int64_t)u[t] * ldx, v[t]);
+                for (int t = 0; t < kLdsRemCap; ++t)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(rs[t], rv[t][k], acc[k]);
+            }
+        } else {
+            // generic path: hub rows / oversize blocks -- gather everything from global memory
+            const int beg = __builtin_amdgcn_readfirstlane(rowptr[row]);
+            const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+            for (int base = beg; base < end; base += kWave) {
+                const int e = base + lane;
+                const int my = (e < end) ? col[e] : 0;
+                float mys = 1.f;
+                if (src_scale) mys = (e < end) ? src_scale[my] : 0.f;
+                const int cnt = min(kWave, end - base);
+                for (int j = 0; j < cnt; j += 4) {
+                    float v[4][VEC];
+                    float sc[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int jj = min(j + t, cnt - 1);
+                        const int u = __builtin_amdgcn_readlane(my, jj);
+                        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                                        __builtin_bit_cast(int, mys), jj));
+                        sc[t] = (j + t < cnt) ? s0 : 0.f;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) v[t][k] = 0.f;
+                        if (active) vload<VEC>(xc + (int64_t)u * ldx, v[t]);
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -471,15 +567,18 @@ static int launch_spmm_blocked(const int32_t *rowptr, const int32_t *col, const 
                                const float *out_scale, const float *src_scale, int accumulate,
                                const int32_t *row_blocks, int64_t n_row_blocks, hipStream_t st) {
     const int n_col_tiles = (int)ceil_div(d, kWave * VEC);
-    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, kSpmmRB);
-    const int64_t grid = nb * n_col_tiles;
+    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, kLdsRB);
+    // split a block's rows over several workgroups (each stages the whole tile) until the
+    // grid can keep 256 CUs busy for a couple of rounds
+    int row_split = (int)ceil_div(640, nb * n_col_tiles);
+    row_split = row_split < 1 ? 1 : (row_split > 4 ? 4 : row_split);
+    const int64_t grid = nb * row_split * n_col_tiles;
     if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
-    const size_t smem = (size_t)kSpmmRB * kWave * VEC * sizeof(float) +
-                        (size_t)(kSpmmColCap + kSpmmRB + 4 + kSpmmRB) * 4;
+    const size_t smem = LdsLayout<VEC>::total;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&spmm_csr_blocked_kernel<VEC>),
+            reinterpret_cast<const void *>(&spmm_csr_lds_kernel<VEC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -487,10 +586,9 @@ static int launch_spmm_blocked(const int32_t *rowptr, const int32_t *col, const 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((spmm_csr_blocked_kernel<VEC>), dim3((unsigned)grid),
-                       dim3(kSpmmBlockedThreads), smem, st,
+    hipLaunchKernelGGL((spmm_csr_lds_kernel<VEC>), dim3((unsigned)grid), dim3(kLdsThreads), smem, st,
                        rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale, src_scale,
-                       accumulate, row_blocks, n_col_tiles);
+                       accumulate, row_blocks, n_col_tiles, row_split);
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 
@@ -546,10 +644,12 @@ extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *c
         return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                                  accumulate, stream);
     hipStream_t st = as_stream(stream);
-    const bool a8 = d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y);
-    if (a8)   // 8 B per lane: 64 KiB of LDS per workgroup -> two workgroups per CU
+    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
+        return launch_spmm_blocked<4>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale,
+                                      src_scale, accumulate, row_blocks, n_row_blocks, st);
+    if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y))
         return launch_spmm_blocked<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale,
                                       src_scale, accumulate, row_blocks, n_row_blocks, st);
-    return launch_spmm_blocked<1>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
-                                  accumulate, row_blocks, n_row_blocks, st);
+    return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                             accumulate, stream);
 }
