@@ -172,7 +172,7 @@ def main():
     it.bind(engine)
     lr = 0.01
 
-    nnz_log = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int32, device=dev)
+    timed_ids = []          # id slices of the timed batches (replayed AFTER timing for nnz stats)
     n_log = []
     state = dict(total_iter=0, epoch=0)
 
@@ -193,8 +193,8 @@ def main():
                     ist_model.dispatch_model()
                 ist_model.sub.reset_optimizer()              # fresh Adam (:405-407)
             engine.train_step(b, lr, 0.0)
-            if log_from is not None:
-                nnz_log[log_from + s:log_from + s + 1].copy_(b.rowptr[b.n:b.n + 1])
+            if log_from is not None:        # bookkeeping only: no device work in the timed region
+                timed_ids.append(b.ids)
                 n_log.append(b.n)
             state['total_iter'] = ti + 1
             if ist_model is not None and state['total_iter'] % args.iter_per_site == 0:
@@ -261,7 +261,11 @@ def main():
             'host_path': 'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',
         }
         if prof is not None:
-            nnz = nnz_log[:args.steps].cpu().numpy().astype(np.int64)
+            # in-batch edge counts of the timed batches: re-extract them now, outside the timing
+            nnz = np.zeros(args.steps, np.int64)
+            for i, ids in enumerate(timed_ids):
+                bb = it.batcher.extract(ids, engine.z0_left(ids.numel()))
+                nnz[i] = int(bb.rowptr[bb.n].item())
             gem = prof['gemm']
             g_ms = sum(ms for ms, _ in gem)
             g_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in gem)

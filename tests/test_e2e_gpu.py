@@ -182,7 +182,8 @@ def test_full_size_step_properties():
     assert torch.isfinite(eng.arena.params).all()
 
 
-def test_native_step_equals_op_by_op():
+@pytest.mark.parametrize('n_layers,use_ln,p_drop', [(3, True, 0.2), (1, False, 0.2), (2, True, 0.0)])
+def test_native_step_equals_op_by_op(n_layers, use_ln, p_drop):
     """gist_sage_step (one C-ABI call per iteration) issues the same kernels in the same
     order as the Python op-by-op path: parameters after 4 steps with dropout 0.2 must be
     BITWISE identical, and the native HIP-event timer must see 5*(L+1)-2 launches/step."""
@@ -192,13 +193,13 @@ def test_native_step_equals_op_by_op():
     ds = datasets.toy(seed=9, n=3000, n_blocks=30, n_feats=50, n_classes=6, train_frac=1.0)
     g = ds.g
     nid = np.arange(g.number_of_nodes(), dtype=np.int64)
-    dims = dims_for(50, 96, 6, 3)
+    dims = dims_for(50, 96, 6, n_layers)
     results = []
     for native in (True, False):
         random.seed(4)
         it = EngineClusterIter('toy', g, len(ds.par_li), 5, nid, par_li=[p.copy() for p in ds.par_li],
                                device=DEV)
-        eng = SageEngine(dims, True, 0.2, it.n_max, DEV, seed=11)
+        eng = SageEngine(dims, use_ln, p_drop, it.n_max, DEV, seed=11)
         gen = torch.Generator().manual_seed(1)
         for k, (i, o) in enumerate(dims):
             eng.arena.W[k].copy_((torch.rand(o, 2 * i, generator=gen) - 0.5) * 0.3)
