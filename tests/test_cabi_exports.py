@@ -60,3 +60,21 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libgist_hip.so')
     with pytest.raises(_lib.GistLibraryError, match='no CPU fallback'):
         _lib.load()
+
+
+def test_plain_c_consumer_compiles_links_and_runs(tmp_path):
+    """include/gist_hip.h is valid C99 and libgist_hip.so links from a C program (no Python,
+    no torch): the boundary really is a C ABI."""
+    import subprocess
+    from gist_amd import _lib
+    src = os.path.join(ROOT, 'tests', 'cabi_consumer.c')
+    exe = str(tmp_path / 'cabi_consumer')
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), src,
+           '-o', exe, '-L', libdir, '-l:libgist_hip.so', '-Wl,-rpath,' + libdir,
+           '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    assert 'cabi consumer ok' in r.stdout
