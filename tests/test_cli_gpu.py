@@ -63,3 +63,66 @@ def test_ist_cli_world1_and_rccl_collectives():
         assert torch.equal(out, inp)
     finally:
         dist.destroy_process_group()
+
+
+def test_zero_edit_drop_in_script_matches_engine_path():
+    """INTEGRATION.md route A: a script shaped like cluster_gcn/cluster_gcn.py main() --
+    `import dgl` resolving to gist_amd.dgl_compat, ClusterIter yielding graph objects,
+    `model(cluster)`, `loss.backward()`, `optimizer.step()`, `evaluate(...)` -- trains to the
+    same parameters as the SageEngine fast path on the same data (dropout 0, same seeds)."""
+    import random
+    import torch.nn.functional as F
+    import gist_amd.dgl_compat as dgl_compat
+    dgl_compat.install()
+    import dgl                                             # noqa: F401  (the alias)
+    import dgl.function as fn                              # noqa: F401
+    assert dgl is dgl_compat and fn.copy_src is dgl_compat.function.copy_src
+    from gist_amd import datasets
+    from gist_amd.modules import GCN
+    from gist_amd.nn import CrossEntropyLoss
+    from gist_amd.optim import Adam
+    from gist_amd.sampler import ClusterIter
+    from gist_amd.trainer import ClusterGCNTrainer
+    from gist_amd.utils import evaluate
+
+    dev = torch.device('cuda', 0)
+    data = datasets.toy(seed=7)
+    g = data.g
+    train_nid = np.nonzero(g.ndata['train_mask'].numpy())[0].astype(np.int64)
+    in_feats, n_classes = g.ndata['feat'].shape[1], data.num_classes
+    psize, bs, hidden, L, lr = len(data.par_li), 4, 32, 2, 0.01
+
+    # ---- reference-shaped script (module path) -------------------------------------------
+    torch.manual_seed(5)
+    random.seed(5)
+    cluster_iterator = ClusterIter('toy', g, psize, bs, train_nid, use_pp=False,
+                                   par_li=[p.copy() for p in data.par_li], device=dev)
+    model = GCN(in_feats, hidden, n_classes, L, F.relu, 0.0, True, False, False, 1, True)
+    init = [(l.linear.weight.detach().clone(), l.linear.bias.detach().clone()) for l in model.layers]
+    model.cuda()
+    loss_f = CrossEntropyLoss()
+    optimizer = Adam(model.parameters(), lr=lr, weight_decay=0)
+    g_dev = g.to(dev)
+    for epoch in range(2):
+        for j, cluster in enumerate(cluster_iterator):
+            model.train()
+            pred = model(cluster)
+            batch_labels = cluster.ndata['label']
+            batch_train_mask = cluster.ndata['train_mask']
+            loss = loss_f(pred[batch_train_mask], batch_labels[batch_train_mask])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+    acc_script = evaluate(model, g_dev, g_dev.ndata['label'], g_dev.ndata['val_mask'])
+    assert torch.isfinite(loss) and 0.0 <= acc_script <= 1.0
+
+    # ---- engine path, same seeds / data / init -----------------------------------------------
+    random.seed(5)
+    tr = ClusterGCNTrainer('toy', g, [p.copy() for p in data.par_li], psize, bs, hidden, L,
+                           n_classes, 0.0, True, lr, 0.0, dev, init_params=init)
+    for epoch in range(2):
+        tr.train_epoch()
+    for layer, (W, b) in zip(model.layers, tr.engine.arena.export()):
+        assert np.abs(layer.linear.weight.detach().cpu().numpy() - W).max() < 1e-4
+        assert np.abs(layer.linear.bias.detach().cpu().numpy() - b).max() < 1e-4
+    assert abs(tr.evaluate('val_mask') - acc_script) < 1e-9
