@@ -155,11 +155,9 @@ class Graph(object):
         dev = self.device
         if torch.is_tensor(nids):
             ids = nids.to(device=dev, dtype=torch.int32).contiguous()
-            full_deg_sum = None
         else:
             nids = np.asarray(nids).reshape(-1)
             ids = torch.from_numpy(nids.astype(np.int32)).to(dev)
-            full_deg_sum = None
         nb = ids.numel()
         if self._remap is None:
             self._remap = torch.empty(self._n, dtype=torch.int32, device=dev)

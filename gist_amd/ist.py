@@ -28,7 +28,6 @@ What is re-designed for one MI355X node (8 GPUs, xGMI full mesh, 288 GB each):
 import random as _pyrandom
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -22,7 +22,6 @@ import numpy as np
 import torch
 
 from . import hip
-from .graph import Graph
 
 
 def load_partition_cache(path):
