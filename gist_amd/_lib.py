@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GistLibraryError(RuntimeError):
@@ -70,6 +70,7 @@ GIST_MAX_LAYERS = 16
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 GIST_STEP_OVERLAP_ADAM = 4
+GIST_STEP_OVERLAP_DW = 8
 
 
 class LayerDesc(ctypes.Structure):
@@ -84,6 +85,7 @@ class StepPlan(ctypes.Structure):
                 ('layer', LayerDesc * GIST_MAX_LAYERS),
                 ('dlogits', _p), ('ldc', _i64), ('dZ', _p), ('partials', _p),
                 ('row_loss', _p), ('loss', _p), ('workspace', _p), ('workspace_bytes', _i64),
+                ('workspace2', _p), ('workspace2_bytes', _i64),
                 ('params', _p), ('grads', _p), ('exp_avg', _p), ('exp_avg_sq', _p),
                 ('n_params', _i64),
                 ('g_rowptr', _p), ('g_col', _p), ('g_t_rowptr', _p), ('g_t_col', _p),

@@ -147,9 +147,10 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     // exist and W_k has been read for the last time (dZ = dY.W_k), concurrently with the
     // rest of the backward; the step joins the side stream before it returns.
     const bool overlap = (flags & GIST_STEP_OVERLAP_ADAM) != 0 && L1 > 1;
+    const bool overlap_dw = (flags & GIST_STEP_OVERLAP_DW) != 0 && !overlap && p->workspace2 != nullptr;
     static hipStream_t side = nullptr;
     static hipEvent_t ev_ready[GIST_MAX_LAYERS], ev_done = nullptr;
-    if (overlap && side == nullptr) {
+    if ((overlap || overlap_dw) && side == nullptr) {
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) {
             set_error("gist_sage_step: cannot create the Adam side stream");
             return GIST_ELAUNCH;
@@ -173,17 +174,32 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             dy = l.Y;
             lddy = l.ldy;
         }
-        if (k > 0) {      // dZ first: it is the last reader of W_k
+        if (overlap_dw) {
+            // dY_k is complete on the main stream: fork dW_k / db_k to the side stream, where
+            // all weight-gradient work is serialised (one split-K scratch, one colsum scratch).
+            (void)hipEventRecord(ev_ready[k], st);
+            (void)hipStreamWaitEvent(side, ev_ready[k], 0);
+            {
+                Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, side);
+                GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
+                                          2 * l.n_in, n, p->workspace2, p->workspace2_bytes,
+                                          (gist_stream_t)side));
+            }
+            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, (gist_stream_t)side));
+        }
+        if (k > 0) {      // dZ (before dW on the main stream: it is the last reader of W_k)
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
             GIST_TRY(gist_gemm_nn_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n, 2 * l.n_in,
                                       l.n_out, p->workspace, p->workspace_bytes, s));
         }
-        {
-            Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
-            GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in,
-                                      n, p->workspace, p->workspace_bytes, s));
+        if (!overlap_dw) {
+            {
+                Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
+                GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
+                                          2 * l.n_in, n, p->workspace, p->workspace_bytes, s));
+            }
+            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
         }
-        GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
         if (overlap) {
             const int64_t off = l.W - p->params;                 // [W_k | b_k] is contiguous
             const int64_t cnt = l.n_out * 2 * l.n_in + l.n_out;
@@ -208,6 +224,10 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         (void)hipEventRecord(ev_done, side);
         (void)hipStreamWaitEvent(st, ev_done, 0);
         return launch_status("gist_sage_step");
+    }
+    if (overlap_dw) {       // every dW / db must exist before Adam reads the gradient arena
+        (void)hipEventRecord(ev_done, side);
+        (void)hipStreamWaitEvent(st, ev_done, 0);
     }
     GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
                            beta2, eps, weight_decay, adam_step, s));

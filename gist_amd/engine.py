@@ -16,6 +16,8 @@ One engine = one (sub-)GCN on one GPU.  Everything lives in HBM for the whole ru
 The step follows SURVEY.md appendix A / cluster_gcn_ist_distrib.py:408-417 exactly:
 forward, mean CE over the batch rows, backward, Adam (coupled L2).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -173,12 +175,16 @@ class SageEngine(object):
             for (m, n, k) in ((self.n_max, o, 2 * i), (self.n_max, 2 * i, o), (o, 2 * i, self.n_max)):
                 need = max(need, L.gist_gemm_workspace_bytes(m, n, k))
         self._ws = hip.workspace(need, device)
+        self._ws2 = torch.empty(max(int(need), 1 << 20), dtype=torch.uint8, device=device)
         self._drop_offsets = []
         self.plan = None
         self._plan_keep = None
         # measured NEGATIVE on MI355X (H=4096: 4.47 -> 4.60 ms/step, h=512: 0.47 -> 0.57): the
         # concurrent Adam traffic slows the L2-bound SpMM and the stream joins add latency
         self.overlap_adam = False
+        # dW GEMM + column sum on a side stream next to dZ -> dropout -> SpMM: also measured
+        # negative (h=512: 0.39 -> 0.41 ms, H=4096: 4.40 -> 4.44); env knob for experiments
+        self.overlap_dw = os.environ.get('GIST_OVERLAP_DW', '0') == '1'
 
     # ------------------------------------------------------------------
     def attach_batcher(self, batcher):
@@ -207,6 +213,7 @@ class SageEngine(object):
         P.dZ, P.partials = self.dZ.data_ptr(), self.partials.data_ptr()
         P.row_loss, P.loss = self.row_loss.data_ptr(), self.loss.data_ptr()
         P.workspace, P.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        P.workspace2, P.workspace2_bytes = self._ws2.data_ptr(), self._ws2.numel()
         P.params, P.grads = A.params.data_ptr(), A.grads.data_ptr()
         P.exp_avg, P.exp_avg_sq = A.exp_avg.data_ptr(), A.exp_avg_sq.data_ptr()
         P.n_params = A.numel
@@ -220,7 +227,7 @@ class SageEngine(object):
         P.col_capacity = batcher.col.numel()
         P.norm, P.labels = batcher.norm.data_ptr(), batcher.lab.data_ptr()
         self.plan = P
-        self._plan_keep = (batcher, g, self._ws)           # keep every buffer alive
+        self._plan_keep = (batcher, g, self._ws, self._ws2)           # keep every buffer alive
         return P
 
     def enable_timer(self, capacity):
@@ -265,6 +272,8 @@ class SageEngine(object):
         flags = (_lib.GIST_STEP_TRAIN if train else 0) | (0 if b.ready else _lib.GIST_STEP_EXTRACT)
         if self.overlap_adam:
             flags |= _lib.GIST_STEP_OVERLAP_ADAM
+        if self.overlap_dw:
+            flags |= _lib.GIST_STEP_OVERLAP_DW
         off = self.drop_calls
         if train and self.p_drop > 0.0:
             for (i, o) in self.dims:

@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 2 */
+int gist_abi_version(void);   /* currently 3 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -277,6 +277,7 @@ typedef struct gist_step_plan {
     float *partials;               /* colsum scratch                                */
     float *row_loss, *loss;        /* [n_max], [1]                                  */
     void *workspace; int64_t workspace_bytes;   /* split-K scratch                  */
+    void *workspace2; int64_t workspace2_bytes; /* second scratch for GIST_STEP_OVERLAP_DW  */
     float *params, *grads, *exp_avg, *exp_avg_sq; int64_t n_params;   /* flat arenas */
     /* resident training graph + the batch buffers the extraction fills */
     const int32_t *g_rowptr, *g_col, *g_t_rowptr, *g_t_col;
@@ -302,6 +303,11 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
 
 #define GIST_STEP_EXTRACT 1   /* build the batch from ids (else: batch buffers already valid) */
 #define GIST_STEP_TRAIN 2     /* dropout on, backward + Adam (else: forward + loss only)      */
+#define GIST_STEP_OVERLAP_DW 8   /* dW = dY^T.Z (+ bias column sum) of every layer on a side
+                                    stream, concurrent with dZ = dY.W -> dropout -> SpMM on the
+                                    main stream (they only share the read of dY); joined before
+                                    Adam.  Pays where one GEMM cannot fill the chip (small
+                                    widths); needs workspace2 for the side stream's split-K   */
 #define GIST_STEP_OVERLAP_ADAM 4 /* per-layer Adam on a side stream under the backward GEMMs;
                                     same result (each slice is updated exactly once, after
                                     its last reader), joined before the call's work ends     */
