@@ -182,18 +182,23 @@ def test_full_size_step_properties():
     assert torch.isfinite(eng.arena.params).all()
 
 
-@pytest.mark.parametrize('n_layers,use_ln,p_drop', [(3, True, 0.2), (1, False, 0.2), (2, True, 0.0)])
-def test_native_step_equals_op_by_op(n_layers, use_ln, p_drop):
+@pytest.mark.parametrize('n_layers,use_ln,p_drop,n_feats,n_hidden', [
+    (3, True, 0.2, 50, 96), (1, False, 0.2, 50, 96), (2, True, 0.0, 50, 96),
+    (2, True, 0.2, 302, 512),       # wide rows: workgroup-per-row SpMM, VEC2 features
+    (3, False, 0.5, 301, 1024),     # odd feature width (scalar loads), no LayerNorm
+    (2, True, 0.2, 64, 2048),       # split-K dZ GEMM: mask applied in the slab reduction
+])
+def test_native_step_equals_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden):
     """gist_sage_step (one C-ABI call per iteration) issues the same kernels in the same
-    order as the Python op-by-op path: parameters after 4 steps with dropout 0.2 must be
+    order as the Python op-by-op path: parameters after 4 steps with dropout must be
     BITWISE identical, and the native HIP-event timer must see 5*(L+1)-2 launches/step."""
     from gist_amd import datasets
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
-    ds = datasets.toy(seed=9, n=3000, n_blocks=30, n_feats=50, n_classes=6, train_frac=1.0)
+    ds = datasets.toy(seed=9, n=3000, n_blocks=30, n_feats=n_feats, n_classes=6, train_frac=1.0)
     g = ds.g
     nid = np.arange(g.number_of_nodes(), dtype=np.int64)
-    dims = dims_for(50, 96, 6, n_layers)
+    dims = dims_for(n_feats, n_hidden, 6, n_layers)
     results = []
     for native in (True, False):
         random.seed(4)
