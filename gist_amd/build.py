@@ -9,7 +9,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OUT = os.path.join(HERE, 'libgist_hip.so')
+# dev knobs for A/B builds of kernel variants: extra -D flags and a different output name
+OUT = os.environ.get('GIST_LIB_OUT', os.path.join(HERE, 'libgist_hip.so'))
+EXTRA = os.environ.get('GIST_EXTRA_FLAGS', '').split()
 SOURCES = ['capi.hip', 'spmm.hip', 'gemm.hip', 'rowops.hip', 'subgraph.hip', 'step.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
@@ -21,7 +23,8 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=False):
-    objdir = os.path.join(HERE, 'build')
+    objdir = os.path.join(HERE, 'build' if not EXTRA else 'build_' + '_'.join(
+        f.strip('-').replace('=', '_') for f in EXTRA))
     os.makedirs(objdir, exist_ok=True)
     deps = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'gist_hip.h')]
     objs, procs = [], []
@@ -30,7 +33,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [HIPCC] + FLAGS + EXTRA + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

@@ -227,12 +227,27 @@ __device__ __forceinline__ float f4(const float4 &v, int j) {
     return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
 }
 
+#ifdef GIST_GEMM_TRACE   // dev builds only (scripts/gemm_trace.py): per-block phase timestamps
+__device__ unsigned long long g_gemm_trace[12 * 16384];
+#define GIST_TRACE(slot)                                                               \
+    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x < 16384)                     \
+        g_gemm_trace[12 * blockIdx.x + (slot)] = wall_clock64();
+// phase accounting of wave 0 inside the main loop, in s_memtime ticks
+#define GIST_PHASE_DECL unsigned long long ph_t = clock64(), ph_acc[6] = {0, 0, 0, 0, 0, 0};
+#define GIST_PHASE(i) { const unsigned long long n_ = clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
+#else
+#define GIST_TRACE(slot)
+#define GIST_PHASE_DECL
+#define GIST_PHASE(i)
+#endif
+
 // ALIGNED: both operands have 16-B aligned bases and leading dimensions % 4 == 0
 // (every buffer the engine allocates); otherwise the generic guarded loader runs.
 // T = block tile edge (128 or 64); 4 waves in 2x2, each wave (T/2)x(T/2) = (T/64)^2 MFMA tiles.
 template <bool A_KC, bool B_KC, bool ALIGNED, int T>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    GIST_TRACE(0)
     constexpr int BK = T == 128 ? 32 : 64;
     constexpr int TA = A_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
     constexpr int TB = B_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
@@ -299,12 +314,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         sstore(0, 0);
     }
     __syncthreads();
+    GIST_TRACE(1)
+    GIST_PHASE_DECL
 
     for (int kt = 0; kt < n_kt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < n_kt;
         if (more) gload(kt + 1);
         __builtin_amdgcn_sched_barrier(0);      // loads are issued; keep their consumers below
+        GIST_PHASE(0)
         const float *a_s = smem + cur * (TA + TB);
         const float *b_s = a_s + TA;
         if (g.setprio) __builtin_amdgcn_s_setprio(1);
@@ -326,9 +344,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         }
         if (g.setprio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);      // nothing of the store phase moves above the MFMAs
+        GIST_PHASE(1)
+#ifdef GIST_GEMM_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0) only: time spent waiting for the loads
+        __builtin_amdgcn_sched_barrier(0);
+        GIST_PHASE(2)
+#endif
         if (more) sstore(cur ^ 1, kt + 1);
+#ifdef GIST_GEMM_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        GIST_PHASE(3)
+#endif
         __syncthreads();
+        GIST_PHASE(4)
     }
+    GIST_TRACE(2)
 
     // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
     float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
@@ -347,6 +377,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             }
         }
     }
+#ifdef GIST_GEMM_TRACE
+    __builtin_amdgcn_s_waitcnt(0);          // this wave's stores are acknowledged
+    GIST_TRACE(3)
+    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x < 16384) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_gemm_trace[12 * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | hw;
+        for (int i = 0; i < 5; ++i) g_gemm_trace[12 * blockIdx.x + 5 + i] = ph_acc[i];
+        g_gemm_trace[12 * blockIdx.x + 10] = (unsigned long long)n_kt;
+    }
+#endif
 }
 
 // C[m,n] = sum_s slab_s[m,n] + bias[n]; slabs are dense [m][n].
@@ -480,6 +522,12 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
 }
 
 }  // namespace gist
+
+#ifdef GIST_GEMM_TRACE
+extern "C" int gist_gemm_trace_read(unsigned long long *out, int64_t n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gist::g_gemm_trace), n_blocks * 12 * 8);
+}
+#endif
 
 extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
