@@ -86,6 +86,27 @@ def cpu_baseline(ds, par_order, dims, use_layernorm, n_steps, seed):
     return step
 
 
+def measured_copy_gbs(dev, n_bytes=1 << 30, reps=5):
+    """Achievable HBM bandwidth ('measure achievable with a device copy
+    kernel'): read + write bytes of a large device-to-device copy over its HIP-event time."""
+    try:
+        import torch
+        src = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        b.record()
+        torch.cuda.synchronize()
+        return 2.0 * n_bytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    except Exception as e:          # reference measurement only: never fail the bench on it
+        print('bench: copy-bandwidth probe failed: %r' % (e,), file=sys.stderr)
+        return 0.0
+
+
 def main():
     args = parse()
     import torch
@@ -303,9 +324,13 @@ def main():
                     traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
+            copy_gbs = measured_copy_gbs(dev)
             out['roofline_spmm'] = {
                 'kernel': 'gist::spmm_csr_rowsplit_kernel', 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
+                # achievable HBM bandwidth on this box: a 1 GiB device-to-device copy (read+write)
+                'peak_measured_copy': round(copy_gbs, 1),
+                'frac_of_measured_copy': round(s_ach / copy_gbs, 4) if copy_gbs > 0 else None,
                 'traffic': traffic, 'launches': len(sp),
                 'avg_launch_ms': round(s_ms / max(len(sp), 1), 5),
                 'avg_algorithmic_bytes': round(s_bytes / max(len(sp), 1), 1),
