@@ -179,6 +179,9 @@ class SageEngine(object):
         self._drop_offsets = []
         self.plan = None
         self._plan_keep = None
+        # inference-only reassociation of the last layer (see forward); GIST_PROJECT_FIRST=0
+        # keeps the reference's aggregate-then-project order
+        self.project_first = os.environ.get('GIST_PROJECT_FIRST', '1') != '0'
         # measured NEGATIVE on MI355X (H=4096: 4.47 -> 4.60 ms/step, h=512: 0.47 -> 0.57): the
         # concurrent Adam traffic slows the L2-bound SpMM and the stream joins add latency
         self.overlap_adam = False
@@ -308,6 +311,19 @@ class SageEngine(object):
         self._drop_offsets = []
         for k, (i, o) in enumerate(self.dims):
             z = self.Z[k][:n]
+            if not training and o < i and k == self.L1 - 1 and self.project_first:
+                # Inference, narrowing layer (H -> C): [h | A^h] W^T = h W1^T + A^(h W2^T), so
+                # aggregate the C-wide projection instead of the H-wide activations (full-graph
+                # evaluation: one D=4096 pass over 115 M edges becomes a D=41 pass).  Same
+                # value up to fp32 summation order; training keeps the reference order because
+                # dropout acts on [h | A^h] and dW needs A^h.
+                W = A.W[k]
+                p_buf = self.dlogits[:n, :o]                      # free in inference
+                hip.gemm_nt(z[:, :i], W[:, i:], None, p_buf)
+                hip.gemm_nt(z[:, :i], W[:, :i], A.b[k], self.Y[k][:n, :o])
+                hip.spmm(b.rowptr, b.col, p_buf, self.Y[k][:n, :o], out_scale=b.norm,
+                         accumulate=True)
+                continue
             hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm)
             if training and self.p_drop > 0.0:
                 off = self._drop_offset(n * 2 * i)
