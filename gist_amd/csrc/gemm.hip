@@ -209,6 +209,49 @@ __device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&s
     }
 }
 
+// ---- VALU-free staging loads for full interior k tiles (ALIGNED operands) -------------
+// Next to an MFMA stream every VALU instruction of the same wave costs ~8.5 cycles of matrix
+// pipe time, SALU costs nothing (profiles/r01_gemm_phase_trace.md).  So the per-thread part of
+// a staging address is a 32-bit byte offset RELATIVE to the workgroup's tile origin, computed
+// once, and the k advance lives in a uniform (SGPR) base pointer: the loads are
+// `global_load_dwordx4 v, v_off, s[base:base+1]` with no vector address arithmetic at all.
+// (Relative offsets stay below 128 rows x ld x 4 B, so they fit 32 bits for any ld < 2^23.)
+template <int IT, int BK>
+__device__ __forceinline__ void rel_offsets_kc(int64_t ld, int rows, int row0, uint32_t (&off)[IT]) {
+    constexpr int CPR = BK / 4;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int dr = min(t / CPR + (256 / CPR) * i, rows - 1 - row0);     // clamped like the loader
+        off[i] = (uint32_t)(((int64_t)dr * ld + (t % CPR) * 4) * 4);
+    }
+}
+
+template <int IT, int R>
+__device__ __forceinline__ void rel_offsets_mc(int64_t ld, int col0, uint32_t (&off)[IT]) {
+    constexpr int CPR = R / 4;
+    const int t = threadIdx.x;
+    const int dc = min(col0 + (t % CPR) * 4, (int)ld - 4) - col0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        off[i] = (uint32_t)(((int64_t)(t / CPR + (256 / CPR) * i) * ld + dc) * 4);
+}
+
+template <int IT>
+__device__ __forceinline__ void load_rel(const float *__restrict__ ubase, const uint32_t (&off)[IT],
+                                         float4 (&st)[IT]) {
+    // raw buffer load: address = resource base (SGPRs, wave-uniform, rebuilt per k tile by
+    // SALU) + the thread's 32-bit byte offset -> buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ubase), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
+        st[i] = __builtin_bit_cast(float4, raw);
+    }
+}
+
 // ---- LDS -> fragment ---------------------------------------------------------
 // Returns the 4 values a lane feeds to MFMA steps j = 0..3 of k block q for the
 // 32-row (or 32-column) slab starting at `base`.
@@ -288,8 +331,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 stA[IT], stB[IT];
+    uint32_t offA[IT], offB[IT];
+    const float *originA = nullptr, *originB = nullptr;     // tile origin at k = 0 (uniform)
+    if constexpr (ALIGNED) {
+        if constexpr (A_KC) { rel_offsets_kc<IT, BK>(g.lda, g.m, row0, offA); originA = g.a + (int64_t)row0 * g.lda; }
+        else { rel_offsets_mc<IT, T>(g.lda, row0, offA); originA = g.a + row0; }
+        if constexpr (B_KC) { rel_offsets_kc<IT, BK>(g.ldb, g.n, col0, offB); originB = g.b + (int64_t)col0 * g.ldb; }
+        else { rel_offsets_mc<IT, T>(g.ldb, col0, offB); originB = g.b + col0; }
+    }
     auto gload = [&](int kt) {
         const int k0 = k_begin + kt * BK;
+        if constexpr (ALIGNED) {
+            if (k0 + BK <= k_end) {          // full tile: no clamps, no vector address math
+                load_rel<IT>(originA + (A_KC ? (int64_t)k0 : (int64_t)k0 * g.lda), offA, stA);
+                load_rel<IT>(originB + (B_KC ? (int64_t)k0 : (int64_t)k0 * g.ldb), offB, stB);
+                return;
+            }
+        }
         if constexpr (A_KC) load_kc<ALIGNED, IT, BK>(g.a, g.lda, g.m, k_end, row0, k0, stA);
         else load_mc<ALIGNED, IT, T>(g.a, g.lda, g.m, k_end, row0, k0, stA);
         if constexpr (B_KC) load_kc<ALIGNED, IT, BK>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
