@@ -29,6 +29,8 @@
 // touch 8 A panels + 8 B panels.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace gist {
@@ -375,8 +377,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     GIST_TRACE(1)
     GIST_PHASE_DECL
 
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const int cur = kt & 1;
+    // Row (or column) of each 32-wide slab this lane reads fragments for.  The slabs' indices
+    // are made opaque to the compiler: otherwise, for m/n-contiguous images, it pairs the two
+    // slabs' reads into ds_read2_b32 and then needs a v_add per two k values for the offsets
+    // that do not fit; unrelated bases pair along k instead (ds_read2st64_b32, immediates only).
+    int arow[NT], brow[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        arow[i] = wm * W + i * 32 + r;
+        brow[i] = wn * W + i * 32 + r;
+        asm volatile("" : "+v"(arow[i]));
+        asm volatile("" : "+v"(brow[i]));
+    }
+    // One k step; the LDS buffer index is a compile-time constant (the loop below is unrolled by
+    // two), so every LDS address of the step is an invariant VGPR plus an immediate and the
+    // buffer toggle costs no vector instruction.
+    auto kstep = [&](auto cur_c, int kt) {
+        constexpr int cur = decltype(cur_c)::value;
         const bool more = kt + 1 < n_kt;
         if (more) gload(kt + 1);
         __builtin_amdgcn_sched_barrier(0);      // loads are issued; keep their consumers below
@@ -388,9 +405,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         for (int q = 0; q < BK / 8; ++q) {
             float4 af[NT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T, BK>(a_s, wm * W + i * 32, q, r, hh);
+            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T, BK>(a_s, arow[i], q, 0, hh);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T, BK>(b_s, wn * W + j * 32, q, r, hh);
+            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T, BK>(b_s, brow[j], q, 0, hh);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -415,6 +432,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #endif
         __syncthreads();
         GIST_PHASE(4)
+    };
+    {
+        int kt = 0;
+        for (; kt + 1 < n_kt; kt += 2) {
+            kstep(std::integral_constant<int, 0>{}, kt);
+            kstep(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        if (kt < n_kt) kstep(std::integral_constant<int, 0>{}, kt);
     }
     GIST_TRACE(2)
 
