@@ -42,8 +42,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // k depth of a tile: 32 for the 128x128 block, 64 for the 64x64 block (half the barriers
 // per flop where a SIMD holds a single wave and nothing hides them).
 template <int R, int BK> struct Img {   // R = rows of a k-contiguous image = columns of an m/n image
-    static constexpr int LDK = BK + 4;      // k-contiguous image: row stride (floats)
-    static constexpr int KC = R * LDK;      // floats
+    // k-contiguous image: R rows of BK floats, no padding; the 16-byte chunk c of row r sits in
+    // slot c ^ (r & 7) of the row (XOR swizzle: 8 consecutive rows put the same k chunk into 8
+    // different bank groups, and a row is a contiguous 4*BK bytes so LDS-DMA can fill it)
+    static constexpr int KC = R * BK;       // floats
     static constexpr int MC = BK * R;
     static constexpr int ITERS = R * BK / 1024;   // float4 per thread per k tile (256 threads)
 };
@@ -148,11 +150,11 @@ template <int IT, int BK>
 __device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&st)[IT]) {
     constexpr int CPR = BK / 4;
     const int t = threadIdx.x;
-    const int kq = (t % CPR) * 4;
+    const int kq = t % CPR;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int r = t / CPR + (256 / CPR) * i;
-        *reinterpret_cast<float4 *>(s + r * (BK + 4) + kq) = st[i];
+        *reinterpret_cast<float4 *>(s + r * BK + ((kq ^ (r & 7)) << 2)) = st[i];
     }
 }
 
@@ -239,6 +241,51 @@ __device__ __forceinline__ void rel_offsets_mc(int64_t ld, int col0, uint32_t (&
         off[i] = (uint32_t)(((int64_t)(t / CPR + (256 / CPR) * i) * ld + dc) * 4);
 }
 
+// LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction moves 64 x 16 B from per-lane
+// global addresses to 1 KiB of LDS at M0 + lane*16, without passing through VGPRs and without a
+// ds_write (a ds_write_b128 next to MFMAs costs 26-45 cycles of matrix-pipe time).  A 16 KiB
+// image is 16 such instructions, 4 per wave: instruction j = 4*wave + jj fills LDS bytes
+// [1024 j, 1024 (j+1)) of the image, so the thread's source is whatever belongs there:
+//   k-contiguous image : row (64j + lane) / CPR, slot (64j + lane) % CPR, k chunk slot ^ (row&7)
+//   m/n-contiguous     : k row (64j + lane) / (R/4), column chunk (64j + lane) % (R/4)
+template <int IT, int BK>
+__device__ __forceinline__ void dma_offsets_kc(int64_t ld, int rows, int row0, int wave, int lane,
+                                               uint32_t (&off)[IT]) {
+    constexpr int CPR = BK / 4;
+#pragma unroll
+    for (int jj = 0; jj < IT; ++jj) {
+        const int p = 64 * (IT * wave + jj) + lane;
+        const int r = p / CPR, slot = p % CPR;
+        const int dr = min(r, rows - 1 - row0);
+        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ (r & 7)) << 2)) * 4);
+    }
+}
+
+template <int IT, int R>
+__device__ __forceinline__ void dma_offsets_mc(int64_t ld, int col0, int wave, int lane,
+                                               uint32_t (&off)[IT]) {
+    constexpr int CPR = R / 4;
+#pragma unroll
+    for (int jj = 0; jj < IT; ++jj) {
+        const int p = 64 * (IT * wave + jj) + lane;
+        const int kk = p / CPR;
+        const int dc = min(col0 + (p % CPR) * 4, (int)ld - 4) - col0;
+        off[jj] = (uint32_t)(((int64_t)kk * ld + dc) * 4);
+    }
+}
+
+template <int IT>
+__device__ __forceinline__ void dma_image(const float *ubase, const uint32_t *off, float *image,
+                                          int wave) {
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ubase), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < IT; ++jj)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void *)(image + (IT * wave + jj) * 256), 16,
+            off[jj], 0, 0, 0);
+}
+
 template <int IT>
 __device__ __forceinline__ void load_rel(const float *__restrict__ ubase, const uint32_t (&off)[IT],
                                          float4 (&st)[IT]) {
@@ -255,15 +302,18 @@ __device__ __forceinline__ void load_rel(const float *__restrict__ ubase, const 
 }
 
 // ---- LDS -> fragment ---------------------------------------------------------
-// Returns the 4 values a lane feeds to MFMA steps j = 0..3 of k block q for the
-// 32-row (or 32-column) slab starting at `base`.
+// The 4 values a lane feeds to MFMA steps j = 0..3 of k block q (k = 8q + 4hh .. +3) of the
+// 32-row (or 32-column) slab whose row for this lane is `row`.
+//   k-contiguous image: one ds_read_b128 at row*BK + ((2q+hh) ^ (row&7))*4; `kc_off[q&3]` holds
+//   that offset for q = 0..3 (computed once: the XOR is lane dependent), q >= 4 (BK = 64) adds 32;
+//   m/n-contiguous image [k][C]: 4 scalars C apart (paired along k into ds_read2st64_b32).
 template <bool KC, int C, int BK>
-__device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int base, int q, int r,
-                                            int hh) {
+__device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int row, int q, int hh,
+                                            const int (&kc_off)[4]) {
     if constexpr (KC) {
-        return *reinterpret_cast<const float4 *>(s + (base + r) * (BK + 4) + 8 * q + 4 * hh);
+        return *reinterpret_cast<const float4 *>(s + kc_off[q & 3] + (q >> 2) * 32);
     } else {
-        const float *p = s + (8 * q + 4 * hh) * C + base + r;
+        const float *p = s + (8 * q + 4 * hh) * C + row;
         return make_float4(p[0], p[C], p[2 * C], p[3 * C]);
     }
 }
@@ -332,24 +382,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Staging.  ALIGNED operands: full k tiles go global -> LDS by DMA (no VGPRs, no ds_write, no
+    // vector address arithmetic: the resource base in SGPRs carries tile origin + k advance, the
+    // thread's part is a 32-bit offset computed once).  The ragged last k tile of a split, and
+    // every tile of unaligned operands, takes the register path (clamped loads, k mask, ds_write).
     float4 stA[IT], stB[IT];
     uint32_t offA[IT], offB[IT];
     const float *originA = nullptr, *originB = nullptr;     // tile origin at k = 0 (uniform)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     if constexpr (ALIGNED) {
-        if constexpr (A_KC) { rel_offsets_kc<IT, BK>(g.lda, g.m, row0, offA); originA = g.a + (int64_t)row0 * g.lda; }
-        else { rel_offsets_mc<IT, T>(g.lda, row0, offA); originA = g.a + row0; }
-        if constexpr (B_KC) { rel_offsets_kc<IT, BK>(g.ldb, g.n, col0, offB); originB = g.b + (int64_t)col0 * g.ldb; }
-        else { rel_offsets_mc<IT, T>(g.ldb, col0, offB); originB = g.b + col0; }
+        if constexpr (A_KC) { dma_offsets_kc<IT, BK>(g.lda, g.m, row0, wave_u, lane, offA); originA = g.a + (int64_t)row0 * g.lda; }
+        else { dma_offsets_mc<IT, T>(g.lda, row0, wave_u, lane, offA); originA = g.a + row0; }
+        if constexpr (B_KC) { dma_offsets_kc<IT, BK>(g.ldb, g.n, col0, wave_u, lane, offB); originB = g.b + (int64_t)col0 * g.ldb; }
+        else { dma_offsets_mc<IT, T>(g.ldb, col0, wave_u, lane, offB); originB = g.b + col0; }
     }
+    auto full_tile = [&](int kt) { return ALIGNED && k_begin + (kt + 1) * BK <= k_end; };
+    auto dma = [&](int buf, int kt) {
+        const int k0 = k_begin + kt * BK;
+        float *sa = smem + buf * (TA + TB);
+        dma_image<IT>(originA + (A_KC ? (int64_t)k0 : (int64_t)k0 * g.lda), offA, sa, wave_u);
+        dma_image<IT>(originB + (B_KC ? (int64_t)k0 : (int64_t)k0 * g.ldb), offB, sa + TA, wave_u);
+    };
     auto gload = [&](int kt) {
         const int k0 = k_begin + kt * BK;
-        if constexpr (ALIGNED) {
-            if (k0 + BK <= k_end) {          // full tile: no clamps, no vector address math
-                load_rel<IT>(originA + (A_KC ? (int64_t)k0 : (int64_t)k0 * g.lda), offA, stA);
-                load_rel<IT>(originB + (B_KC ? (int64_t)k0 : (int64_t)k0 * g.ldb), offB, stB);
-                return;
-            }
-        }
         if constexpr (A_KC) load_kc<ALIGNED, IT, BK>(g.a, g.lda, g.m, k_end, row0, k0, stA);
         else load_mc<ALIGNED, IT, T>(g.a, g.lda, g.m, k_end, row0, k0, stA);
         if constexpr (B_KC) load_kc<ALIGNED, IT, BK>(g.b, g.ldb, g.n, k_end, col0, k0, stB);
@@ -360,43 +415,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         float *sb = sa + TA;
         if constexpr (ALIGNED) {
             const int k0 = k_begin + kt * BK;
-            if (k0 + BK > k_end) {            // only the last k tile of a split can be ragged
-                if constexpr (A_KC) mask_kc<IT, BK>(stA, k_end, k0); else mask_mc<IT, T>(stA, k_end, k0);
-                if constexpr (B_KC) mask_kc<IT, BK>(stB, k_end, k0); else mask_mc<IT, T>(stB, k_end, k0);
-            }
+            if constexpr (A_KC) mask_kc<IT, BK>(stA, k_end, k0); else mask_mc<IT, T>(stA, k_end, k0);
+            if constexpr (B_KC) mask_kc<IT, BK>(stB, k_end, k0); else mask_mc<IT, T>(stB, k_end, k0);
         }
         if constexpr (A_KC) store_kc<IT, BK>(sa, stA); else store_mc<IT, T>(sa, stA);
         if constexpr (B_KC) store_kc<IT, BK>(sb, stB); else store_mc<IT, T>(sb, stB);
     };
 
     if (n_kt > 0) {
-        gload(0);
-        sstore(0, 0);
+        if (full_tile(0)) {
+            dma(0, 0);
+        } else {
+            gload(0);
+            sstore(0, 0);
+        }
     }
+    __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): the DMA has landed in LDS
     __syncthreads();
     GIST_TRACE(1)
     GIST_PHASE_DECL
 
-    // Row (or column) of each 32-wide slab this lane reads fragments for.  The slabs' indices
-    // are made opaque to the compiler: otherwise, for m/n-contiguous images, it pairs the two
-    // slabs' reads into ds_read2_b32 and then needs a v_add per two k values for the offsets
-    // that do not fit; unrelated bases pair along k instead (ds_read2st64_b32, immediates only).
+    // Fragment addresses.  k-contiguous image: offset of k block q = 0..3 for each slab's row
+    // (the XOR swizzle is lane dependent, so these are computed once).  m/n-contiguous image:
+    // the slab's row, made opaque to the compiler -- otherwise it pairs the two slabs' reads
+    // into ds_read2_b32 and needs a v_add per two k values for the offsets that do not fit;
+    // unrelated bases pair along k instead (ds_read2st64_b32, immediates only).
     int arow[NT], brow[NT];
+    int akc[NT][4], bkc[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         arow[i] = wm * W + i * 32 + r;
         brow[i] = wn * W + i * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            akc[i][q] = arow[i] * BK + ((((2 * q + hh) ^ (arow[i] & 7)) & 7) << 2);
+            bkc[i][q] = brow[i] * BK + ((((2 * q + hh) ^ (brow[i] & 7)) & 7) << 2);
+        }
         asm volatile("" : "+v"(arow[i]));
         asm volatile("" : "+v"(brow[i]));
     }
     // One k step; the LDS buffer index is a compile-time constant (the loop below is unrolled by
     // two), so every LDS address of the step is an invariant VGPR plus an immediate and the
     // buffer toggle costs no vector instruction.
-    auto kstep = [&](auto cur_c, int kt) {
+    // mode 0: the next tile is staged by DMA; 1: through registers (ragged / unaligned);
+    // 2: there is no next tile.  Compile-time, so the steady-state loop (mode 0) carries no
+    // staging registers at all.
+    auto kstep = [&](auto cur_c, auto mode_c, int kt) {
         constexpr int cur = decltype(cur_c)::value;
-        const bool more = kt + 1 < n_kt;
-        if (more) gload(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);      // loads are issued; keep their consumers below
+        constexpr int mode = decltype(mode_c)::value;
+        if constexpr (mode == 0) dma(cur ^ 1, kt + 1);      // buffer cur^1 is free since the last barrier
+        if constexpr (mode == 1) gload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);      // staging is issued; keep the MFMAs below
         GIST_PHASE(0)
         const float *a_s = smem + cur * (TA + TB);
         const float *b_s = a_s + TA;
@@ -405,9 +474,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         for (int q = 0; q < BK / 8; ++q) {
             float4 af[NT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T, BK>(a_s, arow[i], q, 0, hh);
+            for (int i = 0; i < NT; ++i) af[i] = read_frag<A_KC, T, BK>(a_s, arow[i], q, hh, akc[i]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T, BK>(b_s, brow[j], q, 0, hh);
+            for (int j = 0; j < NT; ++j) bf[j] = read_frag<B_KC, T, BK>(b_s, brow[j], q, hh, bkc[j]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -420,12 +489,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         if (g.setprio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);      // nothing of the store phase moves above the MFMAs
         GIST_PHASE(1)
-#ifdef GIST_GEMM_TRACE
-        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0) only: time spent waiting for the loads
+        if constexpr (mode != 2) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): DMA landed / loads arrived
         __builtin_amdgcn_sched_barrier(0);
         GIST_PHASE(2)
-#endif
-        if (more) sstore(cur ^ 1, kt + 1);
+        if constexpr (mode == 1) sstore(cur ^ 1, kt + 1);
 #ifdef GIST_GEMM_TRACE
         __builtin_amdgcn_sched_barrier(0);
         GIST_PHASE(3)
@@ -434,12 +501,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         GIST_PHASE(4)
     };
     {
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        using C2 = std::integral_constant<int, 2>;
         int kt = 0;
-        for (; kt + 1 < n_kt; kt += 2) {
-            kstep(std::integral_constant<int, 0>{}, kt);
-            kstep(std::integral_constant<int, 1>{}, kt + 1);
+        if constexpr (ALIGNED) {
+            // steps whose next tile is a full one: only the last tile of a split can be ragged
+            const int n_dma = n_kt - 1 - (n_kt > 0 && !full_tile(n_kt - 1) ? 1 : 0);
+            for (; kt + 1 < n_dma; kt += 2) {
+                kstep(C0{}, C0{}, kt);
+                kstep(C1{}, C0{}, kt + 1);
+            }
         }
-        if (kt < n_kt) kstep(std::integral_constant<int, 0>{}, kt);
+        for (; kt < n_kt; ++kt) {                // the last (<= 3) steps, or every step if unaligned
+            const int mode = kt + 1 >= n_kt ? 2 : (full_tile(kt + 1) ? 0 : 1);
+            if ((kt & 1) == 0) {
+                if (mode == 0) kstep(C0{}, C0{}, kt); else if (mode == 1) kstep(C0{}, C1{}, kt); else kstep(C0{}, C2{}, kt);
+            } else {
+                if (mode == 0) kstep(C1{}, C0{}, kt); else if (mode == 1) kstep(C1{}, C1{}, kt); else kstep(C1{}, C2{}, kt);
+            }
+        }
     }
     GIST_TRACE(2)
 
