@@ -525,21 +525,62 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     GIST_TRACE(2)
 
     // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
-    float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
+    // A workgroup usually stores its tile while the CU's other workgroup streams MFMAs, and
+    // vector ALU work then only issues in the gaps of that stream (a 64-element epilogue took
+    // up to 60 us).  So the stores carry no vector arithmetic: raw buffer stores whose resource
+    // covers exactly the valid rows of this tile, per-lane column offset computed once (columns
+    // >= n get an out-of-range offset and are dropped by the hardware range check), and the
+    // row advance in a scalar offset.
+    float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride + (int64_t)row0 * g.ldc + col0;
     const bool add_bias = g.bias != nullptr && g.split_stride == 0;
+    const int rows_valid = min(g.m - row0, T);
+    __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+        cbase, 0, (int)((int64_t)rows_valid * g.ldc * 4), 0x00020000);
+    const uint32_t ldc_b = (uint32_t)g.ldc * 4;
+    uint32_t cvoff[NT];
+    float bv[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int cc = col0 + wn * W + j * 32 + r;
-        if (cc >= g.n) continue;
-        const float bv = add_bias ? g.bias[cc] : 0.f;
+        const int cl = wn * W + j * 32 + r;                       // column inside the tile
+        const bool ok = col0 + cl < g.n;
+        cvoff[j] = ok ? (uint32_t)(wm * W + 4 * hh) * ldc_b + (uint32_t)cl * 4 : 0x7fffffffu;
+        bv[j] = (add_bias && ok) ? g.bias[col0 + cl] : 0.f;
+    }
+    if (add_bias) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += bv[j];
+    }
+    // The hardware range check covers the VECTOR offset only (the scalar offset is added after
+    // it), so the row advance may ride in the scalar offset only when every row of the tile is
+    // valid; the last row tile of a ragged m adds it to the vector offset instead.
+    if (rows_valid == T) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rr = row0 + wm * W + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (rr < g.m) cbase[(int64_t)rr * g.ldc + cc] = acc[i][j][e] + bv;
+                const uint32_t soff = (uint32_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_b;   // uniform
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float v = acc[i][j][e];       // (bit_cast of the vector element itself
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j], soff, 0);
+                }                                       //  picks element 0: go through a scalar)
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t roff = (uint32_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc_b;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float v = acc[i][j][e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j] + roff, 0, 0);
+                }
+            }
     }
 #ifdef GIST_GEMM_TRACE
     __builtin_amdgcn_s_waitcnt(0);          // this wave's stores are acknowledged
