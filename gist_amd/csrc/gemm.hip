@@ -694,6 +694,10 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     if (m >= (1LL << 31) || n >= (1LL << 31) || k >= (1LL << 31)) {
         set_error("%s: size >= 2^31", name); return GIST_EINVAL;
     }
+    // tile-relative byte offsets are 32-bit (DMA staging, buffer-store epilogue): 128 rows x ld x 4
+    if (lda >= (1LL << 22) || ldb >= (1LL << 22) || ldc >= (1LL << 22)) {
+        set_error("%s: leading dimension >= 2^22 elements", name); return GIST_EINVAL;
+    }
     GemmArgs g;
     g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.c = c; g.ldc = ldc;
     g.m = (int)m; g.n = (int)n; g.k = (int)k;

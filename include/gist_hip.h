@@ -86,7 +86,11 @@ int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col,
  * Dense projection (fp32 MFMA, exact fp32 arithmetic)
  * ------------------------------------------------------------------------- */
 
-/* Bytes of workspace gist_gemm_* may need for the given output shape (split-K
+/* All three forms: sizes < 2^31, leading dimensions < 2^22 elements (GIST_EINVAL otherwise).
+ * 16-byte aligned operands with leading dimensions % 4 == 0 (every buffer the engine
+ * allocates) take the LDS-DMA staging path; anything else is still exact, only slower.
+ *
+ * Bytes of workspace gist_gemm_* may need for the given output shape (split-K
  * partial sums); 0 is a valid answer.  Host function. */
 int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
