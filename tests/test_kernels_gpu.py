@@ -153,6 +153,56 @@ def test_gemm_strided_unaligned_operands(hip):
     assert (ybuf[:, :3] == 0).all() and (ybuf[:, 3 + n:] == 0).all()
 
 
+def test_gemm_output_window_untouched_around_ragged_tiles(hip):
+    """The store epilogue relies on the hardware range check for ragged columns and on a
+    vector-offset path for ragged rows: nothing outside the [m, n] window may be written,
+    for all three forms, with m and n that are not tile multiples."""
+    rs = np.random.RandomState(4)
+    m, n, k = 130, 70, 96
+    guard = 5
+    for form in ('nt', 'nn', 'tn'):
+        ybuf = torch.full((m + guard, n + 6), 123.0, device=DEV)
+        y = ybuf[:m, 2:2 + n]
+        if form == 'nt':
+            a, w = rs.randn(m, k).astype(np.float32), rs.randn(n, k).astype(np.float32)
+            hip.gemm_nt(dev(a), dev(w), None, y)
+            ref = a.astype(np.float64) @ w.T.astype(np.float64)
+        elif form == 'nn':
+            a, w = rs.randn(m, k).astype(np.float32), rs.randn(k, n).astype(np.float32)
+            hip.gemm_nn(dev(a), dev(w), y)
+            ref = a.astype(np.float64) @ w.astype(np.float64)
+        else:
+            a, w = rs.randn(k, m).astype(np.float32), rs.randn(k, n).astype(np.float32)
+            hip.gemm_tn(dev(a), dev(w), y)
+            ref = a.T.astype(np.float64) @ w.astype(np.float64)
+        close(y, ref.astype(np.float32), tol=2e-5)
+        assert (ybuf[m:] == 123.0).all(), form
+        assert (ybuf[:, :2] == 123.0).all() and (ybuf[:, 2 + n:] == 123.0).all(), form
+
+
+def test_gemm_rows_beyond_4gib(hip):
+    """Tile-relative 32-bit offsets: an operand of 4.9 GB (300 000 rows x 4096), whose last
+    rows lie beyond 4 GiB from its base, as in full-graph evaluation."""
+    m, k, n = 300000, 4096, 64
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    a = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.randn(n, k, device=DEV, generator=gen)
+    y = torch.empty(m, n, device=DEV)
+    hip.gemm_nt(a, w, None, y)
+    for lo in (0, 150000, m - 300):
+        ref = (a[lo:lo + 300].double() @ w.double().t()).float()
+        assert (y[lo:lo + 300] - ref).abs().max().item() < 2e-3
+
+
+def test_gemm_rejects_huge_leading_dimension(hip):
+    from gist_amd import _lib
+    L = _lib.load()
+    a = torch.zeros(4, 4, device=DEV)
+    rc = L.gist_gemm_nt_f32(a.data_ptr(), 1 << 22, a.data_ptr(), 4, None, a.data_ptr(), 4, 4, 4, 4,
+                            None, 0, None)
+    assert rc < 0 and b'leading dimension' in L.gist_last_error()
+
+
 def test_gemm_identity_asymmetric(hip):
     """A = I against an asymmetric B catches a swapped C/D register map."""
     n = 96
