@@ -6,23 +6,34 @@
 //   NN  Z[m,n] = G[m,k] . W[k,n]            dZ = dY . W
 //   TN  D[m,n] = G[k,m]^T . A[k,n]          dW = dY^T . Z
 //
-// Block tile 128x128x32 (or 64x64x32 when the output has too few 128x128 tiles to fill and
+// Block tile 128x128x32 (or 64x64x64 when the output has too few 128x128 tiles to fill and
 // balance 256 CUs), 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles of
-// 32x32 (64 accumulator VGPRs; one tile for the 64x64 block).  Global -> registers -> LDS staging,
-// double buffered (the next tile's loads are issued before the MFMA block and
-// written to the other LDS buffer after it; one barrier per k tile).
+// 32x32 (64 accumulator VGPRs; one tile for the 64x64 block).  Two LDS buffers, one barrier
+// per k tile.  The main loop holds nothing but MFMAs, fragment reads, 8 LDS-DMA instructions
+// and scalar ops: next to an fp32 MFMA stream a VALU op of the wave costs ~8.5 cycles of
+// matrix-pipe time and a ds_write_b128 26-45 (profiles/r01_gemm_phase_trace.md), so
+//   * full k tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds): the buffer
+//     resource's base (SGPRs) carries tile origin + k advance, the thread's part is a 32-bit
+//     offset computed once; no staging VGPRs, no ds_write;
+//   * the k loop is unrolled by two, so the LDS buffer index is a compile-time constant and
+//     every fragment address is an invariant VGPR + immediate;
+//   * only the ragged last k tile of a split (and operands that are not 16-B aligned) goes
+//     through registers (clamped loads, k mask, ds_write);
+//   * the epilogue is raw buffer stores: row advance in the scalar offset, ragged columns
+//     dropped by the hardware range check.
 //
-// LDS images (chosen so that global loads stay 16-B coalesced and fragment reads
-// are bank-conflict free, MI355X_MICROARCH.md section LDS):
-//   k-contiguous operand  : [128 rows][32 k + 4 pad]; a lane reads ONE ds_read_b128
-//                           = 4 consecutive k of its row.  Lanes 0-31 take k = 8q..8q+3,
-//                           lanes 32-63 k = 8q+4..8q+7, so MFMA step j of block q
-//                           multiplies k = 8q + 4*(lane>>5) + j -- a permutation of k
-//                           applied to BOTH operands, which a dot product allows.
-//   m/n-contiguous operand: [32 k][128]; a lane reads 4 ds_read_b32 at the same
-//                           permuted k; 32 consecutive lanes hit 32 consecutive banks.
+// LDS images (MI355X_MICROARCH.md section LDS):
+//   k-contiguous operand  : [128 rows][32 k], no padding; the 16-byte chunk c of row r sits in
+//                           slot c ^ (r & 7) of its row (a DMA instruction's 1 KiB lands
+//                           contiguously; 8 consecutive rows put the same k chunk into 8
+//                           different bank groups).  A lane reads ONE ds_read_b128 = 4
+//                           consecutive k of its row.  Lanes 0-31 take k = 8q..8q+3, lanes 32-63
+//                           k = 8q+4..8q+7, so MFMA step j of block q multiplies
+//                           k = 8q + 4*(lane>>5) + j -- a permutation of k applied to BOTH
+//                           operands, which a dot product allows.
+//   m/n-contiguous operand: [32 k][128]; a lane reads its 4 k values as two
+//                           ds_read2st64_b32; 32 consecutive lanes hit 32 consecutive banks.
 //
-// Ragged m, n, k are zero-filled in the loader; the store is predicated.
 // Shapes with few output tiles (n = 41 logits, dW of the last layer) are split along
 // k across blockIdx.z into a workspace and reduced deterministically.
 // Blocks are dealt to XCDs in 8x8 super-tiles so that the 64 blocks sharing an L2
@@ -213,34 +224,13 @@ __device__ __forceinline__ void store_mc(float *__restrict__ s, const float4 (&s
     }
 }
 
-// ---- VALU-free staging loads for full interior k tiles (ALIGNED operands) -------------
+// ---- LDS-DMA staging for full interior k tiles (ALIGNED operands) ------------------------
 // Next to an MFMA stream every VALU instruction of the same wave costs ~8.5 cycles of matrix
-// pipe time, SALU costs nothing (profiles/r01_gemm_phase_trace.md).  So the per-thread part of
-// a staging address is a 32-bit byte offset RELATIVE to the workgroup's tile origin, computed
-// once, and the k advance lives in a uniform (SGPR) base pointer: the loads are
-// `global_load_dwordx4 v, v_off, s[base:base+1]` with no vector address arithmetic at all.
-// (Relative offsets stay below 128 rows x ld x 4 B, so they fit 32 bits for any ld < 2^23.)
-template <int IT, int BK>
-__device__ __forceinline__ void rel_offsets_kc(int64_t ld, int rows, int row0, uint32_t (&off)[IT]) {
-    constexpr int CPR = BK / 4;
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int dr = min(t / CPR + (256 / CPR) * i, rows - 1 - row0);     // clamped like the loader
-        off[i] = (uint32_t)(((int64_t)dr * ld + (t % CPR) * 4) * 4);
-    }
-}
-
-template <int IT, int R>
-__device__ __forceinline__ void rel_offsets_mc(int64_t ld, int col0, uint32_t (&off)[IT]) {
-    constexpr int CPR = R / 4;
-    const int t = threadIdx.x;
-    const int dc = min(col0 + (t % CPR) * 4, (int)ld - 4) - col0;
-#pragma unroll
-    for (int i = 0; i < IT; ++i)
-        off[i] = (uint32_t)(((int64_t)(t / CPR + (256 / CPR) * i) * ld + dc) * 4);
-}
-
+// pipe time and a ds_write_b128 26-45, SALU costs nothing (profiles/r01_gemm_phase_trace.md).
+// So the per-thread part of a staging address is a 32-bit byte offset RELATIVE to the
+// workgroup's tile origin, computed once, and the k advance lives in the wave-uniform base of
+// a buffer resource (SGPRs, rebuilt per k tile by SALU).  Relative offsets stay below
+// 128 rows x ld x 4 B, so they fit 32 bits for any ld < 2^22 (checked by the launcher).
 // LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction moves 64 x 16 B from per-lane
 // global addresses to 1 KiB of LDS at M0 + lane*16, without passing through VGPRs and without a
 // ds_write (a ds_write_b128 next to MFMAs costs 26-45 cycles of matrix-pipe time).  A 16 KiB
@@ -284,21 +274,6 @@ __device__ __forceinline__ void dma_image(const float *ubase, const uint32_t *of
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rsrc, (__attribute__((address_space(3))) void *)(image + (IT * wave + jj) * 256), 16,
             off[jj], 0, 0, 0);
-}
-
-template <int IT>
-__device__ __forceinline__ void load_rel(const float *__restrict__ ubase, const uint32_t (&off)[IT],
-                                         float4 (&st)[IT]) {
-    // raw buffer load: address = resource base (SGPRs, wave-uniform, rebuilt per k tile by
-    // SALU) + the thread's 32-bit byte offset -> buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(ubase), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
-        st[i] = __builtin_bit_cast(float4, raw);
-    }
 }
 
 // ---- LDS -> fragment ---------------------------------------------------------
