@@ -35,6 +35,7 @@ SIGNATURES = {
     'gist_device_count': (_int, []),
     'gist_in_degree_norm_f32': (_int, [_p, _i64, _p, _p]),
     'gist_spmm_csr_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p]),
+    'gist_partition_graph': (_int, [_p, _p, _p, _p, _i64, _i32, _u64, _i32, _f, _p]),
     'gist_spmm_csr_blocked_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _p]),
     'gist_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'gist_gemm_nt_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),

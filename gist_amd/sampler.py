@@ -13,7 +13,9 @@ Differences, all on the MI355X side of the boundary:
     (partition_utils.py:20-25), built by HIP kernels from the resident graph -- the
     reference does this on the CPU inside the timed loop and uploads the result;
   * METIS is not bundled: partition lists come from the reference's own cache file
-    `../data/{dn}_{psize}.npy` (sampler.py:44-51 format) or from `par_li=`.
+    `../data/{dn}_{psize}.npy` (sampler.py:44-51 format), from `par_li=`, or -- on a cache
+    miss, like the reference -- from the library's own partitioner (gist_partition_graph),
+    whose result is then cached in the same format.
 """
 import os
 import random
@@ -41,9 +43,13 @@ def save_partition_cache(path, par_li):
 
 
 def get_partition_list(g, psize):
-    """partition_utils.py:11-18 -- needs METIS through DGL, which is not bundled."""
+    """partition_utils.py:11-18: list of node-id arrays, one per part.  The parts come from the
+    library's own partitioner (dgl_compat.transform.metis_partition), not from METIS."""
+    from .dgl_compat import NID
+    from .dgl_compat.backend import asnumpy
     from .dgl_compat.transform import metis_partition
-    return metis_partition(g, psize)
+    p_gs = metis_partition(g, psize)
+    return [asnumpy(val.ndata[NID]) for _, val in p_gs.items()]
 
 
 def get_subgraph(g, par_arr, i, psize, batch_size):

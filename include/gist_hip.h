@@ -83,6 +83,21 @@ int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col,
                               gist_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Data preparation (HOST function, host pointers)
+ * ------------------------------------------------------------------------- */
+
+/* k-way partition of a graph: the stand-in for dgl.transform.metis_partition
+ * (cluster_gcn/partition_utils.py:11-18; METIS is not available offline).  rowptr/col: in-edge
+ * CSR, t_rowptr/t_col: out-edge CSR (may be NULL for a symmetric graph); neighbours are the
+ * union.  Restreaming linear-deterministic-greedy: BFS-ordered placement, then n_passes
+ * refinement sweeps; every part holds at most ceil((1 + imbalance) * n / k) nodes and none is
+ * empty.  part[v] in [0, k).  Deterministic for a given seed.  One-time preparation whose
+ * result ClusterIter caches in the reference's ../data/{dataset}_{psize}.npy format. */
+int gist_partition_graph(const int32_t *rowptr, const int32_t *col,
+                         const int32_t *t_rowptr, const int32_t *t_col, int64_t n, int32_t k,
+                         uint64_t seed, int32_t n_passes, float imbalance, int32_t *part);
+
+/* ---------------------------------------------------------------------------
  * Dense projection (fp32 MFMA, exact fp32 arithmetic)
  * ------------------------------------------------------------------------- */
 

@@ -393,3 +393,29 @@ def test_config4_amazon_like_F100_C47_L4():
     from gist_amd import datasets
     ds = datasets.amazon_synth(seed=1, n=171000, n_blocks=1500)
     _check(*_steps_vs_oracle(ds, 10, 512, 4, 3, p_seed=2))
+
+
+def test_cluster_iter_partitions_on_cache_miss(tmp_path, monkeypatch):
+    """sampler.py:44-53: without a cache file ClusterIter partitions the train graph itself
+    (here: gist_partition_graph instead of METIS), writes the reference's .npy format and
+    reads the same list back on the next construction."""
+    from gist_amd import datasets
+    from gist_amd.sampler import ClusterIter, load_partition_cache
+    ds = datasets.toy(seed=4, train_frac=0.8)
+    train_nid = np.nonzero(ds.g.ndata['train_mask'].numpy())[0].astype(np.int64)
+    work = tmp_path / 'run'
+    work.mkdir()
+    monkeypatch.chdir(work)                      # the cache path is relative: ../data/
+    random.seed(3)
+    it = ClusterIter('toy-miss', ds.g, 24, 4, train_nid, device=DEV)
+    cache = tmp_path / 'data' / 'toy-miss_24.npy'
+    assert cache.exists()
+    on_disk = load_partition_cache(str(cache))
+    assert len(on_disk) == 24
+    ids = np.sort(np.concatenate(on_disk))
+    assert np.array_equal(ids, np.arange(train_nid.shape[0]))        # ids of the TRAIN graph
+    random.seed(3)
+    it2 = ClusterIter('toy-miss', ds.g, 24, 4, train_nid, device=DEV)
+    assert all(np.array_equal(a, b) for a, b in zip(it.par_li, it2.par_li))
+    sub = next(iter(it2))
+    assert sub.number_of_nodes() == sum(len(p) for p in it2.par_li[:4])
