@@ -90,7 +90,14 @@ def toy(seed=2, n=2400, n_blocks=24, n_feats=32, n_classes=5, train_frac=0.7):
                               seed=seed, train_frac=train_frac)
 
 
-def load_dataset(name):
+def load_dataset(name, data_root=None):
+    """Real data when `data_root` (or $GIST_DATA_ROOT) holds it (gist_amd/ingest.py), else the
+    seeded synthetic stand-in with the documented statistics."""
+    import os
+    from . import ingest
+    real = ingest.try_load(name, data_root or os.environ.get('GIST_DATA_ROOT'))
+    if real is not None:
+        return real
     if name in ('reddit-synth', 'reddit-self-loop', 'reddit'):
         return reddit_synth(n=232965, train_frac=0.6586)      # 153431 / 232965 like Reddit
     if name in ('amazon-synth', 'amazon2m'):

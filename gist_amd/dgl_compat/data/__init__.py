@@ -4,12 +4,17 @@ from . import utils  # noqa: F401
 
 def register_data_args(parser):
     parser.add_argument('--dataset', type=str, required=False, default='reddit-synth',
-                        help='dataset name (synthetic generators: reddit-synth, amazon-synth, toy)')
+                        help='dataset name: reddit / reddit-self-loop / amazon2m read real files from '
+                             '--data-root (or $GIST_DATA_ROOT) when present; otherwise, and for '
+                             'reddit-synth / amazon-synth / toy, a seeded synthetic stand-in')
+    parser.add_argument('--data-root', type=str, default=None,
+                        help='directory with reddit_data.npz + reddit[_self_loop]_graph.npz, or '
+                             'GraphSAGE-format {name}-G.json/-feats.npy/-id_map.json/-class_map.json')
 
 
 def load_data(args):
     from ...datasets import load_dataset
-    return load_dataset(args.dataset)
+    return load_dataset(args.dataset, getattr(args, 'data_root', None))
 
 
 class DGLDataset(object):
