@@ -203,6 +203,48 @@ def test_gemm_rejects_huge_leading_dimension(hip):
     assert rc < 0 and b'leading dimension' in L.gist_last_error()
 
 
+def test_gemm_random_shapes_all_forms(hip):
+    """60 random (m, n, k) per form, including windows with odd offsets / leading dimensions,
+    against a float64 product: exercises full and ragged tiles, the DMA and the register
+    staging paths, both tile sizes and split-K as the chooser picks them."""
+    rs = np.random.RandomState(123)
+    for it in range(60):
+        m = int(rs.choice([1, 7, 33, 64, 100, 128, 129, 200, 257, 511, 700, 1030]))
+        n = int(rs.choice([1, 5, 41, 64, 96, 128, 130, 300, 513, 1024]))
+        k = int(rs.choice([1, 4, 31, 32, 33, 64, 65, 127, 128, 200, 513, 1204, 2050]))
+        aligned = it % 3 != 0
+        pad = 0 if aligned else int(rs.choice([1, 2, 3]))
+        for form in ('nt', 'nn', 'tn'):
+            if form == 'nt':
+                A, W = rs.randn(m, k + pad), rs.randn(n, k + pad)
+                a, w = dev(A.astype(np.float32))[:, pad:], dev(W.astype(np.float32))[:, pad:]
+                ref = A[:, pad:].astype(np.float32).astype(np.float64) @ W[:, pad:].astype(np.float32).astype(np.float64).T
+            elif form == 'nn':
+                A, W = rs.randn(m, k + pad), rs.randn(k, n + pad)
+                a, w = dev(A.astype(np.float32))[:, pad:], dev(W.astype(np.float32))[:, pad:]
+                ref = A[:, pad:].astype(np.float32).astype(np.float64) @ W[:, pad:].astype(np.float32).astype(np.float64)
+            else:
+                A, W = rs.randn(k, m + pad), rs.randn(k, n + pad)
+                a, w = dev(A.astype(np.float32))[:, pad:], dev(W.astype(np.float32))[:, pad:]
+                ref = A[:, pad:].astype(np.float32).astype(np.float64).T @ W[:, pad:].astype(np.float32).astype(np.float64)
+            ybuf = torch.full((m, n + pad + 1), 9.0, device=DEV)
+            y = ybuf[:, pad:pad + n]
+            bias = None
+            if form == 'nt' and it % 2 == 0:
+                b = rs.randn(n).astype(np.float32)
+                bias = dev(b)
+                ref = ref + b.astype(np.float64)
+            if form == 'nt':
+                hip.gemm_nt(a, w, bias, y)
+            elif form == 'nn':
+                hip.gemm_nn(a, w, y)
+            else:
+                hip.gemm_tn(a, w, y)
+            err = np.abs(y.cpu().numpy().astype(np.float64) - ref).max()
+            assert err <= 3e-6 * np.sqrt(k) * max(1.0, np.abs(ref).max()) + 1e-6, (form, m, n, k, pad, err)
+            assert (ybuf[:, pad + n:] == 9.0).all() and (ybuf[:, :pad] == 9.0).all(), (form, m, n, k, pad)
+
+
 def test_gemm_identity_asymmetric(hip):
     """A = I against an asymmetric B catches a swapped C/D register map."""
     n = 96
