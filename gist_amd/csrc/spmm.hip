@@ -173,12 +173,19 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // 158 VGPRs and ran slower), and the four partial sums are combined through LDS in wave
 // order (deterministic).  A 64-neighbour row costs 2 trips per wave instead of 16; a hub
 // row 11 instead of 83.
-template <int VEC>
+//
+// HALF (VEC = 4 only): d % 4 == 2 with 16-byte aligned source rows but an output that is only
+// 8-byte aligned -- the layer-0 aggregation of F = 602 features inside Z_0 = [h | ah], whose right
+// half starts 2408 bytes into a 4816-byte row.  Sources are still gathered 16 bytes per lane (the
+// last lane of a row reads two floats past d, inside the row pitch, and never stores them);
+// the result leaves as two 8-byte stores.
+template <int VEC, bool HALF = false>
 __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int n_rows, int d, const float *__restrict__ out_scale,
     const float *__restrict__ src_scale, int accumulate, int n_col_tiles, int chunk_rows) {
+    static_assert(!HALF || VEC == 4, "HALF is the 16-byte-load / 8-byte-store variant");
     __shared__ float part[3][kWave * VEC];
     // Row chunks (~ one METIS part: consecutive batch rows whose neighbours are mostly in the
     // same chunk) are dealt to XCDs -- workgroups b, b+8, b+16, ... share an L2 -- so the
@@ -245,16 +252,29 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
             for (int k = 0; k < VEC; ++k) acc[k] += part[w][lane * VEC + k];
         const float os = out_scale ? out_scale[row] : 1.f;
         float *yp = y + (int64_t)row * ldy + c0;
-        float o[VEC];
-        if (accumulate) {
-            vload<VEC>(yp, o);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) o[k] = fmaf(os, acc[k], o[k]);
+        if constexpr (HALF) {
+            const bool upper = c0 + 2 < d;                 // false only for the row's last lane
+            float lo[2] = {0.f, 0.f}, hi[2] = {0.f, 0.f};
+            if (accumulate) {
+                vload<2>(yp, lo);
+                if (upper) vload<2>(yp + 2, hi);
+            }
+            lo[0] = fmaf(os, acc[0], lo[0]); lo[1] = fmaf(os, acc[1], lo[1]);
+            hi[0] = fmaf(os, acc[2], hi[0]); hi[1] = fmaf(os, acc[3], hi[1]);
+            vstore<2>(yp, lo);
+            if (upper) vstore<2>(yp + 2, hi);
         } else {
+            float o[VEC];
+            if (accumulate) {
+                vload<VEC>(yp, o);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
+                for (int k = 0; k < VEC; ++k) o[k] = fmaf(os, acc[k], o[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
+            }
+            vstore<VEC>(yp, o);
         }
-        vstore<VEC>(yp, o);
     }
 }
 
@@ -518,7 +538,7 @@ __global__ void in_degree_norm_kernel(const int32_t *__restrict__ rowptr, int64_
     }
 }
 
-template <int VEC>
+template <int VEC, bool HALF = false>
 static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
                        const float *src_scale, int accumulate, hipStream_t st) {
@@ -536,9 +556,9 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
             set_error("gist_spmm_csr_f32: grid too large");
             return GIST_EINVAL;
         }
-        hipLaunchKernelGGL((spmm_csr_rowsplit_kernel<VEC>), dim3((unsigned)g2), dim3(256), 0, st,
-                           rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale, src_scale,
-                           accumulate, n_col_tiles, chunk_rows);
+        hipLaunchKernelGGL((spmm_csr_rowsplit_kernel<VEC, HALF>), dim3((unsigned)g2), dim3(256), 0,
+                           st, rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,
+                           src_scale, accumulate, n_col_tiles, chunk_rows);
         return launch_status("gist_spmm_csr_f32");
     }
     const int64_t grid = xcd_tiles ? (int64_t)8 * ceil_div(n_col_tiles, 8) * n_row_blocks
@@ -618,6 +638,12 @@ extern "C" int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, cons
     if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
         return launch_spmm<4>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                               accumulate, st);
+    // d = 4q + 2 wide enough for the workgroup-per-row kernel, 16-byte source rows with room
+    // for the last lane's over-read, 8-byte destination: gather 16 bytes per lane anyway
+    if (d % 4 == 2 && d >= 4 * kWave && ldx % 4 == 0 && ldx >= d + 2 && aligned16(x) && ldy % 2 == 0 &&
+        aligned8(y))
+        return launch_spmm<4, true>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                    accumulate, st);
     if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y))
         return launch_spmm<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                               accumulate, st);

@@ -64,7 +64,7 @@ def test_spmm_forward(hip, n, d, deg, hub):
     assert (y[np.diff(rowptr) == 0] == 0).all()       # zero in-degree rows -> exactly 0
 
 
-@pytest.mark.parametrize('n,d', [(64, 10), (300, 602), (700, 256), (1500, 1024)])
+@pytest.mark.parametrize('n,d', [(64, 10), (300, 602), (700, 256), (1500, 1024), (130, 258), (90, 1026)])
 def test_spmm_concat_window_and_backward_form(hip, n, d):
     """x/y as the two halves of one [n, 2d] buffer; backward = src_scale + accumulate."""
     rowptr, col = rand_graph(n, 9, seed=d)
