@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GistLibraryError(RuntimeError):
@@ -38,6 +38,8 @@ SIGNATURES = {
     'gist_partition_graph': (_int, [_p, _p, _p, _p, _i64, _i32, _u64, _i32, _f, _p]),
     'gist_spmm_csr_blocked_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _p]),
     'gist_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'gist_gemm_set_mode': (_int, [_int]),
+    'gist_gemm_get_mode': (_int, []),
     'gist_gemm_nt_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_gemm_nn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_gemm_tn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),

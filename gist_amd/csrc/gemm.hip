@@ -595,6 +595,12 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int64_t slab,
 //           + [splits > 1] * (12 + 6.5 * splits * m*n/1e6)      (slab traffic + reduce launch)
 struct GemmCfg { int tile; int splits; };
 
+// gemm_h3.hip: the f16x3 split path (fp32-accurate products on the f16 matrix cores)
+int h3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda, const float *b,
+            int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+            void *ws, int64_t ws_bytes, hipStream_t st);
+int64_t h3_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
 static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
     const int64_t kt = ceil_div(k, 32);      // the model counts k in units of 32
     // developer override for tuning sweeps (scripts/gemm_sweep.py); not used in production
@@ -673,6 +679,10 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     if (lda >= (1LL << 22) || ldb >= (1LL << 22) || ldc >= (1LL << 22)) {
         set_error("%s: leading dimension >= 2^22 elements", name); return GIST_EINVAL;
     }
+    {   // large, chip-filling shapes: split operands + f16 MFMA (mode 1); 0 = not taken
+        const int rc = h3_gemm(name, A_KC, B_KC, a, lda, b, ldb, bias, c, ldc, m, n, k, ws, ws_bytes, st);
+        if (rc != 0) return rc < 0 ? rc : GIST_OK;
+    }
     GemmArgs g;
     g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.c = c; g.ldc = ldc;
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
@@ -715,6 +725,8 @@ extern "C" int gist_gemm_trace_read(unsigned long long *out, int64_t n_blocks) {
 
 extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int64_t h3 = gist::h3_workspace_bytes(m, n, k);
+    if (h3 > 0) return h3;
     const int s = gist::choose_cfg(m, n, k).splits;
     return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }

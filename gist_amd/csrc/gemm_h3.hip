@@ -1,0 +1,494 @@
+// fp32-accurate GEMM on the f16 matrix cores: every fp32 operand x is split once into two
+// halves, x * 2^e = hi + lo with hi = f16(x 2^e), lo = f16(x 2^e - hi) (22 significant bits, one
+// power-of-two scale per operand ROW so neither half leaves the f16 range), and
+//     (A.B^T)[i][j]  ~=  2^-(ea_i+eb_j) * sum_k (ah.bh + ah.bl + al.bh)   (fp32 accumulation)
+// on v_mfma_f32_32x32x16_f16.  The dropped al.bl term is 2^-22 of a product, below the fp32
+// rounding of the running sum; measured against fp64 the result has the error of the
+// fp32-MFMA kernel (tests/test_gemm_h3_gpu.py).  Three f16 MFMAs replace sixteen fp32-rate
+// MFMA slots: the matrix-core time of a tile drops 5.3x and the kernel becomes bound by the
+// L2 -> LDS staging rate instead.
+//
+// Pre-pass (HBM-bound, per operand): row maxima -> scale exponents; split kernel writes the operand
+// k-contiguous whatever its source layout (the transposed form of NN/TN operands is produced
+// here, so there is ONE GEMM kernel, NT), rows padded with zeros to a multiple of 32 k, in the
+// "chunk-interleaved" layout
+//     row r : [k0..7 hi (16 B)] [k0..7 lo (16 B)] [k8..15 hi] [k8..15 lo] ...
+// i.e. 4 bytes per element like fp32: a 128 x 32-k tile is the same 16 KiB LDS image the
+// fp32 kernel stages (LDS-DMA, buffer_load_dwordx4 ... lds), and one lane's MFMA fragment
+// (8 consecutive k of one row) is one ds_read_b128 for hi and one for lo.
+//
+// LDS image: [128 rows][8 chunks of 16 B]; chunk c of row r sits in slot c ^ ((r >> 1) & 7).
+// ds_read_b128 is served in 16-lane groups that hold rows {0-3,12-15,20-27} / {4-11,16-19,
+// 28-31}; two rows span the 64 banks, so rows of equal parity must differ in (r>>1)&7 -- they
+// do for both groups: conflict free.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace gist {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float h3_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int H3_T = 128;        // block tile edge
+constexpr int H3_BK = 32;        // k per tile = 32-bit words per image row
+constexpr int H3_IMG = H3_T * H3_BK;              // words per image (16 KiB)
+constexpr int H3_BUF_BYTES = 2 * H3_IMG * 4;      // A + B image of one stage
+
+// ---- pre-pass ---------------------------------------------------------------------------
+// One power-of-two scale per ROW of a split operand (= per output row for A, per output column
+// for B): a row's error depends on its own magnitude only, whatever the spread between rows
+// (gradient rows differ by orders of magnitude).
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// x * scale has its largest magnitude in [2^13, 2^14): hi never overflows f16 (65504), lo of
+// every element above 2^-17 of the row maximum is a normal f16, and the representation error
+// of any element is below max(2^-22 |x|, 2^-39 row max).
+__device__ __forceinline__ float h3_scale(unsigned amax_bits, float *inv) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    int shift = amax_bits == 0u ? 0 : 13 - (e - 127);
+    shift = max(-60, min(60, shift));
+    *inv = __uint_as_float((unsigned)(127 - shift) << 23);
+    return __uint_as_float((unsigned)(127 + shift) << 23);
+}
+
+__device__ __forceinline__ void h3_emit(const float (&v)[8], float s, uint32_t *__restrict__ dst) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = v[2 * j] * s, x1 = v[2 * j + 1] * s;
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+        const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+        h[j] = (uint32_t)__builtin_bit_cast(unsigned short, h0) |
+               ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+        l[j] = (uint32_t)__builtin_bit_cast(unsigned short, l0) |
+               ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4 *>(dst + 4) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__device__ __forceinline__ void h3_load8(const float *__restrict__ p, int k0, int k, float (&v)[8]) {
+    if (k0 + 8 <= k) {
+        const float4 a = *reinterpret_cast<const float4 *>(p);
+        const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = k0 + j < k ? p[j] : 0.f;
+    }
+}
+
+// source [rows][k] (k contiguous) -> dst [rows][kpad words] + inv[rows]; one workgroup per row:
+// pass 1 row maximum, pass 2 (the row is L2/L1-hot) split; a thread handles 8 consecutive k.
+__global__ __launch_bounds__(256) void h3_split_rows_kernel(const float *__restrict__ src, int64_t ld,
+                                                            int k, uint32_t *__restrict__ dst,
+                                                            int64_t ldd, float *__restrict__ inv_out) {
+    __shared__ float wmax[4];
+    const int64_t r = blockIdx.x;
+    const float *row = src + r * ld;
+    const int nkb = (int)(ldd >> 3);
+    float m = 0.f;
+    for (int kb = threadIdx.x; kb < nkb; kb += 256) {
+        float v[8];
+        h3_load8(row + kb * 8, kb * 8, k, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float inv;
+    const float s = h3_scale(__float_as_uint(m), &inv);
+    if (threadIdx.x == 0) inv_out[r] = inv;
+    for (int kb = threadIdx.x; kb < nkb; kb += 256) {
+        float v[8];
+        h3_load8(row + kb * 8, kb * 8, k, v);
+        h3_emit(v, s, dst + r * ldd + kb * 8);
+    }
+}
+
+// source [k][cols] (cols contiguous): column maxima.  256 k x 64 cols per block.
+__global__ __launch_bounds__(256) void h3_colmax_kernel(const float *__restrict__ src, int64_t ld,
+                                                        int k, int cols, unsigned *__restrict__ cmax) {
+    __shared__ float part[16][65];
+    const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 256;
+    const int t = threadIdx.x;
+    const int c4 = (t & 15) * 4, kr = t >> 4;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int kk = k0 + kr + 16 * i;
+        if (kk < k) {
+            const float *p = src + (int64_t)kk * ld + c0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + c4 + 3 < cols) {
+                v = *reinterpret_cast<const float4 *>(p);
+            } else {
+                if (c0 + c4 + 0 < cols) v.x = p[0];
+                if (c0 + c4 + 1 < cols) v.y = p[1];
+                if (c0 + c4 + 2 < cols) v.z = p[2];
+            }
+            m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y));
+            m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+        }
+    }
+    part[kr][c4 + 0] = m.x; part[kr][c4 + 1] = m.y; part[kr][c4 + 2] = m.z; part[kr][c4 + 3] = m.w;
+    __syncthreads();
+    if (t < 64 && c0 + t < cols) {
+        float mm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mm = fmaxf(mm, part[i][t]);
+        if (mm > 0.f) atomicMax(cmax + c0 + t, __float_as_uint(mm));
+    }
+}
+
+// source [k][cols] (cols contiguous) -> dst [cols][kpad words] + inv[cols]: 64 k x 64 cols per
+// block through LDS; 8 consecutive lanes write 256 contiguous bytes of one output row.
+__global__ __launch_bounds__(256) void h3_split_t_kernel(const float *__restrict__ src, int64_t ld,
+                                                         int k, int cols, uint32_t *__restrict__ dst,
+                                                         int64_t ldd, const unsigned *__restrict__ cmax,
+                                                         float *__restrict__ inv_out) {
+    __shared__ float tile[64][65];
+    __shared__ float cscale[64];
+    const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+    if (t < 64) {
+        float inv = 1.f;
+        const float s = c0 + t < cols ? h3_scale(cmax[c0 + t], &inv) : 1.f;
+        cscale[t] = s;
+        if (blockIdx.y == 0 && c0 + t < cols) inv_out[c0 + t] = inv;
+    }
+    const int c4 = (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kk = (t >> 4) + 16 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + kk < k) {
+            const float *p = src + (int64_t)(k0 + kk) * ld + c0 + c4;
+            if (c0 + c4 + 3 < cols) {
+                v = *reinterpret_cast<const float4 *>(p);
+            } else {
+                if (c0 + c4 + 0 < cols) v.x = p[0];
+                if (c0 + c4 + 1 < cols) v.y = p[1];
+                if (c0 + c4 + 2 < cols) v.z = p[2];
+            }
+        }
+        tile[kk][c4 + 0] = v.x; tile[kk][c4 + 1] = v.y;
+        tile[kk][c4 + 2] = v.z; tile[kk][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    const int kb = t & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (t >> 3) + 32 * i;
+        if (c0 + c < cols && k0 + kb * 8 < (int)ldd) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[kb * 8 + j][c];
+            h3_emit(v, cscale[c], dst + (int64_t)(c0 + c) * ldd + k0 + kb * 8);
+        }
+    }
+}
+
+// ---- the GEMM -----------------------------------------------------------------------------
+struct H3Args {
+    const uint32_t *a; int64_t lda;      // split operands, [rows][kpad] 32-bit words
+    const uint32_t *b; int64_t ldb;
+    const float *inv_a, *inv_b;          // [m], [n]: 2^-e per row of A / of B (split kernels)
+    const float *bias;
+    float *c; int64_t ldc;
+    int m, n, kpad;
+    int tiles_m, tiles_n;
+};
+
+// 4 LDS-DMA instructions per wave fill one 16 KiB image: instruction j = 4*wave + jj writes LDS
+// bytes [1024 j, 1024 (j+1)); the lane's source is the chunk that belongs at its 16 bytes.
+__device__ __forceinline__ void h3_dma_offsets(int64_t ld, int rows, int row0, int wave, int lane,
+                                               uint32_t (&off)[4]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int p = 64 * (4 * wave + jj) + lane;
+        const int r = p >> 3, slot = p & 7;
+        const int dr = min(r, rows - 1 - row0);     // rows beyond the operand: re-read the last one
+        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ ((r >> 1) & 7)) << 2)) * 4);
+    }
+}
+
+__device__ __forceinline__ void h3_dma_image(const uint32_t *ubase, const uint32_t (&off)[4],
+                                             char *image, int wave) {
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(ubase), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void *)(image + (4 * wave + jj) * 1024), 16,
+            off[jj], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char h3_smem[];
+    constexpr int T = H3_T;
+
+    // block -> output tile, 8-row super-tiles per XCD (as the fp32 kernel)
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int orig = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    constexpr int GM = 8;
+    const int width = GM * g.tiles_n;
+    const int group = L / width;
+    const int first_m = group * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int bm = first_m + (L % width) % gsz;
+    const int bn = (L % width) / gsz;
+    const int row0 = bm * T, col0 = bn * T;
+    const int n_kt = g.kpad / H3_BK;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+
+    h3_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint32_t offA[4], offB[4];
+    h3_dma_offsets(g.lda, g.m, row0, wave, lane, offA);
+    h3_dma_offsets(g.ldb, g.n, col0, wave, lane, offB);
+    const uint32_t *originA = g.a + (int64_t)row0 * g.lda;
+    const uint32_t *originB = g.b + (int64_t)col0 * g.ldb;
+    auto dma = [&](int buf, int kt) {
+        char *sa = h3_smem + buf * H3_BUF_BYTES;
+        h3_dma_image(originA + (int64_t)kt * H3_BK, offA, sa, wave);
+        h3_dma_image(originB + (int64_t)kt * H3_BK, offB, sa + H3_IMG * 4, wave);
+    };
+
+    // fragment byte offsets inside an image: [slab][k16 step][hi/lo]
+    int fa[2][2][2], fb[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ar = wm * 64 + i * 32 + r, br = wn * 64 + i * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int lo = 0; lo < 2; ++lo) {
+                const int c = 4 * s + 2 * hh + lo;
+                fa[i][s][lo] = ar * 128 + ((c ^ ((ar >> 1) & 7)) << 4);
+                fb[i][s][lo] = br * 128 + ((c ^ ((br >> 1) & 7)) << 4) + H3_IMG * 4;
+            }
+    }
+
+    if (n_kt > 0) dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): the DMA has landed
+    __syncthreads();
+
+    auto kstep = [&](auto cur_c, auto next_c, int kt) {
+        constexpr int cur = decltype(cur_c)::value;
+        constexpr bool has_next = decltype(next_c)::value != 0;
+        if constexpr (has_next) dma(cur ^ 1, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *img = h3_smem + cur * H3_BUF_BYTES;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][s][0]);
+                bh[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][s][0]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bl[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][s][1]);
+                al[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][s][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (has_next) __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    };
+    {
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        int kt = 0;
+        for (; kt + 2 < n_kt; kt += 2) {
+            kstep(C0{}, C1{}, kt);
+            kstep(C1{}, C1{}, kt + 1);
+        }
+        for (; kt < n_kt; ++kt) {
+            const bool nx = kt + 1 < n_kt;
+            if ((kt & 1) == 0) { if (nx) kstep(C0{}, C1{}, kt); else kstep(C0{}, C0{}, kt); }
+            else               { if (nx) kstep(C1{}, C1{}, kt); else kstep(C1{}, C0{}, kt); }
+        }
+    }
+
+    // ---- epilogue: undo the operand scales, bias, raw buffer stores (as the fp32 kernel) ----
+    float *cbase = g.c + (int64_t)row0 * g.ldc + col0;
+    const int rows_valid = min(g.m - row0, T);
+    __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+        cbase, 0, (int)((int64_t)rows_valid * g.ldc * 4), 0x00020000);
+    const uint32_t ldc_b = (uint32_t)g.ldc * 4;
+    uint32_t cvoff[2];
+    float bv[2], sb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cl = wn * 64 + j * 32 + r;
+        const bool ok = col0 + cl < g.n;
+        cvoff[j] = ok ? (uint32_t)(wm * 64 + 4 * hh) * ldc_b + (uint32_t)cl * 4 : 0x7fffffffu;
+        bv[j] = (g.bias != nullptr && ok) ? g.bias[col0 + cl] : 0.f;
+        sb[j] = ok ? g.inv_b[col0 + cl] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rl = i * 32 + (e & 3) + 8 * (e >> 2);             // uniform part of the row
+            const uint32_t roff = (uint32_t)rl * ldc_b;
+            const int grow = min(row0 + wm * 64 + 4 * hh + rl, g.m - 1);
+            const float sa = g.inv_a[grow];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float v = fmaf(acc[i][j][e] * sa, sb[j], bv[j]);
+                if (rows_valid == T)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j], roff, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j] + roff, 0, 0);
+            }
+        }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static int g_h3_mode = -1;      // -1: read GIST_GEMM_MODE on first use
+
+int h3_mode() {
+    if (g_h3_mode < 0) {
+        const char *e = getenv("GIST_GEMM_MODE");
+        g_h3_mode = 1;
+        if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) g_h3_mode = 0;
+        else if (e && (!strcmp(e, "f16x3") || !strcmp(e, "1"))) g_h3_mode = 1;
+    }
+    return g_h3_mode;
+}
+
+static inline int64_t h3_kpad(int64_t k) { return ceil_div(k, H3_BK) * H3_BK; }
+
+// Shapes the split path takes: enough 128x128 tiles to occupy the chip and enough flops to
+// pay for the pre-pass (measured break-even ~20 GFLOP, scripts/h3_bench.py).  Everything else
+// stays on the fp32 kernel.
+bool h3_eligible(int64_t m, int64_t n, int64_t k) {
+    if (h3_mode() != 1) return false;
+    const double min_gflop = getenv("GIST_H3_MIN_GFLOP") ? atof(getenv("GIST_H3_MIN_GFLOP")) : 16.0;
+    const int min_tiles = getenv("GIST_H3_MIN_TILES") ? atoi(getenv("GIST_H3_MIN_TILES")) : 64;
+    if (m < 64 || n < 64 || k < 64) return false;
+    if (ceil_div(m, H3_T) * ceil_div(n, H3_T) < min_tiles) return false;
+    if (2.0 * (double)m * (double)n * (double)k < min_gflop * 1e9) return false;
+    if (h3_kpad(k) >= (1LL << 22)) return false;
+    return true;
+}
+
+// workspace: [inv_a: m floats][inv_b: n floats][max bits: m + n] padded to 256 B, then the splits
+static inline int64_t h3_head_bytes(int64_t m, int64_t n) { return ceil_div((m + n) * 8, 256) * 256; }
+
+int64_t h3_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    if (!h3_eligible(m, n, k)) return 0;
+    return h3_head_bytes(m, n) + (m + n) * h3_kpad(k) * 4;
+}
+
+// A: a_kc ? [m][k] : [k][m];  B: b_kc ? [n][k] : [k][n].  Returns 1 if the GEMM was issued,
+// 0 if this call is not for the split path (caller falls back to fp32), < 0 on error.
+int h3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda, const float *b,
+            int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+            void *ws, int64_t ws_bytes, hipStream_t st) {
+    if (!h3_eligible(m, n, k)) return 0;
+    if (!(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0)) return 0;
+    if (ws == nullptr || !aligned16(ws) || ws_bytes < h3_workspace_bytes(m, n, k)) return 0;
+    const int64_t kpad = h3_kpad(k);
+    float *inv_a = static_cast<float *>(ws), *inv_b = inv_a + m;
+    unsigned *max_a = reinterpret_cast<unsigned *>(inv_b + n), *max_b = max_a + m;
+    uint32_t *sa = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + h3_head_bytes(m, n));
+    uint32_t *sb = sa + m * kpad;
+    if ((!a_kc || !b_kc) && hipMemsetAsync(max_a, 0, (size_t)(m + n) * 4, st) != hipSuccess) {
+        set_error("%s: hipMemsetAsync failed", name);
+        return GIST_ELAUNCH;
+    }
+    // k-contiguous source [rows][k]: one fused kernel; [k][rows] source: column maxima, then the
+    // transposing split
+    auto split = [&](bool kc, const float *src, int64_t ld, int64_t rows, uint32_t *dst,
+                     unsigned *mx, float *iv) {
+        if (kc) {
+            hipLaunchKernelGGL(h3_split_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, src, ld,
+                               (int)k, dst, kpad, iv);
+        } else {
+            hipLaunchKernelGGL(h3_colmax_kernel,
+                               dim3((unsigned)ceil_div(rows, 64), (unsigned)ceil_div(k, 256)),
+                               dim3(256), 0, st, src, ld, (int)k, (int)rows, mx);
+            hipLaunchKernelGGL(h3_split_t_kernel,
+                               dim3((unsigned)ceil_div(rows, 64), (unsigned)ceil_div(kpad, 64)),
+                               dim3(256), 0, st, src, ld, (int)k, (int)rows, dst, kpad, mx, iv);
+        }
+    };
+    split(a_kc, a, lda, m, sa, max_a, inv_a);
+    split(b_kc, b, ldb, n, sb, max_b, inv_b);
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * H3_BUF_BYTES);
+        if (e != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return GIST_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    H3Args g;
+    g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.inv_a = inv_a; g.inv_b = inv_b; g.bias = bias;
+    g.c = c; g.ldc = ldc; g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
+    g.tiles_m = (int)ceil_div(m, H3_T);
+    g.tiles_n = (int)ceil_div(n, H3_T);
+    hipLaunchKernelGGL(gemm_h3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256),
+                       2 * H3_BUF_BYTES, st, g);
+    const int rc = launch_status(name);
+    return rc == GIST_OK ? 1 : rc;
+}
+
+}  // namespace gist
+
+extern "C" int gist_gemm_set_mode(int mode) {
+    GIST_REQUIRE(mode == 0 || mode == 1, "gist_gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (f16x3 split)");
+    gist::g_h3_mode = mode;
+    return GIST_OK;
+}
+
+extern "C" int gist_gemm_get_mode(void) { return gist::h3_mode(); }

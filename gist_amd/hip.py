@@ -162,6 +162,19 @@ def _ws_for(m, n, k, device):
     return w.data_ptr(), w.numel()
 
 
+def gemm_mode(mode=None):
+    """Get (and with an argument, set) how large projections form their products:
+    'f32' = v_mfma_f32_32x32x2_f32 everywhere, 'f16x3' = split operands on the f16 matrix cores
+    (fp32-level accuracy, include/gist_hip.h gist_gemm_set_mode).  Process-wide."""
+    L = _lib.load()
+    if mode is not None:
+        code = {'f32': 0, 'f16x3': 1, 0: 0, 1: 1}.get(mode)
+        if code is None:
+            raise ValueError("gist_amd: gemm mode must be 'f32' or 'f16x3'")
+        _lib.check(L.gist_gemm_set_mode(code), 'gist_gemm_set_mode')
+    return 'f16x3' if L.gist_gemm_get_mode() == 1 else 'f32'
+
+
 def gemm_nt(a, w, bias, y):
     """y = a @ w.T + bias"""
     L = _lib.load()

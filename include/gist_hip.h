@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 3 */
+int gist_abi_version(void);   /* currently 4 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -127,6 +127,19 @@ int gist_gemm_nn_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
 int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
                      float *d, int64_t ldd, int64_t m, int64_t n, int64_t k,
                      void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
+/* How the three entry points above form their products on shapes large enough to fill the
+ * chip (>= 64 output tiles of 128x128, >= 16 GFLOP, 16-byte aligned operands, workspace of
+ * gist_gemm_workspace_bytes): mode 1 (default; GIST_GEMM_MODE=f16x3) splits each fp32 operand
+ * once into two f16 halves under one power-of-two scale per operand (22 significant bits)
+ * and accumulates ah.bh + ah.bl + al.bh in fp32 on v_mfma_f32_32x32x16_f16 -- fp32-level
+ * accuracy (error against fp64 equal to mode 0's, tests/test_gemm_h3_gpu.py) at 1/5 of the
+ * matrix-core time; mode 0 (GIST_GEMM_MODE=f32) keeps every shape on v_mfma_f32_32x32x2_f32.
+ * Inputs and outputs are fp32 in both modes; small and skinny shapes always take mode 0's
+ * kernel.  Process-wide; set it before sizing workspaces.  Both replace the same call,
+ * self.linear(h), cluster_gcn/modules.py:233, and its autograd. */
+int gist_gemm_set_mode(int mode);
+int gist_gemm_get_mode(void);
 
 /* ---------------------------------------------------------------------------
  * Row-wise epilogues of one ISTSAGELayer

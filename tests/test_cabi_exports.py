@@ -36,8 +36,18 @@ def test_host_only_entry_points():
     L = _lib.load()
     assert L.gist_abi_version() == _lib.ABI_VERSION
     assert L.gist_gemm_workspace_bytes(0, 5, 5) == 0
+    prev = L.gist_gemm_get_mode()
+    assert L.gist_gemm_set_mode(0) == 0                                # fp32 MFMA everywhere
     assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) == 0          # enough tiles
     assert L.gist_gemm_workspace_bytes(2046, 41, 8192) > 0             # split-K
+    assert L.gist_gemm_set_mode(1) == 0                                # f16x3 split on large shapes
+    kpad = 8192
+    assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) == 49152 + (2046 + 4096) * kpad * 4
+    assert L.gist_gemm_workspace_bytes(2046, 4096, 1204) == 49152 + (2046 + 4096) * 1216 * 4
+    assert L.gist_gemm_workspace_bytes(2046, 41, 8192) > 0             # skinny: fp32 split-K
+    assert L.gist_gemm_workspace_bytes(2046, 41, 8192) < 64 << 20
+    assert L.gist_gemm_set_mode(7) == -1 and b'mode' in L.gist_last_error()
+    assert L.gist_gemm_set_mode(prev) == 0
     assert L.gist_colsum_partials(0) == 0 and L.gist_colsum_partials(129) == 3
     # argument validation happens before any device work
     assert L.gist_spmm_csr_f32(None, None, None, 4, None, 4, 3, 4, None, None, 0, None) == -1

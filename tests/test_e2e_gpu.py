@@ -395,6 +395,138 @@ def test_config4_amazon_like_F100_C47_L4():
     _check(*_steps_vs_oracle(ds, 10, 512, 4, 3, p_seed=2))
 
 
+def _metric_config_engine(mode):
+    """Engine + first batches of the configuration the metric is quoted on (Reddit-like batch,
+    n_hidden=4096, L=2, full width on one GPU), projections in the given GEMM mode."""
+    from gist_amd import datasets, hip, _lib
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+    hip.gemm_mode(mode)
+    ds = datasets.reddit_synth(seed=0)
+    g = ds.g
+    random.seed(3)
+    it = EngineClusterIter(ds.name, g, len(ds.par_li), 20,
+                           np.arange(g.number_of_nodes(), dtype=np.int64),
+                           par_li=[p.copy() for p in ds.par_li], device=DEV)
+    dims = dims_for(602, 4096, 41, 2)
+    eng = SageEngine(dims, True, 0.0, it.n_max, DEV)
+    big = _lib.load().gist_gemm_workspace_bytes(it.n_max, 4096, 8192)
+    assert (big > (1 << 27)) == (mode == 'f16x3')      # the step really runs on the split path
+    rs = np.random.RandomState(3)
+    params = []
+    for (i, o) in dims:
+        sc = 1.0 / np.sqrt(2 * i)
+        params.append((rs.uniform(-sc, sc, (o, 2 * i)).astype(np.float32),
+                       rs.uniform(-sc, sc, o).astype(np.float32)))
+    eng.arena.load(params)
+    return ds, it, eng, dims, params
+
+
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+def test_metric_config_hidden4096_vs_oracle(mode):
+    """Metric configuration, 2 full training steps against the oracle on the same batches, with
+    the projections on the fp32 matrix-core path and on the f16x3 split path (every GEMM of
+    this step but the 41-wide class layer takes it): the same 1e-4 bar on the outputs for both
+    (gradients at this width are compared against float64 in the next test: a ReLU input at
+    rounding level flips its mask in any fp32 implementation, the oracle's included)."""
+    from gist_amd import hip
+    from oracle import gist_oracle as O
+    from oracle import train_oracle as TO
+    prev = hip.gemm_mode()
+    try:
+        ds, it, eng, dims, params = _metric_config_engine(mode)
+        it.bind(eng)
+        g = ds.g
+        tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
+                           g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
+        opt = O.new_opt_state(params)
+        for j, batch in enumerate(it):
+            loss = eng.train_step(batch, 0.01, 0.0)
+            logits = eng.logits(batch.n).cpu().numpy()
+            b = tg.batch(it.batch_ids(j))
+            ref_loss, ref_logits, _ = O.train_step(b[0], b[1], b[2], b[3], b[4], b[5], params, opt,
+                                                   True, 0.01)
+            assert abs(float(loss.item()) - float(ref_loss)) < TOL, (j, float(loss.item()), ref_loss)
+            if j == 0:
+                assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max())
+            if j == 1:
+                break
+        errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in
+                               zip(eng.arena.export(), params)])
+        assert float(errs.mean()) < 1e-5 and float((errs > TOL).mean()) < 2e-2, \
+            (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
+    finally:
+        hip.gemm_mode(prev)
+
+
+def _float64_step(rowptr, col, feat, labels, params, masks):
+    """float64 autograd evaluation of one forward/backward of the model on
+    the device, dense normalised adjacency; masks[k] (bool [n, H]) replaces relu's own mask so
+    that the comparison does not depend on the sign of rounding-level activations."""
+    import torch.nn.functional as F
+    n = len(rowptr) - 1
+    A = torch.zeros(n, n, dtype=torch.float64, device=DEV)
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV),
+                                   torch.from_numpy(np.diff(rowptr)).to(DEV))
+    A.index_put_((rows, torch.from_numpy(col).to(DEV)),
+                 torch.ones(len(col), dtype=torch.float64, device=DEV), accumulate=True)
+    deg = A.sum(1, keepdim=True)
+    A = torch.where(deg > 0, A / deg.clamp(min=1), torch.zeros_like(A))
+    ps = [(torch.from_numpy(W).to(DEV).double().requires_grad_(),
+           torch.from_numpy(b).to(DEV).double().requires_grad_()) for W, b in params]
+    h = torch.from_numpy(feat).to(DEV).double()
+    yhats = []
+    for k, (W, b) in enumerate(ps):
+        y = torch.cat([h, A @ h], 1) @ W.t() + b
+        if k + 1 < len(ps):
+            y = F.layer_norm(y, (y.shape[1],), eps=1e-5)
+            yhats.append(y.detach())
+            h = y * masks[k]
+    loss = F.cross_entropy(y, torch.from_numpy(labels).to(DEV).long())
+    loss.backward()
+    return loss.item(), y.detach(), [(W.grad, b.grad) for W, b in ps], yhats
+
+
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+def test_metric_config_hidden4096_vs_float64(mode):
+    """Metric configuration, one forward/backward against float64 autograd on the same batch.
+    Both GEMM modes must reproduce the float64 activations, logits, loss and every gradient to
+    fp32 rounding level; the handful of ReLU inputs within rounding of zero (their count is
+    bounded here) take the GPU's own mask in the reference."""
+    from gist_amd import hip
+    from oracle import train_oracle as TO
+    prev = hip.gemm_mode()
+    try:
+        ds, it, eng, dims, params = _metric_config_engine(mode)
+        it.bind(eng, native=False)
+        g = ds.g
+        tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
+                           g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
+        batch = next(iter(it))
+        n = batch.n
+        b = tg.batch(it.batch_ids(0))
+        eng.forward(batch, True)
+        yh = [eng.Y[k][:n].clone() for k in range(2)]
+        masks = [(t > 0).double() for t in yh]
+        l64, y64, g64, yh64 = _float64_step(b[0], b[1], b[4], b[5], params, masks)
+        for k in range(2):
+            d = (yh[k].double() - yh64[k])
+            assert d.pow(2).mean().sqrt().item() < 5e-6, (k, d.pow(2).mean().sqrt().item())
+            assert d.abs().max().item() < 1e-4
+            flips = int(((yh[k] > 0) != (yh64[k] > 0)).sum().item())
+            assert flips <= 40, (k, flips)              # of 8.4 M activations
+        loss = eng.loss_and_backward(batch)
+        assert abs(loss.item() - l64) < 1e-5
+        assert (eng.logits(n).double() - y64).abs().max().item() < TOL * max(1.0, y64.abs().max().item())
+        for k in range(len(dims)):
+            for got, ref in ((eng.arena.dW[k], g64[k][0]), (eng.arena.db[k], g64[k][1])):
+                rel = (torch.linalg.norm(got.double() - ref) / torch.linalg.norm(ref)).item()
+                assert rel < 2e-5, (k, tuple(got.shape), rel)
+                assert (got.double() - ref).abs().max().item() <= TOL * ref.abs().max().item()
+    finally:
+        hip.gemm_mode(prev)
+
+
 def test_cluster_iter_partitions_on_cache_miss(tmp_path, monkeypatch):
     """sampler.py:44-53: without a cache file ClusterIter partitions the train graph itself
     (here: gist_partition_graph instead of METIS), writes the reference's .npy format and
