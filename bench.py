@@ -19,7 +19,14 @@ batch, plus the sync/dispatch work that falls on that iteration.  An epoch = 75 
 under GIST every rank trains n_epochs/S epochs (cluster_gcn_ist_distrib.py:385), so the
 job's throughput is the SUM of the ranks' epochs/sec ("weak": per-GPU batch stream fixed).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fp32-MFMA GEMM),
+Projections: fp32 in, fp32 out, fp32 accumulation.  By default (--gemm-mode f16x3) every
+projection >= 16 GFLOP forms its products as 3 f16-split terms on v_mfma_f32_32x32x16_f16
+(gist_amd/csrc/gemm_h3.hip; error against float64 equal to or below the fp32-MFMA kernel's,
+tests/test_gemm_h3_gpu.py, tests/test_e2e_gpu.py); --gemm-mode f32 keeps all of them on
+v_mfma_f32_32x32x2_f32.  At N=1 the line also carries `f32_mfma`: the same workload re-timed
+in mode f32 in the same process.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the projection GEMM),
 `roofline_spmm` (the SpMM against HBM), `cpu_baseline` (the oracle timed on host cores).
 """
 import argparse
@@ -36,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 STEPS_PER_EPOCH = 75
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
+MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA, dense
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 
 
@@ -48,6 +56,11 @@ def parse():
     ap.add_argument('--n-layers', type=int, default=2)
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--iter-per-site', type=int, default=100)
+    ap.add_argument('--gemm-mode', choices=['f16x3', 'f32'], default='f16x3',
+                    help='products of the large projections: 3-term f16 split on the f16 matrix '
+                         'cores (fp32-level accuracy) or v_mfma_f32_32x32x2_f32')
+    ap.add_argument('--no-f32-rerun', action='store_true',
+                    help='N=1, mode f16x3: skip re-timing the workload in mode f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-timing', action='store_true',
@@ -135,6 +148,7 @@ def main():
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
 
+    hip.gemm_mode(args.gemm_mode)       # before any workspace is sized
     seed = 0
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -241,7 +255,7 @@ def main():
     if timing:
         if native:          # HIP events recorded by the native step driver on the launch stream
             sample_timer = engine.enable_timer(
-                (args.steps // max(args.timing_every, 1) + 1) * (5 * len(dims) + 2))
+                (args.steps // max(args.timing_every, 1) + 1) * (8 * len(dims) + 2))
         else:
             hip.profile_begin()
     t0 = time.time()
@@ -252,6 +266,7 @@ def main():
     if timing and native:
         rec = engine.read_timer()
         prof = {'gemm': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 1],
+                'h3': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 2],
                 'spmm': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 0]}
         engine.disable_timer()
     elif timing:
@@ -263,6 +278,24 @@ def main():
     elapsed = float(el.item())
     loss_val = float(engine.loss.item())
 
+    # the same workload on the fp32 matrix-core path, same process (workspaces stay sized for
+    # the split path, which is a superset)
+    f32_rerun = None
+    if world == 1 and args.gemm_mode == 'f16x3' and not args.no_f32_rerun:
+        hip.gemm_mode('f32')
+        engine.plan.timer = None
+        n_re = max(args.steps // 3, 10)
+        run_steps(3)
+        fence()
+        t1 = time.time()
+        run_steps(n_re)
+        fence()
+        e1 = time.time() - t1
+        f32_rerun = {'value': round(n_re / STEPS_PER_EPOCH / e1, 4), 'unit': 'epochs/s',
+                     'ms_per_step': round(e1 / n_re * 1e3, 4), 'steps': n_re,
+                     'gemm': 'every projection on v_mfma_f32_32x32x2_f32 (--gemm-mode f32)'}
+        hip.gemm_mode('f16x3')
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # every rank runs `steps` iterations of its own sub-GCN: S * steps / 75 epochs of work
@@ -271,7 +304,12 @@ def main():
             'metric': 'epochs/sec', 'value': round(value, 4), 'unit': 'epochs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32' if args.gemm_mode == 'f32' else
+                     'f32 (storage, accumulation, all non-GEMM kernels; projection products as 3 '
+                     'f16-split terms on the f16 matrix cores, error vs float64 <= the fp32-MFMA '
+                     "kernel's)",
+            'data': 'synthetic',
             'config': {
                 'workload': 'Reddit-like synthetic (N_train=153431, F=602, C=41, 1500 parts, '
                             'batch=20 parts, 75 steps/epoch); GraphSAGE n_hidden=%d n_layers=%d '
@@ -299,15 +337,52 @@ def main():
             g_ms = sum(ms for ms, _ in gem)
             g_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in gem)
             ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-            out['roofline'] = {
-                'kernel': 'gist::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; NT/NN/TN)',
-                'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                'traffic': None, 'launches': len(gem),
-                'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
-                'avg_launch_ms': round(g_ms / max(len(gem), 1), 5),
-                'share_of_step': round(g_ms * (args.timing_every if native else 1) / (elapsed * 1e3), 4),
-            }
+            every = args.timing_every if native else 1
+            h3 = prof.get('h3', [])
+            if h3:
+                # dominant kernel: the split GEMM's main kernel, bracketed on its own.  achieved =
+                # ALGORITHMIC flops (2mnk) / its time; it executes 3 f16 MFMA flops per
+                # algorithmic flop, so its ceiling is the dense f16 peak / 3.
+                h_ms = sum(ms for ms, _ in h3)
+                h_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in h3)
+                h_ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+                out['roofline'] = {
+                    'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_32x32x16_f16, 3 MFMA flops per '
+                              'algorithmic flop: ah.bh + ah.bl + al.bh)',
+                    'bound': 'mfma', 'achieved': round(h_ach, 3), 'peak': MFMA_F16_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(h_ach / MFMA_F16_PEAK_TFLOPS, 4),
+                    'mfma_flops_per_algorithmic_flop': 3,
+                    'mfma_rate_tflops': round(3 * h_ach, 1),
+                    'frac_mfma_rate_of_peak': round(3 * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
+                    'traffic': None, 'launches': len(h3),
+                    'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
+                    'avg_launch_ms': round(h_ms / max(len(h3), 1), 5),
+                    'share_of_step': round(h_ms * every / (elapsed * 1e3), 4),
+                    # every projection call of the step: split pre-pass + main kernel, and the
+                    # class-layer GEMMs that stay on gist::gemm_f32_kernel
+                    'all_projection_calls': {
+                        'achieved': round(ach, 3), 'unit': 'TFLOP/s (algorithmic)',
+                        'vs_f32_mfma_peak': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                        'calls': len(gem), 'avg_call_ms': round(g_ms / max(len(gem), 1), 5),
+                        'share_of_step': round(g_ms * every / (elapsed * 1e3), 4),
+                        'split_prepass_share_of_step': round(
+                            (sum(ms for ms, (_, m, n, k) in gem
+                                 if any((m, n, k) == s[1:] for _, s in h3)) - h_ms)
+                            * every / (elapsed * 1e3), 4),
+                    },
+                }
+            else:
+                out['roofline'] = {
+                    'kernel': 'gist::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; NT/NN/TN)',
+                    'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    'traffic': None, 'launches': len(gem),
+                    'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
+                    'avg_launch_ms': round(g_ms / max(len(gem), 1), 5),
+                    'share_of_step': round(g_ms * every / (elapsed * 1e3), 4),
+                }
+            if f32_rerun is not None:
+                out['f32_mfma'] = f32_rerun
             sp = prof['spmm']
             per_step = 2 * len(dims) - 1                 # SpMM launches per instrumented step
             stride = args.timing_every if native else 1  # which timed step a record belongs to

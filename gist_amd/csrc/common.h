@@ -32,6 +32,13 @@ static inline int launch_status(const char *what) {
         }                                  \
     } while (0)
 
+// HIP-event timer of the native step driver (step.hip).  While gist_sage_step runs with a timer
+// armed, tl_timer points at it so that a kernel below an entry point (the split GEMM's main
+// kernel) can be bracketed on its own: slot = timer_begin(...); launch; timer_end(slot).
+extern thread_local gist_timer *tl_timer;
+int64_t timer_begin(gist_timer *t, int kind, int64_t m, int64_t n, int64_t k, hipStream_t s);
+void timer_end(gist_timer *t, int64_t slot, hipStream_t s);
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -74,17 +74,32 @@ extern "C" int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kin
     return GIST_OK;
 }
 
+namespace gist {
+thread_local gist_timer *tl_timer = nullptr;
+
+int64_t timer_begin(gist_timer *t, int kind, int64_t m, int64_t n, int64_t k, hipStream_t s) {
+    if (!t || t->count >= t->capacity) return -1;
+    const int64_t slot = t->count++;
+    t->kind[slot] = kind; t->m[slot] = m; t->n[slot] = n; t->k[slot] = k;
+    (void)hipEventRecord(t->start[slot], s);
+    return slot;
+}
+
+void timer_end(gist_timer *t, int64_t slot, hipStream_t s) {
+    if (t && slot >= 0) (void)hipEventRecord(t->stop[slot], s);
+}
+}  // namespace gist
+
 namespace {
 struct Scope {   // records start now, stop at scope exit
     gist_timer *t; int64_t slot; hipStream_t s;
-    Scope(gist_timer *t_, int kind, int64_t m, int64_t n, int64_t k, hipStream_t s_) : t(t_), slot(-1), s(s_) {
-        if (t && t->count < t->capacity) {
-            slot = t->count++;
-            t->kind[slot] = kind; t->m[slot] = m; t->n[slot] = n; t->k[slot] = k;
-            (void)hipEventRecord(t->start[slot], s);
-        }
-    }
-    ~Scope() { if (slot >= 0) (void)hipEventRecord(t->stop[slot], s); }
+    Scope(gist_timer *t_, int kind, int64_t m, int64_t n, int64_t k, hipStream_t s_)
+        : t(t_), slot(timer_begin(t_, kind, m, n, k, s_)), s(s_) {}
+    ~Scope() { timer_end(t, slot, s); }
+};
+struct ActiveTimer {   // kernels below the entry points see the armed timer for this call only
+    explicit ActiveTimer(gist_timer *t) { tl_timer = t; }
+    ~ActiveTimer() { tl_timer = nullptr; }
 };
 }  // namespace
 
@@ -97,6 +112,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     GIST_REQUIRE(n > 0, "gist_sage_step: empty batch");
     const int L1 = p->n_layers;
     hipStream_t st = as_stream(s);
+    ActiveTimer active(p->timer);
     const bool train = (flags & GIST_STEP_TRAIN) != 0;
     const bool drop = train && p->p_drop > 0.f;
 

@@ -323,7 +323,9 @@ typedef struct gist_step_plan {
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream by the step
  * driver around every SpMM and GEMM call (what bench.py's `roofline` is computed from).
- * kind: 0 = SpMM (m = rows, n = source rows, k = width), 1 = GEMM (m, n, k). */
+ * kind: 0 = SpMM (m = rows, n = source rows, k = width), 1 = GEMM call (m, n, k; in mode 1 it
+ * includes the split pre-pass), 2 = the split GEMM's main kernel alone (nested in a kind-1
+ * record). */
 typedef struct gist_timer gist_timer;
 gist_timer *gist_timer_create(int64_t capacity);
 void gist_timer_destroy(gist_timer *t);

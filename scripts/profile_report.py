@@ -11,13 +11,18 @@ title = sys.argv[3]
 print('# rocprofv3 --kernel-trace --stats: %s\n' % title)
 print('bench line of the profiled run:\n\n```\n%s\n```\n' % line)
 print('| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|')
-gemm_calls = gemm_ns = spmm_calls = spmm_ns = 0
+gemm_calls = gemm_ns = spmm_calls = spmm_ns = h3_calls = h3_ns = pre_ns = 0
 for r in rows:
     name, calls, tot = r['Name'], int(r['Calls']), float(r['TotalDurationNs'])
-    if 'gemm_f32' in name or 'splitk_reduce' in name:
+    if 'gemm_f32' in name or 'splitk_reduce' in name or 'gemm_h3' in name or 'h3_' in name:
         gemm_ns += tot
-        if 'gemm_f32' in name:
+        if 'gemm_f32' in name or 'gemm_h3' in name:
             gemm_calls += calls
+    if 'gemm_h3_kernel' in name:
+        h3_calls += calls
+        h3_ns += tot
+    elif 'h3_' in name:
+        pre_ns += tot
     if 'spmm_csr' in name:
         spmm_calls += calls
         spmm_ns += tot
@@ -27,10 +32,16 @@ for r in rows:
                                                   float(r['Percentage'])))
 d = json.loads(line)
 print()
-print('GEMM (all layouts/tiles + split-K reduce): %d GEMM launches, %.3f ms total, %.4f ms average per '
-      'GEMM call -- compare `roofline.avg_launch_ms` = %s of the bench line (native HIP-event timer, '
-      'sampled).' % (gemm_calls, gemm_ns / 1e6, gemm_ns / 1e6 / max(gemm_calls, 1),
-                     d.get('roofline', {}).get('avg_launch_ms')))
+print('GEMM (all layouts/tiles + split-K reduce + split pre-pass): %d GEMM launches, %.3f ms total, %.4f ms average per '
+      'GEMM call -- compare the bench line\'s per-call figure %s (native HIP-event timer, sampled).'
+      % (gemm_calls, gemm_ns / 1e6, gemm_ns / 1e6 / max(gemm_calls, 1),
+         d.get('roofline', {}).get('all_projection_calls', {}).get('avg_call_ms',
+                                                                   d.get('roofline', {}).get('avg_launch_ms'))))
+if h3_calls:
+    print('Split GEMM main kernel (gist::gemm_h3_kernel): %d launches, %.3f ms total, %.4f ms average -- '
+          'compare `roofline.avg_launch_ms` = %s; its split pre-pass kernels (h3_split_rows / h3_colmax / '
+          'h3_split_t): %.3f ms total.' % (h3_calls, h3_ns / 1e6, h3_ns / 1e6 / h3_calls,
+                                           d.get('roofline', {}).get('avg_launch_ms'), pre_ns / 1e6))
 print('SpMM: %d launches, %.3f ms total, %.4f ms average -- compare `roofline_spmm.avg_launch_ms` = %s.'
       % (spmm_calls, spmm_ns / 1e6, spmm_ns / 1e6 / max(spmm_calls, 1),
          d.get('roofline_spmm', {}).get('avg_launch_ms')))
