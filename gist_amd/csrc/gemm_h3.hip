@@ -2,11 +2,12 @@
 // halves, x * 2^e = hi + lo with hi = f16(x 2^e), lo = f16(x 2^e - hi) (22 significant bits, one
 // power-of-two scale per operand ROW so neither half leaves the f16 range), and
 //     (A.B^T)[i][j]  ~=  2^-(ea_i+eb_j) * sum_k (ah.bh + ah.bl + al.bh)   (fp32 accumulation)
-// on v_mfma_f32_32x32x16_f16.  The dropped al.bl term is 2^-22 of a product, below the fp32
+// on v_mfma_f32_16x16x32_f16.  The dropped al.bl term is 2^-22 of a product, below the fp32
 // rounding of the running sum; measured against fp64 the result has the error of the
-// fp32-MFMA kernel (tests/test_gemm_h3_gpu.py).  Three f16 MFMAs replace sixteen fp32-rate
-// MFMA slots: the matrix-core time of a tile drops 5.3x and the kernel becomes bound by the
-// L2 -> LDS staging rate instead.
+// fp32-MFMA kernel or less (tests/test_gemm_h3_gpu.py, profiles/r01_gemm_h3_error_vs_float64.txt).
+// Three f16 MFMAs replace sixteen fp32-rate MFMA slots: the matrix-core time of a tile drops
+// 5.3x; what bounds the kernel then is the clock the chip holds under the MFMA load (1.8 GHz
+// measured) and, at 64 % matrix-pipe occupancy in cycles, the L2 -> LDS staging next to it.
 //
 // Pre-pass (HBM-bound, per operand): row maxima -> scale exponents; split kernel writes the operand
 // k-contiguous whatever its source layout (the transposed form of NN/TN operands is produced
@@ -17,10 +18,10 @@
 // fp32 kernel stages (LDS-DMA, buffer_load_dwordx4 ... lds), and one lane's MFMA fragment
 // (8 consecutive k of one row) is one ds_read_b128 for hi and one for lo.
 //
-// LDS image: [128 rows][8 chunks of 16 B]; chunk c of row r sits in slot c ^ ((r >> 1) & 7).
-// ds_read_b128 is served in 16-lane groups that hold rows {0-3,12-15,20-27} / {4-11,16-19,
-// 28-31}; two rows span the 64 banks, so rows of equal parity must differ in (r>>1)&7 -- they
-// do for both groups: conflict free.
+// Measured and dropped: the same tile on
+// v_mfma_f32_32x32x16_f16 (8 % slower per call: lower clock under load), a 128 x 256 x 16 tile
+// with three LDS stages (-25 % staged bytes, prefetch two steps ahead: equal or slower), and a
+// start-up stagger between the two workgroups of a CU (no effect).
 #include <stdlib.h>
 #include <string.h>
 
@@ -31,7 +32,6 @@
 namespace gist {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float h3_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int H3_T = 128;        // block tile edge
 constexpr int H3_BK = 32;        // k per tile = 32-bit words per image row
@@ -211,19 +211,6 @@ struct H3Args {
     int tiles_m, tiles_n;
 };
 
-// 4 LDS-DMA instructions per wave fill one 16 KiB image: instruction j = 4*wave + jj writes LDS
-// bytes [1024 j, 1024 (j+1)); the lane's source is the chunk that belongs at its 16 bytes.
-__device__ __forceinline__ void h3_dma_offsets(int64_t ld, int rows, int row0, int wave, int lane,
-                                               uint32_t (&off)[4]) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int p = 64 * (4 * wave + jj) + lane;
-        const int r = p >> 3, slot = p & 7;
-        const int dr = min(r, rows - 1 - row0);     // rows beyond the operand: re-read the last one
-        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ ((r >> 1) & 7)) << 2)) * 4);
-    }
-}
-
 __device__ __forceinline__ void h3_dma_image(const uint32_t *ubase, const uint32_t (&off)[4],
                                              char *image, int wave) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -235,11 +222,35 @@ __device__ __forceinline__ void h3_dma_image(const uint32_t *ubase, const uint32
             off[jj], 0, 0, 0);
 }
 
+// 128 x 128 x 32 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_f16 (48 MFMAs of 16 cycles per k tile), two LDS stages of 32 KiB, two
+// workgroups per CU, LDS-DMA staging issued one k tile ahead.  The 16x16x32 shape is chosen over
+// 32x32x16 (same cycles per flop, same LDS traffic) because the chip holds a higher clock
+// under it (MI355X_MICROARCH.md, DVFS give-back item 7): measured 8 % faster per call here.
+// A lane's fragment: row l&15 of a 16-row slab, k = 8 (l>>4) .. +7  ->  chunk 2 (l>>4) (hi) /
+// +1 (lo) of the 128-byte image row.  A ds_read_b128 lane group mixes two k groups
+// ({0-3,12-15} with k group g, {20-27} = rows 4-11 with g+1): chunk c of row r sits in slot
+// c ^ (bit1(r) | bit3(r) << 2), which keeps both kinds of group on 16 different bank quads
+// (SQ_LDS_BANK_CONFLICT = 0).
+typedef float h3_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int h3_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
+
+__device__ __forceinline__ void h3_dma_offsets(int64_t ld, int rows, int row0, int wave, int lane,
+                                                uint32_t (&off)[4]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int p = 64 * (4 * wave + jj) + lane;
+        const int r = p >> 3, slot = p & 7;
+        const int dr = min(r, rows - 1 - row0);
+        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ h3_swz(r)) << 2)) * 4);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     extern __shared__ __attribute__((aligned(16))) char h3_smem[];
     constexpr int T = H3_T;
 
-    // block -> output tile, 8-row super-tiles per XCD (as the fp32 kernel)
     const int nwg = g.tiles_m * g.tiles_n;
     const int orig = blockIdx.x;
     const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -257,15 +268,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, hh = lane >> 5;
+    const int rr = lane & 15, kg = lane >> 4;
 
-    h3_f32x16 acc[2][2];
+    h3_f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     uint32_t offA[4], offB[4];
     h3_dma_offsets(g.lda, g.m, row0, wave, lane, offA);
@@ -278,23 +289,21 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         h3_dma_image(originB + (int64_t)kt * H3_BK, offB, sa + H3_IMG * 4, wave);
     };
 
-    // fragment byte offsets inside an image: [slab][k16 step][hi/lo]
-    int fa[2][2][2], fb[2][2][2];
+    // fragment byte offsets inside an image: [16-row slab][hi/lo]
+    int fa[4][2], fb[4][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ar = wm * 64 + i * 32 + r, br = wn * 64 + i * 32 + r;
+    for (int i = 0; i < 4; ++i) {
+        const int ar = wm * 64 + i * 16 + rr, br = wn * 64 + i * 16 + rr;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int lo = 0; lo < 2; ++lo) {
-                const int c = 4 * s + 2 * hh + lo;
-                fa[i][s][lo] = ar * 128 + ((c ^ ((ar >> 1) & 7)) << 4);
-                fb[i][s][lo] = br * 128 + ((c ^ ((br >> 1) & 7)) << 4) + H3_IMG * 4;
-            }
+        for (int lo = 0; lo < 2; ++lo) {
+            const int c = 2 * kg + lo;
+            fa[i][lo] = ar * 128 + ((c ^ h3_swz(ar)) << 4);
+            fb[i][lo] = br * 128 + ((c ^ h3_swz(br)) << 4) + H3_IMG * 4;
+        }
     }
 
     if (n_kt > 0) dma(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): the DMA has landed
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
 
     auto kstep = [&](auto cur_c, auto next_c, int kt) {
@@ -307,35 +316,30 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         const char *img = h3_smem + cur * H3_BUF_BYTES;
         __builtin_amdgcn_s_setprio(1);
 #ifndef H3_PROBE_NO_MFMA
+        f16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+        for (int i = 0; i < 4; ++i) ah[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][0]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][s][0]);
-                bh[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][s][0]);
-            }
+        for (int i = 0; i < 4; ++i) bh[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][0]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                bl[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][s][1]);
-                al[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][s][1]);
-            }
+        for (int i = 0; i < 4; ++i) bl[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][1]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i) al[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][1]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -357,32 +361,32 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         }
     }
 
-    // ---- epilogue: undo the operand scales, bias, raw buffer stores (as the fp32 kernel) ----
+    // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)row0 * g.ldc + col0;
     const int rows_valid = min(g.m - row0, T);
     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
         cbase, 0, (int)((int64_t)rows_valid * g.ldc * 4), 0x00020000);
     const uint32_t ldc_b = (uint32_t)g.ldc * 4;
-    uint32_t cvoff[2];
-    float bv[2], sb[2];
+    uint32_t cvoff[4];
+    float bv[4], sb[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cl = wn * 64 + j * 32 + r;
+    for (int j = 0; j < 4; ++j) {
+        const int cl = wn * 64 + j * 16 + rr;
         const bool ok = col0 + cl < g.n;
-        cvoff[j] = ok ? (uint32_t)(wm * 64 + 4 * hh) * ldc_b + (uint32_t)cl * 4 : 0x7fffffffu;
+        cvoff[j] = ok ? (uint32_t)(wm * 64 + 4 * kg) * ldc_b + (uint32_t)cl * 4 : 0x7fffffffu;
         bv[j] = (g.bias != nullptr && ok) ? g.bias[col0 + cl] : 0.f;
         sb[j] = ok ? g.inv_b[col0 + cl] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rl = i * 32 + (e & 3) + 8 * (e >> 2);             // uniform part of the row
+        for (int e = 0; e < 4; ++e) {
+            const int rl = i * 16 + e;
             const uint32_t roff = (uint32_t)rl * ldc_b;
-            const int grow = min(row0 + wm * 64 + 4 * hh + rl, g.m - 1);
+            const int grow = min(row0 + wm * 64 + 4 * kg + rl, g.m - 1);
             const float sa = g.inv_a[grow];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const float v = fmaf(acc[i][j][e] * sa, sb[j], bv[j]);
                 if (rows_valid == T)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j], roff, 0);
