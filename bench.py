@@ -20,7 +20,7 @@ under GIST every rank trains n_epochs/S epochs (cluster_gcn_ist_distrib.py:385),
 job's throughput is the SUM of the ranks' epochs/sec ("weak": per-GPU batch stream fixed).
 
 Projections: fp32 in, fp32 out, fp32 accumulation.  By default (--gemm-mode f16x3) every
-projection >= 16 GFLOP forms its products as 3 f16-split terms on v_mfma_f32_32x32x16_f16
+projection >= 16 GFLOP forms its products as 3 f16-split terms on v_mfma_f32_16x16x32_f16
 (gist_amd/csrc/gemm_h3.hip; error against float64 equal to or below the fp32-MFMA kernel's,
 tests/test_gemm_h3_gpu.py, tests/test_e2e_gpu.py); --gemm-mode f32 keeps all of them on
 v_mfma_f32_32x32x2_f32.  At N=1 the line also carries `f32_mfma`: the same workload re-timed
@@ -255,7 +255,7 @@ def main():
     if timing:
         if native:          # HIP events recorded by the native step driver on the launch stream
             sample_timer = engine.enable_timer(
-                (args.steps // max(args.timing_every, 1) + 1) * (8 * len(dims) + 2))
+                (args.steps // max(args.timing_every, 1) + 1) * (12 * len(dims) + 4))
         else:
             hip.profile_begin()
     t0 = time.time()
@@ -267,6 +267,7 @@ def main():
         rec = engine.read_timer()
         prof = {'gemm': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 1],
                 'h3': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 2],
+                'pre': [ms for (ms, kind, m, n, k) in rec if kind == 3],
                 'spmm': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 0]}
         engine.disable_timer()
     elif timing:
@@ -334,7 +335,7 @@ def main():
                 bb = it.batcher.extract(ids, engine.z0_left(ids.numel()))
                 nnz[i] = int(bb.rowptr[bb.n].item())
             gem = prof['gemm']
-            g_ms = sum(ms for ms, _ in gem)
+            g_ms = sum(ms for ms, _ in gem) + sum(prof.get('pre', []))   # + split work outside the calls
             g_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in gem)
             ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
             every = args.timing_every if native else 1
@@ -347,7 +348,7 @@ def main():
                 h_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in h3)
                 h_ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
                 out['roofline'] = {
-                    'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_32x32x16_f16, 3 MFMA flops per '
+                    'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_16x16x32_f16, 3 MFMA flops per '
                               'algorithmic flop: ah.bh + ah.bl + al.bh)',
                     'bound': 'mfma', 'achieved': round(h_ach, 3), 'peak': MFMA_F16_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(h_ach / MFMA_F16_PEAK_TFLOPS, 4),
@@ -367,8 +368,8 @@ def main():
                         'share_of_step': round(g_ms * every / (elapsed * 1e3), 4),
                         'split_prepass_share_of_step': round(
                             (sum(ms for ms, (_, m, n, k) in gem
-                                 if any((m, n, k) == s[1:] for _, s in h3)) - h_ms)
-                            * every / (elapsed * 1e3), 4),
+                                 if any((m, n, k) == s[1:] for _, s in h3)) - h_ms
+                             + sum(prof.get('pre', []))) * every / (elapsed * 1e3), 4),
                     },
                 }
             else:

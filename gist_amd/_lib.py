@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GistLibraryError(RuntimeError):
@@ -67,6 +67,7 @@ SIGNATURES = {
     'gist_timer_reset': (None, [_p]),
     'gist_timer_count': (_i64, [_p]),
     'gist_timer_read': (_int, [_p, _i64, _p, _p, _p, _p, _p]),
+    'gist_step_h3_workspace_bytes': (_i64, [_p]),
     'gist_sage_step': (_int, [_p, _p, _i64, _u64, _f, _f, _f, _f, _f, _i64, _int, _p]),
 }
 
@@ -95,7 +96,9 @@ class StepPlan(ctypes.Structure):
                 ('g_rowptr', _p), ('g_col', _p), ('g_t_rowptr', _p), ('g_t_col', _p),
                 ('feat', _p), ('ld_feat', _i64), ('labels_all', _p), ('remap', _p),
                 ('rowptr', _p), ('col', _p), ('t_rowptr', _p), ('t_col', _p),
-                ('col_capacity', _i64), ('norm', _p), ('labels', _p), ('timer', _p)]
+                ('col_capacity', _i64), ('norm', _p), ('labels', _p), ('timer', _p),
+                ('n_max', _i64), ('feat_absmax', _f), ('h3_workspace', _p),
+                ('h3_workspace_bytes', _i64)]
 
 
 _lib = None

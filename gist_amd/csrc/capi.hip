@@ -14,7 +14,7 @@ void set_error(const char *fmt, ...) {
 }  // namespace gist
 
 extern "C" const char *gist_last_error(void) { return gist::g_err; }
-extern "C" int gist_abi_version(void) { return 4; }
+extern "C" int gist_abi_version(void) { return 5; }
 extern "C" int gist_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

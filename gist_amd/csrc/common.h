@@ -39,6 +39,42 @@ extern thread_local gist_timer *tl_timer;
 int64_t timer_begin(gist_timer *t, int kind, int64_t m, int64_t n, int64_t k, hipStream_t s);
 void timer_end(gist_timer *t, int64_t slot, hipStream_t s);
 
+// dropout's counter-based generator (rowops.hip; also applied inside the split pre-pass)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// gemm_h3.hip: building blocks of the split projection path for a caller that manages the
+// split operands itself (the step driver).  Split operand = [rows][h3_kpad(k)] 32-bit words
+// + one inverse scale (power of two) per row.
+int64_t h3_kpad(int64_t k);
+bool h3_eligible(int64_t m, int64_t n, int64_t k);
+struct H3Dual {                       // one read of src[rows, cols] -> up to two split operands
+    const float *src; int64_t ld; int64_t rows, cols;
+    float p; uint64_t seed, offset;   // dropout applied on the fly (p = 0: none), gist_dropout_f32's stream
+    int fixed_shift;                  // uniform scale 2^fixed_shift ...
+    const unsigned *amax;             // ... or, if not NULL, from the tensor's max |x| (float bits)
+    const float *rowmax, *colmax;     // if not NULL: per-row / per-column maxima instead
+    uint32_t *dst_r; float *inv_r;    // [rows][kpad(cols)]: k = columns of src   (NULL: skip)
+    uint32_t *dst_t; float *inv_t;    // [cols][kpad(rows)]: k = rows of src      (NULL: skip)
+};
+int h3_dual_split(const H3Dual &d, hipStream_t st);
+int h3_split_rows(const float *src, int64_t ld, int64_t rows, int64_t k, uint32_t *dst, float *inv,
+                  hipStream_t st);
+int h3_absmax(const float *src, int64_t ld, int64_t rows, int64_t cols, unsigned *out, hipStream_t st);
+int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, const uint32_t *sb,
+                     const float *inv_b, const float *bias, float *c, int64_t ldc, int64_t m,
+                     int64_t n, int64_t k, hipStream_t st);
+
+// rowops.hip: the C-ABI kernels with the extra outputs the split projection path consumes
+int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                   float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                   float *rowmax, hipStream_t st);
+int colsum_ex(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, float *out,
+              float *pmax, float *outmax, hipStream_t st);
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

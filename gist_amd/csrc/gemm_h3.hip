@@ -200,6 +200,120 @@ __global__ __launch_bounds__(256) void h3_split_t_kernel(const float *__restrict
     }
 }
 
+// One read of src[rows, cols] -> the split operand with k = columns (dst_r) and/or the one with
+// k = rows (dst_t), 64 x 64 per block through LDS.  Scales: uniform (a given exponent, or from
+// the tensor's max |x|), or per row / per column from given maxima.  Dropout is applied on the
+// fly with gist_dropout_f32's generator (element index offset + r * cols + c), so the fp32
+// dropped tensor never has to exist.
+__global__ __launch_bounds__(256) void h3_dual_split_kernel(H3Dual d, int64_t ldd_r, int64_t ldd_t,
+                                                            float keep) {
+    __shared__ float tile[64][65];
+    __shared__ float srow[64], scol[64];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+    if (t < 128) {
+        const bool is_row = t < 64;
+        const int i = t & 63;
+        const int64_t g = (is_row ? r0 : c0) + i;
+        const float *mx = is_row ? d.rowmax : d.colmax;
+        float inv, s;
+        if (mx != nullptr) {
+            s = g < (is_row ? d.rows : d.cols) ? h3_scale(__float_as_uint(mx[g]), &inv) : 1.f;
+        } else if (d.amax != nullptr) {
+            s = h3_scale(*d.amax, &inv);
+        } else {
+            s = __uint_as_float((unsigned)(127 + d.fixed_shift) << 23);
+            inv = __uint_as_float((unsigned)(127 - d.fixed_shift) << 23);
+        }
+        if (is_row) {
+            srow[i] = s;
+            if (blockIdx.x == 0 && d.inv_r != nullptr && g < d.rows) d.inv_r[g] = inv;
+        } else {
+            scol[i] = s;
+            if (blockIdx.y == 0 && d.inv_t != nullptr && g < d.cols) d.inv_t[g] = inv;
+        }
+    }
+    const int c4 = (t & 15) * 4;
+    const uint64_t sm = d.seed * 0x9E3779B97F4A7C15ULL;
+    const float inv24 = 1.0f / 16777216.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (t >> 4) + 16 * i;
+        const int64_t r = r0 + rr;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < d.rows) {
+            const float *p = d.src + r * d.ld + c0 + c4;
+            if (c0 + c4 + 3 < d.cols) {
+                const float4 q = *reinterpret_cast<const float4 *>(p);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (c0 + c4 + j < d.cols) v[j] = p[j];
+            }
+            if (d.p > 0.f) {
+                const uint64_t idx0 = d.offset + (uint64_t)r * (uint64_t)d.cols + (uint64_t)(c0 + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t idx = idx0 + j;
+                    const uint64_t h = splitmix64((idx >> 1) + sm);
+                    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+                    v[j] *= ((float)(w >> 8) * inv24 >= d.p) ? keep : 0.f;
+                }
+            }
+        }
+        tile[rr][c4 + 0] = v[0]; tile[rr][c4 + 1] = v[1];
+        tile[rr][c4 + 2] = v[2]; tile[rr][c4 + 3] = v[3];
+    }
+    __syncthreads();
+    const int kb = t & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (t >> 3) + 32 * i;
+        if (d.dst_r != nullptr && r0 + q < d.rows && c0 + kb * 8 < ldd_r) {      // row q, 8 columns
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[q][kb * 8 + j];
+            h3_emit(v, srow[q], d.dst_r + (int64_t)(r0 + q) * ldd_r + c0 + kb * 8);
+        }
+        if (d.dst_t != nullptr && c0 + q < d.cols && r0 + kb * 8 < ldd_t) {      // column q, 8 rows
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[kb * 8 + j][q];
+            h3_emit(v, scol[q], d.dst_t + (int64_t)(c0 + q) * ldd_t + r0 + kb * 8);
+        }
+    }
+}
+
+// max |x| of a [rows, cols] window into *out (float bits; zeroed by the caller).  16 rows per
+// block, 8 independent 16-byte loads in flight per thread.
+__global__ __launch_bounds__(256) void h3_absmax_kernel(const float *__restrict__ src, int64_t ld,
+                                                        int rows, int cols,
+                                                        unsigned *__restrict__ out) {
+    const int c4n = cols >> 2;
+    float m = 0.f;
+    const int rbeg = blockIdx.x * 16, rend = min(rows, rbeg + 16);
+    for (int r = rbeg; r < rend; ++r) {
+        const float *p = src + (int64_t)r * ld;
+        int c = threadIdx.x;
+        for (; c + 7 * 256 < c4n; c += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(p + 4 * (c + 256 * u));
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+        }
+        for (; c < c4n; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + 4 * c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        if ((int)threadIdx.x < (cols & 3)) m = fmaxf(m, fabsf(p[4 * c4n + threadIdx.x]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 // ---- the GEMM -----------------------------------------------------------------------------
 struct H3Args {
     const uint32_t *a; int64_t lda;      // split operands, [rows][kpad] 32-bit words
@@ -409,7 +523,7 @@ int h3_mode() {
     return g_h3_mode;
 }
 
-static inline int64_t h3_kpad(int64_t k) { return ceil_div(k, H3_BK) * H3_BK; }
+int64_t h3_kpad(int64_t k) { return ceil_div(k, H3_BK) * H3_BK; }
 
 // Shapes the split path takes: enough 128x128 tiles to occupy the chip and enough flops to
 // pay for the pre-pass (measured break-even ~20 GFLOP, scripts/h3_bench.py).  Everything else
@@ -431,6 +545,57 @@ static inline int64_t h3_head_bytes(int64_t m, int64_t n) { return ceil_div((m +
 int64_t h3_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (!h3_eligible(m, n, k)) return 0;
     return h3_head_bytes(m, n) + (m + n) * h3_kpad(k) * 4;
+}
+
+int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, const uint32_t *sb,
+                     const float *inv_b, const float *bias, float *c, int64_t ldc, int64_t m,
+                     int64_t n, int64_t k, hipStream_t st) {
+    const int64_t kpad = h3_kpad(k);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * H3_BUF_BYTES);
+        if (e != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return GIST_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    H3Args g;
+    g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.inv_a = inv_a; g.inv_b = inv_b; g.bias = bias;
+    g.c = c; g.ldc = ldc; g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
+    g.tiles_m = (int)ceil_div(m, H3_T);
+    g.tiles_n = (int)ceil_div(n, H3_T);
+    const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel alone
+    hipLaunchKernelGGL(gemm_h3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256),
+                       2 * H3_BUF_BYTES, st, g);
+    timer_end(tl_timer, slot, st);
+    return launch_status(name);
+}
+
+int h3_split_rows(const float *src, int64_t ld, int64_t rows, int64_t k, uint32_t *dst, float *inv,
+                  hipStream_t st) {
+    if (rows <= 0) return GIST_OK;
+    hipLaunchKernelGGL(h3_split_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, src, ld, (int)k,
+                       dst, h3_kpad(k), inv);
+    return launch_status("h3_split_rows");
+}
+
+int h3_absmax(const float *src, int64_t ld, int64_t rows, int64_t cols, unsigned *out, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return GIST_OK;
+    hipLaunchKernelGGL(h3_absmax_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, st, src, ld,
+                       (int)rows, (int)cols, out);
+    return launch_status("h3_absmax");
+}
+
+int h3_dual_split(const H3Dual &d, hipStream_t st) {
+    if (d.rows <= 0 || d.cols <= 0) return GIST_OK;
+    const int64_t ldd_r = h3_kpad(d.cols), ldd_t = h3_kpad(d.rows);
+    const int64_t gx = ceil_div(d.dst_r ? ldd_r : d.cols, 64), gy = ceil_div(d.dst_t ? ldd_t : d.rows, 64);
+    hipLaunchKernelGGL(h3_dual_split_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, d,
+                       ldd_r, ldd_t, d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f);
+    return launch_status("h3_dual_split");
 }
 
 // A: a_kc ? [m][k] : [k][m];  B: b_kc ? [n][k] : [k][n].  Returns 1 if the GEMM was issued,
@@ -469,27 +634,7 @@ int h3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
     split(a_kc, a, lda, m, sa, max_a, inv_a);
     split(b_kc, b, ldb, n, sb, max_b, inv_b);
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * H3_BUF_BYTES);
-        if (e != hipSuccess) {
-            set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-            return GIST_ELAUNCH;
-        }
-        attr_set = true;
-    }
-    H3Args g;
-    g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.inv_a = inv_a; g.inv_b = inv_b; g.bias = bias;
-    g.c = c; g.ldc = ldc; g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
-    g.tiles_m = (int)ceil_div(m, H3_T);
-    g.tiles_n = (int)ceil_div(n, H3_T);
-    const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel alone
-    hipLaunchKernelGGL(gemm_h3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256),
-                       2 * H3_BUF_BYTES, st, g);
-    timer_end(tl_timer, slot, st);
-    const int rc = launch_status(name);
+    const int rc = h3_gemm_presplit(name, sa, inv_a, sb, inv_b, bias, c, ldc, m, n, k, st);
     return rc == GIST_OK ? 1 : rc;
 }
 

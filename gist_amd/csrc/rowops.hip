@@ -101,7 +101,7 @@ template <int TPR, int VEC>
 __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
     const float *__restrict__ d_out, int64_t ldg, const float *yhat, int64_t ldy,
     const float *__restrict__ rstd_in, float *dy, int64_t lddy, int n_rows, int d,
-    int use_lynorm, int relu) {
+    int use_lynorm, int relu, float *__restrict__ rowmax) {
     __shared__ float red[4];
     constexpr int RPB = 256 / TPR;
     const int row = blockIdx.x * RPB + threadIdx.x / TPR;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
         if (live) rstd = rstd_in[row];
     }
     if (!live) return;
+    float mx = 0.f;      // max |dy| of the row (scale of the split projection operand, gemm_h3.hip)
     for (int c = t * VEC; c < d; c += TPR * VEC) {
         if constexpr (VEC == 4) {
             const float4 g = *reinterpret_cast<const float4 *>(gr + c);
@@ -150,24 +151,31 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
                 o.z = rstd * (o.z - m1 - yv.z * m2); o.w = rstd * (o.w - m1 - yv.w * m2);
             }
             *reinterpret_cast<float4 *>(dr + c) = o;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         } else {
             const float yv = yr[c];
             float o = (!relu || yv > 0.f) ? gr[c] : 0.f;
             if (use_lynorm) o = rstd * (o - m1 - yv * m2);
             dr[c] = o;
+            mx = fmaxf(mx, fabsf(o));
         }
+    }
+    if (rowmax != nullptr) {      // uniform per launch; a row's threads are all live here
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if constexpr (TPR == 256) {
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        }
+        if (t == 0) rowmax[row] = mx;
     }
 }
 
 // ---------------------------------------------------------------------------
 // dropout: counter based (splitmix64 finaliser of seed-mixed element index)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-
 // One hash serves two consecutive elements (even index -> low word, odd -> high word).
 __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float scale) {
     const uint64_t h = splitmix64((idx >> 1) + seed * 0x9E3779B97F4A7C15ULL);
@@ -218,37 +226,58 @@ constexpr int kColsumRows = 64;
 // stage 1: workgroup = 64 columns x 4 row lanes over a chunk of 64 rows; a wave reads 64
 // consecutive floats of one row (256 B), four independent row reads in flight per thread,
 // row lanes combined through LDS in fixed order.
+template <bool WITH_MAX>
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float *__restrict__ g,
                                                             int64_t ldg, int n_rows, int d,
-                                                            float *__restrict__ partials) {
+                                                            float *__restrict__ partials,
+                                                            float *__restrict__ pmax) {
     __shared__ float red[3][64];
+    __shared__ float redm[3][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * kColsumRows;
     const int r1 = min(n_rows, r0 + kColsumRows);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, mx = 0.f;
     if (c < d) {
         const float *p = g + c;
         int r = r0 + rl;
         for (; r + 12 < r1; r += 16) {
-            s0 += p[(int64_t)r * ldg];
-            s1 += p[(int64_t)(r + 4) * ldg];
-            s2 += p[(int64_t)(r + 8) * ldg];
-            s3 += p[(int64_t)(r + 12) * ldg];
+            const float a0 = p[(int64_t)r * ldg], a1 = p[(int64_t)(r + 4) * ldg];
+            const float a2 = p[(int64_t)(r + 8) * ldg], a3 = p[(int64_t)(r + 12) * ldg];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+            if constexpr (WITH_MAX)
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(a2), fabsf(a3))));
         }
-        for (; r < r1; r += 4) s0 += p[(int64_t)r * ldg];
+        for (; r < r1; r += 4) {
+            const float a0 = p[(int64_t)r * ldg];
+            s0 += a0;
+            if constexpr (WITH_MAX) mx = fmaxf(mx, fabsf(a0));
+        }
     }
     const float s = (s0 + s1) + (s2 + s3);
-    if (rl > 0) red[rl - 1][cl] = s;
+    if (rl > 0) {
+        red[rl - 1][cl] = s;
+        if constexpr (WITH_MAX) redm[rl - 1][cl] = mx;
+    }
     __syncthreads();
-    if (rl == 0 && c < d)
+    if (rl == 0 && c < d) {
         partials[(int64_t)blockIdx.y * d + c] = ((s + red[0][cl]) + red[1][cl]) + red[2][cl];
+        if constexpr (WITH_MAX)
+            pmax[(int64_t)blockIdx.y * d + c] =
+                fmaxf(fmaxf(mx, redm[0][cl]), fmaxf(redm[1][cl], redm[2][cl]));
+    }
 }
 
 __global__ void colsum_stage2_kernel(const float *__restrict__ partials, int chunks, int d,
-                                     float *__restrict__ out) {
+                                     float *__restrict__ out, const float *__restrict__ pmax,
+                                     float *__restrict__ outmax) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d) return;
+    if (outmax != nullptr) {
+        float m = 0.f;
+        for (int k = 0; k < chunks; ++k) m = fmaxf(m, pmax[(int64_t)k * d + c]);
+        outmax[c] = m;
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
     for (; k + 3 < chunks; k += 4) {
@@ -387,10 +416,11 @@ extern "C" int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t l
     return launch_status("gist_ln_relu_fwd_f32");
 }
 
-extern "C" int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float *yhat,
-                                    int64_t ldy, const float *rstd, float *dy, int64_t lddy,
-                                    int64_t n_rows, int64_t d, int use_lynorm, int relu,
-                                    gist_stream_t stream) {
+namespace gist {
+// + rowmax (NULL or [n_rows]): max |dy| per row, for the split projection path (gemm_h3.hip)
+int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                   float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                   float *rowmax, hipStream_t st) {
     GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_ln_relu_bwd_f32: negative size");
     if (n_rows == 0 || d == 0) return GIST_OK;
     GIST_REQUIRE(d_out && yhat && dy, "gist_ln_relu_bwd_f32: null pointer");
@@ -399,16 +429,24 @@ extern "C" int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float
     GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_ln_relu_bwd_f32: size >= 2^31");
     const bool v4 = d % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 &&
                     aligned16(d_out) && aligned16(yhat) && aligned16(dy);
-    hipStream_t st = as_stream(stream);
     const bool wide = d > 1024;
     const unsigned grid = (unsigned)(wide ? n_rows : ceil_div(n_rows, 4));
 #define L(TPR, V)                                                                               \
     hipLaunchKernelGGL((ln_relu_bwd_kernel<TPR, V>), dim3(grid), dim3(256), 0, st, d_out, ldg,   \
-                       yhat, ldy, rstd, dy, lddy, (int)n_rows, (int)d, use_lynorm, relu)
+                       yhat, ldy, rstd, dy, lddy, (int)n_rows, (int)d, use_lynorm, relu, rowmax)
     if (wide) { if (v4) L(256, 4); else L(256, 1); }
     else { if (v4) L(64, 4); else L(64, 1); }
 #undef L
     return launch_status("gist_ln_relu_bwd_f32");
+}
+}  // namespace gist
+
+extern "C" int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float *yhat,
+                                    int64_t ldy, const float *rstd, float *dy, int64_t lddy,
+                                    int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                    gist_stream_t stream) {
+    return gist::ln_relu_bwd_ex(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu,
+                                nullptr, gist::as_stream(stream));
 }
 
 extern "C" int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d, float p,
@@ -435,22 +473,36 @@ extern "C" int64_t gist_colsum_partials(int64_t n_rows) {
     return n_rows <= 0 ? 0 : ceil_div(n_rows, kColsumRows);
 }
 
-extern "C" int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int64_t d,
-                               float *partials, float *out, gist_stream_t stream) {
+namespace gist {
+// + pmax ([chunks, d] scratch) and outmax ([d]): max |g| per column (both NULL = sums only)
+int colsum_ex(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, float *out,
+              float *pmax, float *outmax, hipStream_t st) {
     GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_colsum_f32: negative size");
     if (d == 0) return GIST_OK;
     GIST_REQUIRE(out, "gist_colsum_f32: null output");
-    hipStream_t st = as_stream(stream);
+    GIST_REQUIRE((pmax == nullptr) == (outmax == nullptr), "gist_colsum_f32: pmax/outmax mismatch");
     const int chunks = (int)gist_colsum_partials(n_rows);
     if (chunks > 0) {
         GIST_REQUIRE(g && partials && ldg >= d, "gist_colsum_f32: bad buffer");
         GIST_REQUIRE(chunks <= 65535, "gist_colsum_f32: too many rows");
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)ceil_div(d, 64), (unsigned)chunks),
-                           dim3(256), 0, st, g, ldg, (int)n_rows, (int)d, partials);
+        const dim3 grid((unsigned)ceil_div(d, 64), (unsigned)chunks);
+        if (pmax)
+            hipLaunchKernelGGL(colsum_stage1_kernel<true>, grid, dim3(256), 0, st, g, ldg,
+                               (int)n_rows, (int)d, partials, pmax);
+        else
+            hipLaunchKernelGGL(colsum_stage1_kernel<false>, grid, dim3(256), 0, st, g, ldg,
+                               (int)n_rows, (int)d, partials, pmax);
     }
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(d, 64)), dim3(64), 0, st,
-                       partials, chunks, (int)d, out);
+                       partials, chunks, (int)d, out, pmax, outmax);
     return launch_status("gist_colsum_f32");
+}
+}  // namespace gist
+
+extern "C" int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int64_t d,
+                               float *partials, float *out, gist_stream_t stream) {
+    return gist::colsum_ex(g, ldg, n_rows, d, partials, out, nullptr, nullptr,
+                           gist::as_stream(stream));
 }
 
 extern "C" int gist_softmax_xent_f32(const float *logits, int64_t ldl, const int32_t *labels,

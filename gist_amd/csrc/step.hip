@@ -4,6 +4,8 @@
 // from ~45 interpreter round trips to ~45 back-to-back hipLaunch calls, which is what
 // bounds the small-width (many-GPU) regime.  Arithmetic is unchanged: it calls the same
 // entry points the op-level API exposes.
+#include <math.h>
+
 #include <new>
 
 #include "common.h"
@@ -103,6 +105,84 @@ struct ActiveTimer {   // kernels below the entry points see the armed timer for
 };
 }  // namespace
 
+// ---- split projection operands kept by the step (gist_step_plan.h3_workspace) ---------------
+namespace {
+struct H3Layer {
+    bool on;                       // this layer's three projections run on pre-split operands
+    int shift;                     // fixed scale exponent of its input activations Z_k
+    uint32_t *Zs, *ZsT, *Ws, *WsT; // [n][kpad(2in)], [2in][kpad(n)], [out][kpad(2in)], [2in][kpad(out)]
+    float *inv_zr, *inv_zt, *inv_wr, *inv_wt;
+};
+struct H3Step {
+    bool any;
+    H3Layer layer[GIST_MAX_LAYERS];
+    uint32_t *dYs, *dYsT;          // [n][kpad(out)], [out][kpad(n)] (shared by the layers)
+    float *inv_dyr, *inv_dyt, *rowmax, *colmax, *pmax;
+    unsigned *amax;                // [GIST_MAX_LAYERS]
+    int64_t bytes;
+};
+
+inline int bound_shift(double bound) {      // 2^shift * bound <= 2^13
+    int e = 0;
+    (void)frexp(bound, &e);                  // bound = f * 2^e, f in [0.5, 1)
+    const int s = 13 - e;
+    return s < -60 ? -60 : (s > 60 ? 60 : s);
+}
+
+// Deterministic carve-up of the workspace from the plan's shapes; base may be NULL (sizing).
+H3Step h3_layout(const gist_step_plan *p, char *base) {
+    H3Step h{};
+    const int L1 = p->n_layers;
+    const int64_t n = p->n_max;
+    if (gist_gemm_get_mode() != 1 || n <= 0) return h;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char *q = base ? base + off : nullptr;
+        off += ceil_div(bytes, 256) * 256;
+        return q;
+    };
+    int64_t max_out = 0;
+    const double keep = p->p_drop > 0.f ? 1.0 / (1.0 - (double)p->p_drop) : 1.0;
+    for (int k = 0; k < L1; ++k) {
+        const gist_layer_desc &l = p->layer[k];
+        const int64_t i2 = 2 * l.n_in, o = l.n_out;
+        H3Layer &hl = h.layer[k];
+        const double bound = k == 0 ? (double)p->feat_absmax * keep
+                                    : (p->use_layernorm ? sqrt((double)(l.n_in > 1 ? l.n_in - 1 : 1)) * keep : 0.0);
+        hl.on = bound > 0.0 && h3_eligible(n, o, i2) && h3_eligible(o, i2, n) &&
+                (k == 0 || h3_eligible(n, i2, o)) && l.ldz % 4 == 0 && l.ldy % 4 == 0;
+        if (!hl.on) continue;
+        h.any = true;
+        hl.shift = bound_shift(bound);
+        hl.Zs = reinterpret_cast<uint32_t *>(take(n * h3_kpad(i2) * 4));
+        hl.ZsT = reinterpret_cast<uint32_t *>(take(i2 * h3_kpad(n) * 4));
+        hl.Ws = reinterpret_cast<uint32_t *>(take(o * h3_kpad(i2) * 4));
+        hl.WsT = k > 0 ? reinterpret_cast<uint32_t *>(take(i2 * h3_kpad(o) * 4)) : nullptr;
+        hl.inv_zr = reinterpret_cast<float *>(take(n * 4));
+        hl.inv_zt = reinterpret_cast<float *>(take(i2 * 4));
+        hl.inv_wr = reinterpret_cast<float *>(take(o * 4));
+        hl.inv_wt = k > 0 ? reinterpret_cast<float *>(take(i2 * 4)) : nullptr;
+        max_out = o > max_out ? o : max_out;
+    }
+    if (!h.any) return h;
+    h.dYs = reinterpret_cast<uint32_t *>(take(n * h3_kpad(max_out) * 4));
+    h.dYsT = reinterpret_cast<uint32_t *>(take(max_out * h3_kpad(n) * 4));
+    h.inv_dyr = reinterpret_cast<float *>(take(n * 4));
+    h.inv_dyt = reinterpret_cast<float *>(take(max_out * 4));
+    h.rowmax = reinterpret_cast<float *>(take(n * 4));
+    h.colmax = reinterpret_cast<float *>(take(max_out * 4));
+    h.pmax = reinterpret_cast<float *>(take(gist_colsum_partials(n) * max_out * 4));
+    h.amax = reinterpret_cast<unsigned *>(take(GIST_MAX_LAYERS * 4));
+    h.bytes = off;
+    return h;
+}
+}  // namespace
+
+extern "C" int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan) {
+    if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS) return 0;
+    return h3_layout(plan, nullptr).bytes;
+}
+
 extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64_t n,
                               uint64_t drop_offset, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int64_t adam_step, int flags,
@@ -115,6 +195,41 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     ActiveTimer active(p->timer);
     const bool train = (flags & GIST_STEP_TRAIN) != 0;
     const bool drop = train && p->p_drop > 0.f;
+
+    // Split operands kept by the step (see gist_step_plan.h3_workspace); off = per-call splits
+    // inside gist_gemm_*.
+    H3Step h3{};
+    if (p->h3_workspace != nullptr && aligned16(p->h3_workspace) && n <= p->n_max &&
+        (flags & (GIST_STEP_OVERLAP_ADAM | GIST_STEP_OVERLAP_DW)) == 0) {
+        h3 = h3_layout(p, static_cast<char *>(p->h3_workspace));
+        if (h3.bytes > p->h3_workspace_bytes) h3 = H3Step{};
+    }
+    if (h3.any) {      // this step's weights: rows split for Y = Z.W^T, transposed for dZ = dY.W
+        Scope sc(p->timer, 3, 0, 0, 0, st);
+        bool zeroed = false;
+        for (int k = 0; k < L1; ++k) {
+            const H3Layer &hl = h3.layer[k];
+            if (!hl.on) continue;
+            const gist_layer_desc &l = p->layer[k];
+            if (k > 0 && train) {      // one read of W_k, one scale for the tensor, both layouts
+                if (!zeroed) {
+                    if (hipMemsetAsync(h3.amax, 0, GIST_MAX_LAYERS * 4, st) != hipSuccess) {
+                        set_error("gist_sage_step: hipMemsetAsync failed");
+                        return GIST_ELAUNCH;
+                    }
+                    zeroed = true;
+                }
+                GIST_TRY(h3_absmax(l.W, 2 * l.n_in, l.n_out, 2 * l.n_in, h3.amax + k, st));
+                H3Dual d{};
+                d.src = l.W; d.ld = 2 * l.n_in; d.rows = l.n_out; d.cols = 2 * l.n_in;
+                d.amax = h3.amax + k;
+                d.dst_r = hl.Ws; d.inv_r = hl.inv_wr; d.dst_t = hl.WsT; d.inv_t = hl.inv_wt;
+                GIST_TRY(h3_dual_split(d, st));
+            } else {
+                GIST_TRY(h3_split_rows(l.W, 2 * l.n_in, l.n_out, 2 * l.n_in, hl.Ws, hl.inv_wr, st));
+            }
+        }
+    }
 
     if (flags & GIST_STEP_EXTRACT) {
         GIST_REQUIRE(ids != nullptr, "gist_sage_step: null ids");
@@ -136,11 +251,26 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                        l.n_in, p->norm, nullptr, 0, s));
         }
         offs[k] = off;
-        if (drop) {
-            GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, off, s));
-            off += round_up2((uint64_t)n * 2 * l.n_in);
-        }
-        {
+        if (h3.layer[k].on) {
+            // dropout + split of Z_k in one pass (both layouts when training); the dropped
+            // fp32 Z_k is never written: the backward only needs its transposed split
+            const H3Layer &hl = h3.layer[k];
+            Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
+            H3Dual d{};
+            d.src = l.Z; d.ld = l.ldz; d.rows = n; d.cols = 2 * l.n_in;
+            d.p = drop ? p->p_drop : 0.f; d.seed = p->seed; d.offset = off;
+            d.fixed_shift = hl.shift;
+            d.dst_r = hl.Zs; d.inv_r = hl.inv_zr;
+            d.dst_t = train ? hl.ZsT : nullptr; d.inv_t = hl.inv_zt;
+            GIST_TRY(h3_dual_split(d, st));
+            if (drop) off += round_up2((uint64_t)n * 2 * l.n_in);
+            GIST_TRY(h3_gemm_presplit("gist_sage_step", hl.Zs, hl.inv_zr, hl.Ws, hl.inv_wr, l.b, l.Y,
+                                      l.ldy, n, l.n_out, 2 * l.n_in, st));
+        } else {
+            if (drop) {
+                GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, off, s));
+                off += round_up2((uint64_t)n * 2 * l.n_in);
+            }
             Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
             GIST_TRY(gist_gemm_nt_f32(l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out,
                                       2 * l.n_in, p->workspace, p->workspace_bytes, s));
@@ -184,11 +314,45 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             lddy = p->ldc;
         } else {
             const int64_t i_next = p->layer[k + 1].n_in;      // == l.n_out
-            GIST_TRY(gist_ln_relu_bwd_f32(p->dZ, 2 * i_next, l.Y, l.ldy,
-                                          p->use_layernorm ? l.rstd : nullptr, l.Y, l.ldy, n,
-                                          l.n_out, p->use_layernorm, 1, s));
+            GIST_TRY(ln_relu_bwd_ex(p->dZ, 2 * i_next, l.Y, l.ldy,
+                                    p->use_layernorm ? l.rstd : nullptr, l.Y, l.ldy, n, l.n_out,
+                                    p->use_layernorm, 1, h3.layer[k].on ? h3.rowmax : nullptr, st));
             dy = l.Y;
             lddy = l.ldy;
+        }
+        if (h3.layer[k].on) {
+            // bias gradient + column maxima of dY_k, one read of dY_k -> both split layouts
+            // (row maxima came from the LayerNorm backward), then dZ_k and dW_k on the splits
+            const H3Layer &hl = h3.layer[k];
+            GIST_TRY(colsum_ex(dy, lddy, n, l.n_out, p->partials, l.db, h3.pmax, h3.colmax, st));
+            {
+                Scope sc(p->timer, 3, 0, 0, 0, st);
+                H3Dual d{};
+                d.src = dy; d.ld = lddy; d.rows = n; d.cols = l.n_out;
+                d.rowmax = h3.rowmax; d.colmax = h3.colmax;
+                d.dst_r = k > 0 ? h3.dYs : nullptr; d.inv_r = h3.inv_dyr;
+                d.dst_t = h3.dYsT; d.inv_t = h3.inv_dyt;
+                GIST_TRY(h3_dual_split(d, st));
+            }
+            if (k > 0) {
+                Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
+                GIST_TRY(h3_gemm_presplit("gist_sage_step", h3.dYs, h3.inv_dyr, hl.WsT, hl.inv_wt,
+                                          nullptr, p->dZ, 2 * l.n_in, n, 2 * l.n_in, l.n_out, st));
+            }
+            {
+                Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
+                GIST_TRY(h3_gemm_presplit("gist_sage_step", h3.dYsT, h3.inv_dyt, hl.ZsT, hl.inv_zt,
+                                          nullptr, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in, n, st));
+            }
+            if (k > 0) {
+                if (drop)
+                    GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
+                                              offs[k], s));
+                Scope sc(p->timer, 0, n, n, l.n_in, st);
+                GIST_TRY(gist_spmm_csr_f32(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                           2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+            }
+            continue;
         }
         if (overlap_dw) {
             // dY_k is complete on the main stream: fork dW_k / db_k to the side stream, where

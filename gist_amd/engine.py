@@ -229,8 +229,18 @@ class SageEngine(object):
         P.t_rowptr, P.t_col = batcher.t_rowptr.data_ptr(), batcher.t_col.data_ptr()
         P.col_capacity = batcher.col.numel()
         P.norm, P.labels = batcher.norm.data_ptr(), batcher.lab.data_ptr()
+        # split projection operands kept by the step (include/gist_hip.h, h3_workspace): sized by
+        # the library for these shapes; 0 bytes = mode 'f32' or no layer large enough
+        P.n_max = self.n_max
+        P.feat_absmax = float(batcher.feat.abs().max().item()) if batcher.feat.numel() else 0.0
+        import ctypes
+        need = _lib.load().gist_step_h3_workspace_bytes(ctypes.byref(P))
+        self._h3_ws = None
+        if need > 0 and os.environ.get('GIST_STEP_H3', '1') != '0':
+            self._h3_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            P.h3_workspace, P.h3_workspace_bytes = self._h3_ws.data_ptr(), need
         self.plan = P
-        self._plan_keep = (batcher, g, self._ws, self._ws2)           # keep every buffer alive
+        self._plan_keep = (batcher, g, self._ws, self._ws2, self._h3_ws)     # keep every buffer alive
         return P
 
     def enable_timer(self, capacity):

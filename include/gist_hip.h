@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 4 */
+int gist_abi_version(void);   /* currently 5 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -131,8 +131,8 @@ int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
 /* How the three entry points above form their products on shapes large enough to fill the
  * chip (>= 64 output tiles of 128x128, >= 16 GFLOP, 16-byte aligned operands, workspace of
  * gist_gemm_workspace_bytes): mode 1 (default; GIST_GEMM_MODE=f16x3) splits each fp32 operand
- * once into two f16 halves under one power-of-two scale per operand (22 significant bits)
- * and accumulates ah.bh + ah.bl + al.bh in fp32 on v_mfma_f32_32x32x16_f16 -- fp32-level
+ * once into two f16 halves under one power-of-two scale per operand row (22 significant bits)
+ * and accumulates ah.bh + ah.bl + al.bh in fp32 on v_mfma_f32_16x16x32_f16 -- fp32-level
  * accuracy (error against fp64 equal to mode 0's, tests/test_gemm_h3_gpu.py) at 1/5 of the
  * matrix-core time; mode 0 (GIST_GEMM_MODE=f32) keeps every shape on v_mfma_f32_32x32x2_f32.
  * Inputs and outputs are fp32 in both modes; small and skinny shapes always take mode 0's
@@ -319,13 +319,27 @@ typedef struct gist_step_plan {
     int32_t *rowptr, *col, *t_rowptr, *t_col; int64_t col_capacity;
     float *norm; int32_t *labels;
     struct gist_timer *timer;      /* NULL = no timing */
+    /* Split projection path inside the step (gist_gemm_set_mode 1): with h3_workspace set the
+     * step keeps the f16-split operands of its large projections itself -- activations are split
+     * (with dropout applied on the fly) by one kernel per layer that emits both the forward and
+     * the weight-gradient layout, weights once per step, gradients once per layer with the row
+     * and column maxima taken from the LayerNorm-backward and bias-gradient kernels -- instead
+     * of once per GEMM call.  n_max = rows the batch buffers were sized for; feat_absmax = an
+     * upper bound of |feat| (0 = unknown: layer 0 then takes the per-call path).  Size the
+     * workspace with gist_step_h3_workspace_bytes; NULL / too small = per-call path. */
+    int64_t n_max;
+    float feat_absmax;
+    void *h3_workspace; int64_t h3_workspace_bytes;
 } gist_step_plan;
+
+/* Bytes of h3_workspace the plan's shapes need (0: no layer qualifies, or mode 0). Host function. */
+int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream by the step
  * driver around every SpMM and GEMM call (what bench.py's `roofline` is computed from).
  * kind: 0 = SpMM (m = rows, n = source rows, k = width), 1 = GEMM call (m, n, k; in mode 1 it
  * includes the split pre-pass), 2 = the split GEMM's main kernel alone (nested in a kind-1
- * record). */
+ * record), 3 = split pre-pass work of the step outside a GEMM call (weights, gradients). */
 typedef struct gist_timer gist_timer;
 gist_timer *gist_timer_create(int64_t capacity);
 void gist_timer_destroy(gist_timer *t);

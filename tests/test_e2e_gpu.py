@@ -527,6 +527,39 @@ def test_metric_config_hidden4096_vs_float64(mode):
         hip.gemm_mode(prev)
 
 
+def test_step_kept_split_operands_equal_per_call_splits(monkeypatch):
+    """Metric configuration, dropout 0.2, GEMM mode f16x3: the native step that keeps its own
+    split operands (dropout applied inside the activation split, one split of W per step,
+    gradient maxima from the LayerNorm-backward / bias-gradient kernels) against the native
+    step that splits inside every gist_gemm_* call (GIST_STEP_H3=0).  Same dropout stream, same
+    arithmetic up to the operand scales: losses of 3 steps within 2e-5, parameters close."""
+    from gist_amd import hip
+    prev = hip.gemm_mode()
+    try:
+        runs = {}
+        for tag, env in (('per_call', '0'), ('kept', '1')):
+            monkeypatch.setenv('GIST_STEP_H3', env)
+            ds, it, eng, dims, params = _metric_config_engine('f16x3')
+            eng.p_drop = 0.2
+            it.bind(eng)
+            assert (eng.plan.h3_workspace is not None) == (tag == 'kept')
+            eng.plan.p_drop = 0.2
+            losses = []
+            for j, batch in enumerate(it):
+                losses.append(float(eng.train_step(batch, 0.01, 0.0).item()))
+                if j == 2:
+                    break
+            runs[tag] = (losses, eng.arena.params.clone())
+        la, lb = runs['per_call'][0], runs['kept'][0]
+        assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+        assert la[0] > 3.0 and abs(la[0] - la[2]) > 1e-3          # it did train, with dropout
+        d = (runs['per_call'][1] - runs['kept'][1]).abs()
+        assert d.mean().item() < 1e-5 and (d > TOL).float().mean().item() < 2e-2, \
+            (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+    finally:
+        hip.gemm_mode(prev)
+
+
 def test_cluster_iter_partitions_on_cache_miss(tmp_path, monkeypatch):
     """sampler.py:44-53: without a cache file ClusterIter partitions the train graph itself
     (here: gist_partition_graph instead of METIS), writes the reference's .npy format and
