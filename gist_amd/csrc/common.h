@@ -50,7 +50,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 // split operands itself (the step driver).  Split operand = [rows][h3_kpad(k)] 32-bit words
 // + one inverse scale (power of two) per row.
 int64_t h3_kpad(int64_t k);
-bool h3_eligible(int64_t m, int64_t n, int64_t k);
+bool h3_eligible(int64_t m, int64_t n, int64_t k);        // a call that splits its own operands
+bool h3_eligible_kept(int64_t m, int64_t n, int64_t k);   // operands split once, kept by the step
 struct H3Dual {                       // one read of src[rows, cols] -> up to two split operands
     const float *src; int64_t ld; int64_t rows, cols;
     float p; uint64_t seed, offset;   // dropout applied on the fly (p = 0: none), gist_dropout_f32's stream

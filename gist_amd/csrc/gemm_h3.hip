@@ -526,11 +526,13 @@ int h3_mode() {
 int64_t h3_kpad(int64_t k) { return ceil_div(k, H3_BK) * H3_BK; }
 
 // Shapes the split path takes: enough 128x128 tiles to occupy the chip and enough flops to
-// pay for the pre-pass (measured break-even ~20 GFLOP, scripts/h3_bench.py).  Everything else
-// stays on the fp32 kernel.
-bool h3_eligible(int64_t m, int64_t n, int64_t k) {
+// pay for the pre-pass.  Break-even measured at ~20 GFLOP when every call splits its own
+// operands (scripts/h3_bench.py) and at ~4 GFLOP inside the step, which shares one split of an
+// operand between the GEMMs that use it (bench.py --n-hidden 1024: 0.606 -> 0.551 ms/step).
+// Everything else stays on the fp32 kernel.
+static bool h3_shape_ok(int64_t m, int64_t n, int64_t k, double default_min_gflop) {
     if (h3_mode() != 1) return false;
-    const double min_gflop = getenv("GIST_H3_MIN_GFLOP") ? atof(getenv("GIST_H3_MIN_GFLOP")) : 16.0;
+    const double min_gflop = getenv("GIST_H3_MIN_GFLOP") ? atof(getenv("GIST_H3_MIN_GFLOP")) : default_min_gflop;
     const int min_tiles = getenv("GIST_H3_MIN_TILES") ? atoi(getenv("GIST_H3_MIN_TILES")) : 64;
     if (m < 64 || n < 64 || k < 64) return false;
     if (ceil_div(m, H3_T) * ceil_div(n, H3_T) < min_tiles) return false;
@@ -538,6 +540,8 @@ bool h3_eligible(int64_t m, int64_t n, int64_t k) {
     if (h3_kpad(k) >= (1LL << 22)) return false;
     return true;
 }
+bool h3_eligible(int64_t m, int64_t n, int64_t k) { return h3_shape_ok(m, n, k, 16.0); }
+bool h3_eligible_kept(int64_t m, int64_t n, int64_t k) { return h3_shape_ok(m, n, k, 4.0); }
 
 // workspace: [inv_a: m floats][inv_b: n floats][max bits: m + n] padded to 256 B, then the splits
 static inline int64_t h3_head_bytes(int64_t m, int64_t n) { return ceil_div((m + n) * 8, 256) * 256; }

@@ -274,9 +274,16 @@ __global__ void colsum_stage2_kernel(const float *__restrict__ partials, int chu
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d) return;
     if (outmax != nullptr) {
-        float m = 0.f;
-        for (int k = 0; k < chunks; ++k) m = fmaxf(m, pmax[(int64_t)k * d + c]);
-        outmax[c] = m;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+        int k = 0;
+        for (; k + 3 < chunks; k += 4) {
+            m0 = fmaxf(m0, pmax[(int64_t)k * d + c]);
+            m1 = fmaxf(m1, pmax[(int64_t)(k + 1) * d + c]);
+            m2 = fmaxf(m2, pmax[(int64_t)(k + 2) * d + c]);
+            m3 = fmaxf(m3, pmax[(int64_t)(k + 3) * d + c]);
+        }
+        for (; k < chunks; ++k) m0 = fmaxf(m0, pmax[(int64_t)k * d + c]);
+        outmax[c] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;

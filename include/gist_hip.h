@@ -325,7 +325,8 @@ typedef struct gist_step_plan {
      * the weight-gradient layout, weights once per step, gradients once per layer with the row
      * and column maxima taken from the LayerNorm-backward and bias-gradient kernels -- instead
      * of once per GEMM call.  n_max = rows the batch buffers were sized for; feat_absmax = an
-     * upper bound of |feat| (0 = unknown: layer 0 then takes the per-call path).  Size the
+     * upper bound of |feat| (0 = unknown: layer 0 then takes the per-call path).  A layer qualifies
+     * when its three projections have >= 64 output tiles and >= 4 GFLOP each.  Size the
      * workspace with gist_step_h3_workspace_bytes; NULL / too small = per-call path. */
     int64_t n_max;
     float feat_absmax;
