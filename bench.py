@@ -347,6 +347,13 @@ def main():
                 h_ms = sum(ms for ms, _ in h3)
                 h_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in h3)
                 h_ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+                h_traffic = None
+                tf = os.path.join(ROOT, 'profiles', 'gemm_h3_traffic.json')
+                if os.path.exists(tf):
+                    try:
+                        h_traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+                    except Exception:
+                        h_traffic = None
                 out['roofline'] = {
                     'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_16x16x32_f16, 3 MFMA flops per '
                               'algorithmic flop: ah.bh + ah.bl + al.bh)',
@@ -355,7 +362,9 @@ def main():
                     'mfma_flops_per_algorithmic_flop': 3,
                     'mfma_rate_tflops': round(3 * h_ach, 1),
                     'frac_mfma_rate_of_peak': round(3 * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
-                    'traffic': None, 'launches': len(h3),
+                    # fabric bytes per launch from PMC (profiles/gemm_h3_traffic.json; Infinity-Cache
+                    # hits are counted): 8 XCDs x (8 + 8) operand panels, 3.6x the operand bytes
+                    'traffic': h_traffic, 'launches': len(h3),
                     'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
                     'avg_launch_ms': round(h_ms / max(len(h3), 1), 5),
                     'share_of_step': round(h_ms * every / (elapsed * 1e3), 4),
