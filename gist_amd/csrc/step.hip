@@ -150,7 +150,8 @@ H3Step h3_layout(const gist_step_plan *p, char *base) {
         const double bound = k == 0 ? (double)p->feat_absmax * keep
                                     : (p->use_layernorm ? sqrt((double)(l.n_in > 1 ? l.n_in - 1 : 1)) * keep : 0.0);
         hl.on = bound > 0.0 && h3_eligible_kept(n, o, i2) && h3_eligible_kept(o, i2, n) &&
-                (k == 0 || h3_eligible_kept(n, i2, o)) && l.ldz % 4 == 0 && l.ldy % 4 == 0;
+                (k == 0 || h3_eligible_kept(n, i2, o)) && l.ldz % 4 == 0 && l.ldy % 4 == 0 &&
+                aligned16(l.W) && aligned16(l.Z) && aligned16(l.Y) && aligned16(l.dW);
         if (!hl.on) continue;
         h.any = true;
         hl.shift = bound_shift(bound);

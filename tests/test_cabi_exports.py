@@ -47,6 +47,29 @@ def test_host_only_entry_points():
     assert L.gist_gemm_workspace_bytes(2046, 41, 8192) > 0             # skinny: fp32 split-K
     assert L.gist_gemm_workspace_bytes(2046, 41, 8192) < 64 << 20
     assert L.gist_gemm_set_mode(7) == -1 and b'mode' in L.gist_last_error()
+    # the step's own split workspace: sized from the plan's shapes, host side only
+    P = _lib.StepPlan()
+    P.n_layers, P.use_layernorm, P.p_drop = 3, 1, 0.2
+    for k, (i, o) in enumerate([(602, 4096), (4096, 4096), (4096, 41)]):
+        P.layer[k].n_in, P.layer[k].n_out = i, o
+        P.layer[k].ldz, P.layer[k].ldy = 2 * i, o if o % 4 == 0 else 44
+    P.n_max, P.feat_absmax = 2200, 5.0
+    assert L.gist_gemm_set_mode(1) == 0
+    need = L.gist_step_h3_workspace_bytes(ctypes.byref(P))
+    # layers 0 and 1 qualify: Zs + ZsT + Ws (+ WsT) + the shared gradient splits
+    kp = lambda k: -(-k // 32) * 32
+    lower = 4 * (2200 * kp(1204) + 1204 * kp(2200) + 4096 * kp(1204)
+                 + 2200 * kp(8192) + 8192 * kp(2200) + 2 * 4096 * kp(8192)
+                 + 2200 * kp(4096) + 4096 * kp(2200))
+    assert lower <= need < lower + (8 << 20), (need, lower)
+    P.feat_absmax = 0.0                                                # unknown bound: layer 0 opts out
+    assert 0 < L.gist_step_h3_workspace_bytes(ctypes.byref(P)) < need
+    P.use_layernorm = 0                                                # no LayerNorm bound: layer 1 too
+    assert L.gist_step_h3_workspace_bytes(ctypes.byref(P)) == 0
+    assert L.gist_gemm_set_mode(0) == 0
+    P.use_layernorm, P.feat_absmax = 1, 5.0
+    assert L.gist_step_h3_workspace_bytes(ctypes.byref(P)) == 0        # mode f32: nothing kept
+    assert L.gist_step_h3_workspace_bytes(None) == 0
     assert L.gist_gemm_set_mode(prev) == 0
     assert L.gist_colsum_partials(0) == 0 and L.gist_colsum_partials(129) == 3
     # argument validation happens before any device work
