@@ -395,9 +395,10 @@ def test_config4_amazon_like_F100_C47_L4():
     _check(*_steps_vs_oracle(ds, 10, 512, 4, 3, p_seed=2))
 
 
-def _metric_config_engine(mode):
+def _metric_config_engine(mode, hidden=4096):
     """Engine + first batches of the configuration the metric is quoted on (Reddit-like batch,
-    n_hidden=4096, L=2, full width on one GPU), projections in the given GEMM mode."""
+    n_hidden=4096, L=2, full width on one GPU; hidden = 4096/N: the per-rank sub-GCN of the
+    N-GPU points), projections in the given GEMM mode."""
     from gist_amd import datasets, hip, _lib
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
@@ -408,10 +409,11 @@ def _metric_config_engine(mode):
     it = EngineClusterIter(ds.name, g, len(ds.par_li), 20,
                            np.arange(g.number_of_nodes(), dtype=np.int64),
                            par_li=[p.copy() for p in ds.par_li], device=DEV)
-    dims = dims_for(602, 4096, 41, 2)
+    dims = dims_for(602, hidden, 41, 2)
     eng = SageEngine(dims, True, 0.0, it.n_max, DEV)
-    big = _lib.load().gist_gemm_workspace_bytes(it.n_max, 4096, 8192)
-    assert (big > (1 << 27)) == (mode == 'f16x3')      # the step really runs on the split path
+    if hidden == 4096:
+        big = _lib.load().gist_gemm_workspace_bytes(it.n_max, 4096, 8192)
+        assert (big > (1 << 27)) == (mode == 'f16x3')      # the step really runs on the split path
     rs = np.random.RandomState(3)
     params = []
     for (i, o) in dims:
@@ -422,11 +424,13 @@ def _metric_config_engine(mode):
     return ds, it, eng, dims, params
 
 
-@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
-def test_metric_config_hidden4096_vs_oracle(mode):
-    """Metric configuration, 2 full training steps against the oracle on the same batches, with
-    the projections on the fp32 matrix-core path and on the f16x3 split path (every GEMM of
-    this step but the 41-wide class layer takes it): the same 1e-4 bar on the outputs for both
+@pytest.mark.parametrize('mode,hidden', [('f32', 4096), ('f16x3', 4096), ('f16x3', 2048),
+                                         ('f16x3', 1024)])
+def test_metric_config_hidden4096_vs_oracle(mode, hidden):
+    """Metric configuration (and the per-rank widths of the 2- and 4-GPU points), 2 full training
+    steps against the oracle on the same batches, with the projections on the fp32 matrix-core
+    path and on the f16x3 split path (every GEMM of the 4096-wide step but the 41-wide class
+    layer takes it): the same 1e-4 bar on the outputs for both
     (gradients at this width are compared against float64 in the next test: a ReLU input at
     rounding level flips its mask in any fp32 implementation, the oracle's included)."""
     from gist_amd import hip
@@ -434,8 +438,10 @@ def test_metric_config_hidden4096_vs_oracle(mode):
     from oracle import train_oracle as TO
     prev = hip.gemm_mode()
     try:
-        ds, it, eng, dims, params = _metric_config_engine(mode)
+        ds, it, eng, dims, params = _metric_config_engine(mode, hidden)
         it.bind(eng)
+        if mode == 'f16x3':       # widths 2048 / 1024: layer 1 (and 0) keep their split operands
+            assert eng.plan.h3_workspace is not None
         g = ds.g
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
                            g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
