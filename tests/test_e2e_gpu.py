@@ -191,7 +191,21 @@ def test_full_size_step_properties():
 def test_native_step_equals_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden):
     """gist_sage_step (one C-ABI call per iteration) issues the same kernels in the same
     order as the Python op-by-op path: parameters after 4 steps with dropout must be
-    BITWISE identical, and the native HIP-event timer must see 5*(L+1)-2 launches/step."""
+    BITWISE identical, and the native HIP-event timer must see 5*(L+1)-2 launches/step.
+    (GEMM mode f32: in mode f16x3 the step keeps its own split operands under different
+    scales than a per-call split -- test_step_kept_split_operands_equal_per_call_splits.)"""
+    from gist_amd import datasets, hip
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+    prev_mode = hip.gemm_mode()
+    hip.gemm_mode('f32')
+    try:
+        _native_vs_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden)
+    finally:
+        hip.gemm_mode(prev_mode)
+
+
+def _native_vs_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden):
     from gist_amd import datasets
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
@@ -226,6 +240,52 @@ def test_native_step_equals_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden
         results.append((eng.arena.params.clone(), torch.stack(losses)))
     assert torch.equal(results[0][0], results[1][0])
     assert torch.equal(results[0][1], results[1][1])
+
+
+@pytest.mark.parametrize('n_layers,n_feats,n_hidden', [(2, 64, 2048), (3, 302, 2048)])
+def test_native_step_kept_splits_small_batch(n_layers, n_feats, n_hidden):
+    """A ~500-row batch at width 2048 (projections of 4-8 GFLOP: above the kept-split threshold,
+    below the per-call one; batch rows not a multiple of 32, so the transposed splits are
+    zero-padded along k): the native step in GEMM mode f16x3 against the same step in mode f32,
+    same dropout stream -- losses of 4 steps within 1e-4 (of their magnitude: this toy run
+    diverges to losses ~20), parameters close."""
+    from gist_amd import datasets, hip
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+    ds = datasets.toy(seed=9, n=3000, n_blocks=30, n_feats=n_feats, n_classes=6, train_frac=1.0)
+    g = ds.g
+    nid = np.arange(g.number_of_nodes(), dtype=np.int64)
+    dims = dims_for(n_feats, n_hidden, 6, n_layers)
+    prev = hip.gemm_mode()
+    out = {}
+    try:
+        for mode in ('f32', 'f16x3'):
+            hip.gemm_mode(mode)
+            random.seed(4)
+            it = EngineClusterIter('toy', g, len(ds.par_li), 5, nid,
+                                   par_li=[p.copy() for p in ds.par_li], device=DEV)
+            eng = SageEngine(dims, True, 0.2, it.n_max, DEV, seed=11)
+            gen = torch.Generator().manual_seed(1)
+            for k, (i, o) in enumerate(dims):
+                s_ = 1.0 / np.sqrt(2 * i)
+                eng.arena.W[k].copy_((torch.rand(o, 2 * i, generator=gen) - 0.5) * 2 * s_)
+                eng.arena.b[k].copy_((torch.rand(o, generator=gen) - 0.5) * 2 * s_)
+            it.bind(eng)
+            assert (eng.plan.h3_workspace is not None) == (mode == 'f16x3')
+            losses = []
+            for j, b in enumerate(it):
+                assert b.n % 32 != 0 or j > 0
+                losses.append(float(eng.train_step(b, 0.01, 5e-4).item()))
+                if j == 3:
+                    break
+            out[mode] = (losses, eng.arena.params.clone())
+    finally:
+        hip.gemm_mode(prev)
+    la, lb = out['f32'][0], out['f16x3'][0]
+    assert all(abs(a - b) <= TOL * max(1.0, abs(a)) for a, b in zip(la, lb)), (la, lb)
+    d = (out['f32'][1] - out['f16x3'][1]).abs()
+    assert d.mean().item() < 2e-5 and (d > TOL).float().mean().item() < 3e-2, \
+        (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
 
 
 def test_ist_wide_block_algebra_properties():
