@@ -325,14 +325,15 @@ struct H3Args {
     int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ void h3_dma_image(const uint32_t *ubase, const uint32_t (&off)[4],
+template <int NI>
+__device__ __forceinline__ void h3_dma_image(const uint32_t *ubase, const uint32_t (&off)[NI],
                                              char *image, int wave) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(ubase), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < NI; ++jj)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc, (__attribute__((address_space(3))) void *)(image + (4 * wave + jj) * 1024), 16,
+            rsrc, (__attribute__((address_space(3))) void *)(image + (NI * wave + jj) * 1024), 16,
             off[jj], 0, 0, 0);
 }
 
@@ -350,20 +351,28 @@ typedef float h3_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int h3_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
 
+template <int NI>
 __device__ __forceinline__ void h3_dma_offsets(int64_t ld, int rows, int row0, int wave, int lane,
-                                                uint32_t (&off)[4]) {
+                                                uint32_t (&off)[NI]) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int p = 64 * (4 * wave + jj) + lane;
+    for (int jj = 0; jj < NI; ++jj) {
+        const int p = 64 * (NI * wave + jj) + lane;
         const int r = p >> 3, slot = p & 7;
         const int dr = min(r, rows - 1 - row0);
         off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ h3_swz(r)) << 2)) * 4);
     }
 }
 
+// TM = rows of the A tile: 128, or 64 for outputs with fewer than two 128x128 tiles per CU
+// (wave tile 32 x 64, 24 MFMAs per k tile, 24 KiB per stage, 512 instead of 256 workgroups on a
+// 2046 x 2048 output).
+template <int TM>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     extern __shared__ __attribute__((aligned(16))) char h3_smem[];
-    constexpr int T = H3_T;
+    constexpr int T = H3_T;                      // columns of the output tile = rows of the B tile
+    constexpr int NI = TM / 32;                  // 16-row A slabs per wave (wave tile TM/2 x 64)
+    constexpr int A_BYTES = TM * 128;            // A image of one stage
+    constexpr int BUF_BYTES = A_BYTES + H3_IMG * 4;
 
     const int nwg = g.tiles_m * g.tiles_n;
     const int orig = blockIdx.x;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     const int gsz = min(g.tiles_m - first_m, GM);
     const int bm = first_m + (L % width) % gsz;
     const int bn = (L % width) / gsz;
-    const int row0 = bm * T, col0 = bn * T;
+    const int row0 = bm * TM, col0 = bn * T;
     const int n_kt = g.kpad / H3_BK;
 
     const int lane = threadIdx.x & 63;
@@ -384,35 +393,39 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int rr = lane & 15, kg = lane >> 4;
 
-    h3_f32x4 acc[4][4];
+    h3_f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    uint32_t offA[4], offB[4];
-    h3_dma_offsets(g.lda, g.m, row0, wave, lane, offA);
-    h3_dma_offsets(g.ldb, g.n, col0, wave, lane, offB);
+    uint32_t offA[NI], offB[4];
+    h3_dma_offsets<NI>(g.lda, g.m, row0, wave, lane, offA);
+    h3_dma_offsets<4>(g.ldb, g.n, col0, wave, lane, offB);
     const uint32_t *originA = g.a + (int64_t)row0 * g.lda;
     const uint32_t *originB = g.b + (int64_t)col0 * g.ldb;
     auto dma = [&](int buf, int kt) {
-        char *sa = h3_smem + buf * H3_BUF_BYTES;
-        h3_dma_image(originA + (int64_t)kt * H3_BK, offA, sa, wave);
-        h3_dma_image(originB + (int64_t)kt * H3_BK, offB, sa + H3_IMG * 4, wave);
+        char *sa = h3_smem + buf * BUF_BYTES;
+        h3_dma_image<NI>(originA + (int64_t)kt * H3_BK, offA, sa, wave);
+        h3_dma_image<4>(originB + (int64_t)kt * H3_BK, offB, sa + A_BYTES, wave);
     };
 
     // fragment byte offsets inside an image: [16-row slab][hi/lo]
-    int fa[4][2], fb[4][2];
+    int fa[NI][2], fb[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ar = wm * 64 + i * 16 + rr, br = wn * 64 + i * 16 + rr;
+    for (int lo = 0; lo < 2; ++lo) {
+        const int c = 2 * kg + lo;
 #pragma unroll
-        for (int lo = 0; lo < 2; ++lo) {
-            const int c = 2 * kg + lo;
+        for (int i = 0; i < NI; ++i) {
+            const int ar = wm * (TM / 2) + i * 16 + rr;
             fa[i][lo] = ar * 128 + ((c ^ h3_swz(ar)) << 4);
-            fb[i][lo] = br * 128 + ((c ^ h3_swz(br)) << 4) + H3_IMG * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int br = wn * 64 + i * 16 + rr;
+            fb[i][lo] = br * 128 + ((c ^ h3_swz(br)) << 4) + A_BYTES;
         }
     }
 
@@ -427,30 +440,30 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         if constexpr (has_next) dma(cur ^ 1, kt + 1);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        const char *img = h3_smem + cur * H3_BUF_BYTES;
+        const char *img = h3_smem + cur * BUF_BYTES;
         __builtin_amdgcn_s_setprio(1);
 #ifndef H3_PROBE_NO_MFMA
-        f16x8 ah[4], al[4], bh[4], bl[4];
+        f16x8 ah[NI], al[NI], bh[4], bl[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ah[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][0]);
+        for (int i = 0; i < NI; ++i) ah[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][0]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) bh[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][0]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) bl[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) al[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][1]);
+        for (int i = 0; i < NI; ++i) al[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
 
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)row0 * g.ldc + col0;
-    const int rows_valid = min(g.m - row0, T);
+    const int rows_valid = min(g.m - row0, TM);
     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
         cbase, 0, (int)((int64_t)rows_valid * g.ldc * 4), 0x00020000);
     const uint32_t ldc_b = (uint32_t)g.ldc * 4;
@@ -487,28 +500,31 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     for (int j = 0; j < 4; ++j) {
         const int cl = wn * 64 + j * 16 + rr;
         const bool ok = col0 + cl < g.n;
-        cvoff[j] = ok ? (uint32_t)(wm * 64 + 4 * kg) * ldc_b + (uint32_t)cl * 4 : 0x7fffffffu;
+        cvoff[j] = ok ? (uint32_t)(wm * (TM / 2) + 4 * kg) * ldc_b + (uint32_t)cl * 4 : 0x7fffffffu;
         bv[j] = (g.bias != nullptr && ok) ? g.bias[col0 + cl] : 0.f;
         sb[j] = ok ? g.inv_b[col0 + cl] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int rl = i * 16 + e;
             const uint32_t roff = (uint32_t)rl * ldc_b;
-            const int grow = min(row0 + wm * 64 + 4 * kg + rl, g.m - 1);
+            const int grow = min(row0 + wm * (TM / 2) + 4 * kg + rl, g.m - 1);
             const float sa = g.inv_a[grow];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = fmaf(acc[i][j][e] * sa, sb[j], bv[j]);
-                if (rows_valid == T)
+                if (rows_valid == TM)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j], roff, 0);
                 else
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j] + roff, 0, 0);
             }
         }
 }
+
+template __global__ void gemm_h3_kernel<128>(H3Args);
+template __global__ void gemm_h3_kernel<64>(H3Args);
 
 // ---- host side ----------------------------------------------------------------------------
 static int g_h3_mode = -1;      // -1: read GIST_GEMM_MODE on first use
@@ -557,9 +573,12 @@ int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, c
     const int64_t kpad = h3_kpad(k);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel<128>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * H3_BUF_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H3_BUF_BYTES);
         if (e != hipSuccess) {
             set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return GIST_ELAUNCH;
@@ -569,11 +588,18 @@ int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, c
     H3Args g;
     g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.inv_a = inv_a; g.inv_b = inv_b; g.bias = bias;
     g.c = c; g.ldc = ldc; g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
-    g.tiles_m = (int)ceil_div(m, H3_T);
     g.tiles_n = (int)ceil_div(n, H3_T);
+    // 64-row A tiles when 128-row tiles would leave CUs without a second workgroup
+    const char *env_tm = getenv("GIST_H3_TM");       // dev: force 64 / 128
+    const bool tm64 = env_tm ? atoi(env_tm) == 64 : ceil_div(m, 128) * g.tiles_n < 512;
+    g.tiles_m = (int)ceil_div(m, tm64 ? 64 : 128);
     const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel alone
-    hipLaunchKernelGGL(gemm_h3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256),
-                       2 * H3_BUF_BYTES, st, g);
+    if (tm64)
+        hipLaunchKernelGGL(gemm_h3_kernel<64>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256),
+                           2 * (64 * 128 + H3_IMG * 4), st, g);
+    else
+        hipLaunchKernelGGL(gemm_h3_kernel<128>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256),
+                           2 * H3_BUF_BYTES, st, g);
     timer_end(tl_timer, slot, st);
     return launch_status(name);
 }

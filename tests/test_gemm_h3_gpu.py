@@ -68,9 +68,18 @@ SHAPES = [('nt', 2046, 4096, 1204), ('nt', 2046, 4096, 8192), ('nn', 2046, 8192,
           ('nn', 1500, 1024, 777), ('tn', 1024, 1204, 2046)]
 
 
+@pytest.fixture(params=['auto', 'a_tile_64', 'a_tile_128'])
+def tile(request, monkeypatch):
+    """Both A-tile heights of the main kernel on every shape (GIST_H3_TM is read per call;
+    'auto' = the launcher's own choice)."""
+    if request.param != 'auto':
+        monkeypatch.setenv('GIST_H3_TM', request.param.split('_')[-1])
+    return request.param
+
+
 @pytest.mark.parametrize('form,m,n,k', SHAPES)
 @pytest.mark.parametrize('kind', ['normal', 'train', 'grad'])
-def test_split_error_matches_fp32_mfma(hip, form, m, n, k, kind):
+def test_split_error_matches_fp32_mfma(hip, tile, form, m, n, k, kind):
     from gist_amd import _lib
     L = _lib.load()
     hip.gemm_mode('f16x3')
@@ -99,7 +108,7 @@ def test_split_error_matches_fp32_mfma(hip, form, m, n, k, kind):
     assert torch.isfinite(y3).all()
 
 
-def test_split_is_exact_on_f16_representable_operands(hip):
+def test_split_is_exact_on_f16_representable_operands(hip, tile):
     """Small integers are exact f16 values (lo = 0) and every partial sum is an integer below
     2^24: both modes must return the exact product, bit for bit."""
     hip.gemm_mode('f16x3')
@@ -117,7 +126,7 @@ def test_split_is_exact_on_f16_representable_operands(hip):
     assert torch.equal(_run(hip, 'tn', eye, b, None, 1024, 1152), b)
 
 
-def test_split_zero_operand_and_output_window(hip):
+def test_split_zero_operand_and_output_window(hip, tile):
     """An all-zero operand (absmax 0) gives zeros; nothing outside the [m, n] window is written
     when m, n are not tile multiples and the output is a window of a wider buffer."""
     hip.gemm_mode('f16x3')
