@@ -45,6 +45,7 @@ SIGNATURES = {
     'gist_gemm_tn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_ln_relu_fwd_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _f, _p]),
     'gist_ln_relu_bwd_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p]),
+    'gist_gemm_nn_dropout_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _u64, _u64, _p, _i64, _p]),
     'gist_dropout_f32': (_int, [_p, _i64, _i64, _i64, _f, _u64, _u64, _p]),
     'gist_colsum_partials': (_i64, [_i64]),
     'gist_colsum_f32': (_int, [_p, _i64, _i64, _i64, _p, _p, _p]),

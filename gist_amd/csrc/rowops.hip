@@ -5,6 +5,8 @@
 //
 // Each kernel streams its rows once or twice with 16-B accesses where alignment
 // allows; rows are owned by one wave (d <= 1024) or one 256-thread workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gist {
@@ -215,6 +217,62 @@ __global__ void dropout_kernel(float *__restrict__ z, int64_t ldz, int64_t n_row
         const int64_t r = i / d, c = i - r * d;
         float *q = z + r * ldz + c;
         *q = *q * keep_scale(seed, offset + (uint64_t)i, p, scale);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dZ of a narrow layer (the class layer: dY is [n, C], C <= 64) with its dropout mask:
+//   dz[i][j] = keep(i, j) * sum_c dy[i][c] * w[c][j]
+// The product is 2nCK flops against 4nK bytes of output: store bound.  A block owns 16 rows x
+// 1024 columns; dy's 16 rows sit in LDS ([c][row]: one broadcast ds_read_b128 per 4 rows), a
+// thread keeps 16 rows x 4 columns of sums, reads each w[c][j..j+3] once and applies the mask
+// of gist_dropout_f32 (same generator, same element index) to what it stores.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void narrow_nn_drop_kernel(
+    const float *__restrict__ dy, int64_t lddy, const float *__restrict__ w, int64_t ldw,
+    float *__restrict__ dz, int64_t lddz, int n_rows, int n_cols, int kc, float p, float scale,
+    uint64_t seed, uint64_t offset) {
+    __shared__ __attribute__((aligned(16))) float sdy[64][16];
+    const int r0 = blockIdx.y * 16;
+    const int c0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    for (int t = threadIdx.x; t < 64 * 16; t += 256) {
+        const int c = t >> 4, r = t & 15;
+        sdy[c][r] = (c < kc && r0 + r < n_rows) ? dy[(int64_t)(r0 + r) * lddy + c] : 0.f;
+    }
+    __syncthreads();
+    if (c0 >= n_cols) return;
+    float4 acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < kc; ++c) {
+        const float4 wv = *reinterpret_cast<const float4 *>(w + (int64_t)c * ldw + c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(&sdy[c][4 * q]);
+            const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 &a = acc[4 * q + u];
+                a.x = fmaf(dv[u], wv.x, a.x); a.y = fmaf(dv[u], wv.y, a.y);
+                a.z = fmaf(dv[u], wv.z, a.z); a.w = fmaf(dv[u], wv.w, a.w);
+            }
+        }
+    }
+    const uint64_t sm = seed * 0x9E3779B97F4A7C15ULL;
+    const float inv24 = 1.0f / 16777216.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r0 + r >= n_rows) break;
+        float4 v = acc[r];
+        if (p > 0.f) {      // offset and n_cols are even, c0 % 4 == 0: two hashes cover the quad
+            const uint64_t pair = (offset + (uint64_t)(r0 + r) * (uint64_t)n_cols + (uint64_t)c0) >> 1;
+            const uint64_t h0 = splitmix64(pair + sm), h1 = splitmix64(pair + 1 + sm);
+            v.x *= ((float)((uint32_t)h0 >> 8) * inv24 >= p) ? scale : 0.f;
+            v.y *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv24 >= p) ? scale : 0.f;
+            v.z *= ((float)((uint32_t)h1 >> 8) * inv24 >= p) ? scale : 0.f;
+            v.w *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv24 >= p) ? scale : 0.f;
+        }
+        *reinterpret_cast<float4 *>(dz + (int64_t)(r0 + r) * lddz + c0) = v;
     }
 }
 
@@ -474,6 +532,29 @@ extern "C" int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d
     hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(256), 0, as_stream(stream), z, ldz, n_rows,
                        d, p, 1.0f / (1.0f - p), seed, offset);
     return launch_status("gist_dropout_f32");
+}
+
+extern "C" int gist_gemm_nn_dropout_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
+                                        float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                                        float p, uint64_t seed, uint64_t offset, void *workspace,
+                                        int64_t workspace_bytes, gist_stream_t stream) {
+    GIST_REQUIRE(p >= 0.f && p < 1.f, "gist_gemm_nn_dropout_f32: p must be in [0,1)");
+    GIST_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gist_gemm_nn_dropout_f32: negative size");
+    const bool narrow = k >= 1 && k <= 64 && m > 0 && n > 0 && g && w && z && n % 4 == 0 &&
+                        ldw % 4 == 0 && ldz % 4 == 0 && aligned16(w) && aligned16(z) &&
+                        (offset & 1) == 0 && ldg >= k && ldw >= n && ldz >= n &&
+                        m < (1LL << 31) && n < (1LL << 31) &&
+                        !(getenv("GIST_NARROW_NN") && atoi(getenv("GIST_NARROW_NN")) == 0);   // dev A/B
+    if (!narrow) {      // any other shape: the projection kernel, then the mask in place
+        const int rc = gist_gemm_nn_f32(g, ldg, w, ldw, z, ldz, m, n, k, workspace, workspace_bytes, stream);
+        if (rc != GIST_OK || p == 0.f) return rc;
+        return gist_dropout_f32(z, ldz, m, n, p, seed, offset, stream);
+    }
+    hipLaunchKernelGGL(gist::narrow_nn_drop_kernel,
+                       dim3((unsigned)gist::ceil_div(n, 1024), (unsigned)gist::ceil_div(m, 16)), dim3(256),
+                       0, gist::as_stream(stream), g, ldg, w, ldw, z, ldz, (int)m, (int)n, (int)k, p,
+                       p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset);
+    return gist::launch_status("gist_gemm_nn_dropout_f32");
 }
 
 extern "C" int64_t gist_colsum_partials(int64_t n_rows) {

@@ -368,10 +368,12 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
             GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, (gist_stream_t)side));
         }
-        if (k > 0) {      // dZ (before dW on the main stream: it is the last reader of W_k)
+        if (k > 0) {      // dZ (before dW on the main stream: it is the last reader of W_k),
+                          // with its dropout mask
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
-            GIST_TRY(gist_gemm_nn_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n, 2 * l.n_in,
-                                      l.n_out, p->workspace, p->workspace_bytes, s));
+            GIST_TRY(gist_gemm_nn_dropout_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
+                                              2 * l.n_in, l.n_out, drop ? p->p_drop : 0.f, p->seed,
+                                              offs[k], p->workspace, p->workspace_bytes, s));
         }
         if (!overlap_dw) {
             {
@@ -391,14 +393,9 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                    adam_step, (gist_stream_t)side));
         }
         if (k > 0) {
-            if (drop)
-                GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
-                                          offs[k], s));
-            {
-                Scope sc(p->timer, 0, n, n, l.n_in, st);
-                GIST_TRY(gist_spmm_csr_f32(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                           2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
-            }
+            Scope sc(p->timer, 0, n, n, l.n_in, st);
+            GIST_TRY(gist_spmm_csr_f32(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                       2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
         }
     }
     if (overlap) {

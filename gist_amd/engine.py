@@ -373,9 +373,10 @@ class SageEngine(object):
             hip.colsum(dy, A.db[k], self.partials)
             if k > 0:
                 dz = self.dZ[:n * 2 * i].view(n, 2 * i)
-                hip.gemm_nn(dy, A.W[k], dz)
                 if self._drop_offsets:
-                    hip.dropout_(dz, self.p_drop, self.seed, self._drop_offsets[k])
+                    hip.gemm_nn_dropout_(dy, A.W[k], dz, self.p_drop, self.seed, self._drop_offsets[k])
+                else:
+                    hip.gemm_nn_dropout_(dy, A.W[k], dz, 0.0, self.seed, 0)
                 hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
                          accumulate=True)
         return self.loss

@@ -263,6 +263,24 @@ def dropout_(z, p, seed, offset):
     return z
 
 
+def gemm_nn_dropout_(g, w, z, p, seed, offset):
+    """z = dropout(g @ w) with gist_dropout_f32's mask stream (one kernel when g is narrow)."""
+    L = _lib.load()
+    gp, ldg = _mat(g, 'g')
+    wp, ldw = _mat(w, 'w')
+    zp, ldz = _mat(z, 'z')
+    m, k = g.shape
+    n = w.shape[1]
+    if w.shape[0] != k or tuple(z.shape) != (m, n):
+        raise ValueError('gist_amd: gemm_nn_dropout_ shape mismatch')
+    wsp, wsb = _ws_for(m, n, k, g.device)
+    with _Timed('gemm', ('nn', m, n, k)):
+        rc = L.gist_gemm_nn_dropout_f32(gp, ldg, wp, ldw, zp, ldz, m, n, k, float(p), int(seed),
+                                        int(offset), wsp, wsb, _stream())
+    _lib.check(rc, 'gist_gemm_nn_dropout_f32')
+    return z
+
+
 def colsum(g, out, partials=None):
     L = _lib.load()
     gp, ldg = _mat(g, 'g')

@@ -171,6 +171,17 @@ int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float *yhat, int
 int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d, float p,
                      uint64_t seed, uint64_t offset, gist_stream_t stream);
 
+/* z = dropout(g . w): gist_gemm_nn_f32 followed by gist_dropout_f32 on its output (same mask
+ * stream: element index offset + row*n + col), as one call.  For a narrow reduction (k <= 64:
+ * the class layer, whose dY is [rows, n_classes]) the product is store-bound and one kernel
+ * forms the sums in fp32 FMAs and masks what it stores; every other shape runs the two kernels.
+ * p = 0: plain product.  Replaces autograd of nn.Linear wrt its input followed by the
+ * backward of nn.Dropout, modules.py:230-233. */
+int gist_gemm_nn_dropout_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
+                             float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                             float p, uint64_t seed, uint64_t offset,
+                             void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
 /* out[j] = sum_i g[i, j], deterministic two-stage reduction.
  * `partials` must hold gist_colsum_partials(n_rows) * d floats.
  * Replaces autograd of nn.Linear wrt its bias (db), modules.py:233. */

@@ -254,6 +254,33 @@ def test_gemm_identity_asymmetric(hip):
     assert np.array_equal(out.cpu().numpy(), b)
 
 
+@pytest.mark.parametrize('m,n,k,p,offset', [
+    (2046, 8192, 41, 0.2, 0), (300, 1024, 6, 0.5, 123456), (513, 2052, 47, 0.0, 0),
+    (17, 1028, 64, 0.3, 2), (100, 1024, 41, 0.2, 7),      # odd offset: two-kernel path
+    (100, 1030, 41, 0.2, 0),                              # n % 4 != 0: two-kernel path
+    (64, 512, 65, 0.2, 0)])                               # k > 64: two-kernel path
+def test_gemm_nn_dropout_fused(hip, m, n, k, p, offset):
+    """z = dropout(g @ w) in one call == gist_gemm_nn_f32 followed by gist_dropout_f32: the
+    same kept/dropped pattern bit for bit, values equal up to the order of a <= 64-term sum."""
+    rs = np.random.RandomState(m + n + k)
+    g = dev(rs.randn(m, k).astype(np.float32))
+    w = dev(rs.randn(k, n).astype(np.float32))
+    zbuf = torch.full((m + 2, n + 4), 5.0, device=DEV)
+    z = zbuf[:m, :n]
+    hip.gemm_nn_dropout_(g, w, z, p, 99, offset)
+    ref = torch.empty(m, n, device=DEV)
+    hip.gemm_nn(g, w, ref)
+    if p > 0:
+        hip.dropout_(ref, p, 99, offset)
+    assert torch.equal(z == 0, ref == 0)
+    scale = max(1.0, ref.abs().max().item())
+    assert (z - ref).abs().max().item() <= 2e-6 * scale * np.sqrt(k)
+    assert (zbuf[m:] == 5.0).all() and (zbuf[:, n:] == 5.0).all()
+    if p > 0:
+        frac = (z == 0).float().mean().item()
+        assert abs(frac - p) < 0.02
+
+
 # ------------------------------------------------------------------ LN / ReLU / dropout / colsum
 @pytest.mark.parametrize('n,d', [(5, 7), (64, 41), (300, 256), (257, 1024), (100, 4096), (33, 1030)])
 @pytest.mark.parametrize('ln,relu', [(True, True), (True, False), (False, True)])
