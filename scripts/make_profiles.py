@@ -60,15 +60,15 @@ for tot, k, n, fa, wa in rows[:24]:
 open(os.path.join(P, 'r01_pmc_fetch_write.md'), 'w').write('\n'.join(md) + '\n')
 
 
-def traffic(kname):
-    f = fetch[kname]['FETCH_SIZE']
-    w = write[kname]['WRITE_SIZE']
+def traffic(kname):          # every instantiation whose name starts with kname
+    f = [x for k in fetch if k.startswith(kname) for x in fetch[k]['FETCH_SIZE']]
+    w = [x for k in write if k.startswith(kname) for x in write[k]['WRITE_SIZE']]
     return dict(launches=len(f), FETCH_SIZE_KB_raw=round(sum(f) / len(f), 1),
                 WRITE_SIZE_KB=round(sum(w) / len(w), 1),
                 hbm_bytes_corrected=int((2 * sum(f) / len(f) + sum(w) / len(w)) * 1024))
 
 
-sp = {k: traffic(k) for k in fetch if k.startswith('gist::spmm_csr_rowsplit_kernel')}
+sp = {k: traffic(k) for k in fetch if k.startswith('gist::spmm_csr_rowsplit_kernel')}   # per VEC/accumulate instantiation
 tot_l = sum(v['launches'] for v in sp.values())
 json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in sp.values()) / tot_l),
            'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 20 '
