@@ -49,6 +49,53 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y,
     float *yr = y + (int64_t)(live ? row : 0) * ldy;
     float *orow = out + (int64_t)(live ? row : 0) * ldo;
     float mean = 0.f, rstd = 1.f;
+#ifndef GIST_LN_STREAMING      // dev A/B build flag: always take the streaming path
+    if constexpr (TPR == 256 && VEC == 4) {
+        // Rows of up to 4096 floats (one workgroup per row): the row is read ONCE into registers
+        // (4 x 16 B per thread) instead of three times; same per-thread order of every sum, so
+        // the results are bit-identical to the streaming path below.
+        if (d <= 4096) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t * 4 + 1024 * u;
+                v[u] = (live && c < d) ? *reinterpret_cast<const float4 *>(yr + c)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (use_lynorm) {
+                float s = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t * 4 + 1024 * u < d) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+                mean = row_sum<TPR>(s, red) / (float)d;
+                float q = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t * 4 + 1024 * u < d) {
+                        const float a = v[u].x - mean, b = v[u].y - mean, e = v[u].z - mean, f = v[u].w - mean;
+                        q += (a * a + b * b) + (e * e + f * f);
+                    }
+                const float var = row_sum<TPR>(q, red) / (float)d;
+                rstd = 1.0f / sqrtf(var + eps);
+                if (live && t == 0 && rstd_out) rstd_out[row] = rstd;
+            }
+            if (!live) return;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t * 4 + 1024 * u;
+                if (c >= d) break;
+                float4 w = v[u];
+                w.x = (w.x - mean) * rstd; w.y = (w.y - mean) * rstd;
+                w.z = (w.z - mean) * rstd; w.w = (w.w - mean) * rstd;
+                if (use_lynorm) *reinterpret_cast<float4 *>(yr + c) = w;
+                if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f);
+                            w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+                *reinterpret_cast<float4 *>(orow + c) = w;
+            }
+            return;
+        }
+    }
+#endif
     if (use_lynorm) {
         float s = 0.f;
         if (live)
@@ -113,6 +160,59 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
     const float *yr = yhat + (int64_t)(live ? row : 0) * ldy;
     float *dr = dy + (int64_t)(live ? row : 0) * lddy;
     float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+#ifndef GIST_LN_STREAMING
+    if constexpr (TPR == 256 && VEC == 4) {
+        if (d <= 4096) {      // one read of d_out and yhat into registers (see the forward kernel)
+            float4 gq[4], yq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t * 4 + 1024 * u;
+                const bool in = live && c < d;
+                gq[u] = in ? *reinterpret_cast<const float4 *>(gr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                yq[u] = in ? *reinterpret_cast<const float4 *>(yr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (relu) {
+                    gq[u].x = yq[u].x > 0.f ? gq[u].x : 0.f; gq[u].y = yq[u].y > 0.f ? gq[u].y : 0.f;
+                    gq[u].z = yq[u].z > 0.f ? gq[u].z : 0.f; gq[u].w = yq[u].w > 0.f ? gq[u].w : 0.f;
+                }
+            }
+            if (use_lynorm) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t * 4 + 1024 * u < d) {
+                        s1 += (gq[u].x + gq[u].y) + (gq[u].z + gq[u].w);
+                        s2 += (gq[u].x * yq[u].x + gq[u].y * yq[u].y) + (gq[u].z * yq[u].z + gq[u].w * yq[u].w);
+                    }
+                m1 = row_sum<TPR>(s1, red) / (float)d;
+                m2 = row_sum<TPR>(s2, red) / (float)d;
+                if (live) rstd = rstd_in[row];
+            }
+            if (!live) return;
+            float mx = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t * 4 + 1024 * u;
+                if (c >= d) break;
+                float4 o = gq[u];
+                if (use_lynorm) {
+                    o.x = rstd * (o.x - m1 - yq[u].x * m2); o.y = rstd * (o.y - m1 - yq[u].y * m2);
+                    o.z = rstd * (o.z - m1 - yq[u].z * m2); o.w = rstd * (o.w - m1 - yq[u].w * m2);
+                }
+                *reinterpret_cast<float4 *>(dr + c) = o;
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+            }
+            if (rowmax != nullptr) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+                __syncthreads();
+                if (t == 0) rowmax[row] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            }
+            return;
+        }
+    }
+#endif
     if (use_lynorm) {
         float s1 = 0.f, s2 = 0.f;
         if (live)
