@@ -286,12 +286,14 @@ __global__ __launch_bounds__(256) void h3_dual_split_kernel(H3Dual d, int64_t ld
 }
 
 // max |x| of a [rows, cols] window into *out (float bits; zeroed by the caller).  16 rows per
-// block, 8 independent 16-byte loads in flight per thread.
+// block, 8 independent 16-byte loads in flight per thread, ONE atomic per block (4 rows per block
+// = 4x the atomics on one address ran 32 -> 59 us).
 __global__ __launch_bounds__(256) void h3_absmax_kernel(const float *__restrict__ src, int64_t ld,
                                                         int rows, int cols,
                                                         unsigned *__restrict__ out) {
     const int c4n = cols >> 2;
     float m = 0.f;
+    __shared__ float wm[4];
     const int rbeg = blockIdx.x * 16, rend = min(rows, rbeg + 16);
     for (int r = rbeg; r < rend; ++r) {
         const float *p = src + (int64_t)r * ld;
@@ -311,7 +313,12 @@ __global__ __launch_bounds__(256) void h3_absmax_kernel(const float *__restrict_
         if ((int)threadIdx.x < (cols & 3)) m = fmaxf(m, fabsf(p[4 * c4n + threadIdx.x]));
     }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
 }
 
 // ---- the GEMM -----------------------------------------------------------------------------

@@ -344,8 +344,7 @@ __global__ __launch_bounds__(256) void narrow_nn_drop_kernel(
     float4 acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < kc; ++c) {
-        const float4 wv = *reinterpret_cast<const float4 *>(w + (int64_t)c * ldw + c0);
+    auto fma_row = [&](int c, const float4 &wv) {      // acc[r] += dy[r][c] * w[c][j..j+3]
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 d4 = *reinterpret_cast<const float4 *>(&sdy[c][4 * q]);
@@ -357,7 +356,18 @@ __global__ __launch_bounds__(256) void narrow_nn_drop_kernel(
                 a.z = fmaf(dv[u], wv.z, a.z); a.w = fmaf(dv[u], wv.w, a.w);
             }
         }
+    };
+    int c = 0;
+    for (; c + 4 <= kc; c += 4) {      // four w rows in flight: the loop is L2-latency bound otherwise
+        float4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            wv[u] = *reinterpret_cast<const float4 *>(w + (int64_t)(c + u) * ldw + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fma_row(c + u, wv[u]);
     }
+    for (; c < kc; ++c)
+        fma_row(c, *reinterpret_cast<const float4 *>(w + (int64_t)c * ldw + c0));
     const uint64_t sm = seed * 0x9E3779B97F4A7C15ULL;
     const float inv24 = 1.0f / 16777216.0f;
 #pragma unroll
