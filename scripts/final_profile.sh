@@ -21,6 +21,8 @@ for h in 2048 1024 512; do
 done
 echo widths done
 python3 $R/scripts/eval_bench.py > $O/eval.log 2>&1 || exit 1
+python3 $R/scripts/h3_error_probe.py > $O/h3_err.log 2>&1 || exit 1
+python3 $R/scripts/h3_bench.py 10 > $O/h3_bench.log 2>&1 || exit 1
 tail -1 $O/eval.log | cut -c1-400
 # keep the merged output small: drop the raw traces, keep stats and counter tables
 find $O -name '*kernel_trace.csv' -size +20M -delete

@@ -106,7 +106,12 @@ for key in sorted(mf, key=lambda k: -sum(dur[k])):
         cyc / d_us / 1e3, c.get('SQ_LDS_BANK_CONFLICT', 0)))
 open(os.path.join(P, 'r01_pmc_mfma.md'), 'w').write('\n'.join(md) + '\n')
 
-# 5. full-graph evaluation
+# 5. split GEMM: error against float64 and time against the fp32 kernel
+for src, dst in (('h3_err.log', 'r01_gemm_h3_error_vs_float64.txt'), ('h3_bench.log', 'r01_gemm_h3_vs_f32_bench.txt')):
+    txt = ''.join(l for l in open(os.path.join(F, src)) if 'amdgpu.ids' not in l)
+    open(os.path.join(P, dst), 'w').write(txt)
+
+# 6. full-graph evaluation
 ev = last_json(os.path.join(F, 'eval.log'))
 old = json.load(open(os.path.join(P, 'r01_eval_fullgraph.json')))
 old.update(ev)
