@@ -307,9 +307,12 @@ def main():
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32' if args.gemm_mode == 'f32' else
-                     'f32 (storage, accumulation, all non-GEMM kernels; projection products as 3 '
-                     'f16-split terms on the f16 matrix cores, error vs float64 <= the fp32-MFMA '
-                     "kernel's)",
+                     'f32 (projection products as 3 f16-split MFMA terms, fp32 accumulation)',
+            'arithmetic_note': None if args.gemm_mode == 'f32' else
+                     'storage, accumulation and every non-GEMM kernel are fp32; the large projections '
+                     'split each fp32 operand into two f16 halves (22 bits) and accumulate ah.bh + '
+                     'ah.bl + al.bh in fp32: error vs float64 <= the fp32-MFMA kernel\'s '
+                     '(tests/test_gemm_h3_gpu.py); `f32_mfma` = same run with --gemm-mode f32',
             'data': 'synthetic',
             'config': {
                 'workload': 'Reddit-like synthetic (N_train=153431, F=602, C=41, 1500 parts, '
@@ -321,6 +324,7 @@ def main():
                                 'all-gather (cluster_gcn_ist_distrib.py path)'
                                 % (S, H // S, args.iter_per_site)),
                 'n_hidden': H, 'n_layers': L, 'num_subnet': S, 'batch_parts': batch_size,
+                'gemm_mode': args.gemm_mode,
                 'psize': psize, 'steps_per_epoch': STEPS_PER_EPOCH,
                 'epochs_per_sec_per_rank': round(value / world, 4),
             },
