@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     auto kstep = [&](auto cur_c, auto next_c, int kt) {
         constexpr int cur = decltype(cur_c)::value;
         constexpr bool has_next = decltype(next_c)::value != 0;
-#ifndef H3_PROBE_NO_DMA      // dev probes (scripts/h3_probe.sh): which side bounds the loop
-        if constexpr (has_next) dma(cur ^ 1, kt + 1);
+#ifndef H3_DMA_AFTER
+#define H3_DMA_AFTER (-1)    // dev knob: MFMAs of the k step issued before the next tile's DMA
 #endif
         __builtin_amdgcn_sched_barrier(0);
         const char *img = h3_smem + cur * BUF_BYTES;
@@ -459,21 +459,31 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         for (int i = 0; i < 4; ++i) bl[i] = *reinterpret_cast<const f16x8 *>(img + fb[i][1]);
 #pragma unroll
         for (int i = 0; i < NI; ++i) al[i] = *reinterpret_cast<const f16x8 *>(img + fa[i][1]);
+        // 3 * NI * 4 MFMAs: ah.bh, ah.bl, al.bh.  The next tile's DMA goes out behind the first
+        // 16 (the ah.bh group) in the 128-row kernel: issued first thing in the step it delays this
+        // wave's own MFMAs by its issue time (8 instructions of 60+ cycles); issued late it is not
+        // landed at the barrier (per launch: first 0.2258 ms, after 8 MFMAs 0.2244, after 16 0.2215,
+        // after 24 0.2250, after 32 0.2332).  The 64-row kernel (24 MFMAs, 3 workgroups per CU)
+        // runs best with the DMA first (h=1024 step 0.525 vs 0.533 ms).
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 3 * NI * 4; ++t) {
+            constexpr int dma_after = H3_DMA_AFTER < 0 ? (TM == 128 ? 16 : 0)
+                                                        : (H3_DMA_AFTER < 3 * NI * 4 ? H3_DMA_AFTER : 3 * NI * 4 - 1);
+            if (t == dma_after) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef H3_PROBE_NO_DMA      // dev probes (scripts/h3_probe.sh): which side bounds the loop
+                if constexpr (has_next) dma(cur ^ 1, kt + 1);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int term = t / (NI * 4), i = (t % (NI * 4)) / 4, j = t % 4;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al[i] : ah[i],
+                                                               term == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+        }
+#else
+#ifndef H3_PROBE_NO_DMA
+        if constexpr (has_next) dma(cur ^ 1, kt + 1);
+#endif
 #endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
