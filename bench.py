@@ -367,7 +367,7 @@ def main():
                     'mfma_rate_tflops': round(3 * h_ach, 1),
                     'frac_mfma_rate_of_peak': round(3 * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
                     # fabric bytes per launch from PMC (profiles/gemm_h3_traffic.json; Infinity-Cache
-                    # hits are counted): 8 XCDs x (8 + 8) operand panels, 3.6x the operand bytes
+                    # hits are counted): up to 8 XCDs x (8 + 8) operand panels, 2.6-3.6x the operand bytes
                     'traffic': h_traffic, 'launches': len(h3),
                     'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
                     'avg_launch_ms': round(h_ms / max(len(h3), 1), 5),
