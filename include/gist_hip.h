@@ -136,7 +136,8 @@ int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
  * accuracy (error against fp64 equal to mode 0's, tests/test_gemm_h3_gpu.py) at 1/5 of the
  * matrix-core time; mode 0 (GIST_GEMM_MODE=f32) keeps every shape on v_mfma_f32_32x32x2_f32.
  * Inputs and outputs are fp32 in both modes; small and skinny shapes always take mode 0's
- * kernel.  Process-wide; set it before sizing workspaces.  Both replace the same call,
+ * kernel.  A NaN or Inf in an operand row makes the corresponding output row / column
+ * non-finite (NaN where fp32 would give Inf) and leaves all other outputs unchanged.  Process-wide; set it before sizing workspaces.  Both replace the same call,
  * self.linear(h), cluster_gcn/modules.py:233, and its autograd. */
 int gist_gemm_set_mode(int mode);
 int gist_gemm_get_mode(void);

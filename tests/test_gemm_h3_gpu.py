@@ -143,6 +143,31 @@ def test_split_zero_operand_and_output_window(hip, tile):
     assert (ybuf[m:] == 7.0).all() and (ybuf[:, :4] == 7.0).all() and (ybuf[:, 4 + n:] == 7.0).all()
 
 
+def test_split_non_finite_inputs_stay_in_their_row(hip):
+    """A NaN or an Inf in one row of an operand makes that output row (A) / column (B)
+    non-finite and leaves every other output exactly as without it: the scales are per row."""
+    hip.gemm_mode('f16x3')
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    m, n, k = 1030, 1100, 520
+    a = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.randn(n, k, device=DEV, generator=gen)
+    clean = _run(hip, 'nt', a, w, None, m, n)
+    a2 = a.clone()
+    a2[7, 100] = float('nan')
+    a2[500, 3] = float('inf')
+    w2 = w.clone()
+    w2[33, 17] = float('nan')
+    y = _run(hip, 'nt', a2, w2, None, m, n)
+    bad_rows = torch.zeros(m, dtype=torch.bool, device=DEV)
+    bad_rows[[7, 500]] = True
+    bad_cols = torch.zeros(n, dtype=torch.bool, device=DEV)
+    bad_cols[33] = True
+    touched = bad_rows[:, None] | bad_cols[None, :]
+    assert not torch.isfinite(y[7]).any() and not torch.isfinite(y[:, 33]).any()
+    assert not torch.isfinite(y[500]).any()                  # Inf row: Inf or NaN everywhere, as in fp32
+    assert torch.equal(y[~touched], clean[~touched])
+
+
 def test_mode_switch_and_small_shapes_stay_fp32(hip):
     from gist_amd import _lib
     L = _lib.load()
