@@ -373,6 +373,10 @@ __device__ __forceinline__ void h3_dma_offsets(int64_t ld, int rows, int row0, i
 // TM = rows of the A tile: 128, or 64 for outputs with fewer than two 128x128 tiles per CU
 // (wave tile 32 x 64, 24 MFMAs per k tile, 24 KiB per stage, 512 instead of 256 workgroups on a
 // 2046 x 2048 output).
+#ifdef H3_CLOCK_PROBE   // dev build (scripts/h3_clock_probe.py): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+__device__ unsigned long long g_h3_clock[4 * 4096];
+#endif
+
 template <int TM>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
     extern __shared__ __attribute__((aligned(16))) char h3_smem[];
@@ -490,6 +494,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         if constexpr (has_next) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
     };
+#ifdef H3_CLOCK_PROBE
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     {
         using C0 = std::integral_constant<int, 0>;
         using C1 = std::integral_constant<int, 1>;
@@ -505,6 +512,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
         }
     }
 
+#ifdef H3_CLOCK_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_h3_clock[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - ck0;
+        g_h3_clock[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)row0 * g.ldc + col0;
     const int rows_valid = min(g.m - row0, TM);
@@ -694,3 +707,9 @@ extern "C" int gist_gemm_set_mode(int mode) {
 }
 
 extern "C" int gist_gemm_get_mode(void) { return gist::h3_mode(); }
+
+#ifdef H3_CLOCK_PROBE
+extern "C" int gist_h3_clock_read(unsigned long long *out, int64_t n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gist::g_h3_clock), n_blocks * 4 * 8);
+}
+#endif
