@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- epochs/sec of GIST's training hot path on MI355X, Reddit-like synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without WORLD_SIZE in the environment: this
+        process starts N rank processes itself (one per GPU, RCCL) BEFORE it touches the GPU,
+        waits for them and exits non-zero if any of them fails.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        the same rank code, launched by torchrun (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
 
 Workload (BASELINE.json metric: "epochs/sec + SpMM GB/s, Reddit 4096-wide GraphSAGE at
 1/2/4/8 GPUs"):
@@ -19,20 +23,23 @@ batch, plus the sync/dispatch work that falls on that iteration.  An epoch = 75 
 under GIST every rank trains n_epochs/S epochs (cluster_gcn_ist_distrib.py:385), so the
 job's throughput is the SUM of the ranks' epochs/sec ("weak": per-GPU batch stream fixed).
 
-Projections: fp32 in, fp32 out, fp32 accumulation.  By default (--gemm-mode f16x3) every
-projection >= 16 GFLOP forms its products as 3 f16-split terms on v_mfma_f32_16x16x32_f16
-(gist_amd/csrc/gemm_h3.hip; error against float64 equal to or below the fp32-MFMA kernel's,
-tests/test_gemm_h3_gpu.py, tests/test_e2e_gpu.py); --gemm-mode f32 keeps all of them on
-v_mfma_f32_32x32x2_f32.  At N=1 the line also carries `f32_mfma`: the same workload re-timed
-in mode f32 in the same process.
+Arithmetic of the headline `value`: fp32 storage, fp32 products, fp32 accumulation -- every
+projection on v_mfma_f32_32x32x2_f32 (--gemm-mode f32, the default).  At N=1 the same
+process then re-times the workload with the large projections as 3-term f16-split products
+(--gemm-mode f16x3: 22 of fp32's 24 operand bits, error vs float64 at the fp32 kernel's level,
+tests/test_gemm_h3_gpu.py) and reports it as the separate leg `f16x3_split` with its own
+roofline -- never as `value`.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the projection GEMM),
-`roofline_spmm` (the SpMM against HBM), `cpu_baseline` (the oracle timed on host cores).
+`roofline_spmm` (the SpMM against HBM), `cpu_baseline` (the oracle timed on host cores, all
+cores and one thread).
 """
 import argparse
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,11 +63,11 @@ def parse():
     ap.add_argument('--n-layers', type=int, default=2)
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--iter-per-site', type=int, default=100)
-    ap.add_argument('--gemm-mode', choices=['f16x3', 'f32'], default='f16x3',
-                    help='products of the large projections: 3-term f16 split on the f16 matrix '
-                         'cores (fp32-level accuracy) or v_mfma_f32_32x32x2_f32')
-    ap.add_argument('--no-f32-rerun', action='store_true',
-                    help='N=1, mode f16x3: skip re-timing the workload in mode f32')
+    ap.add_argument('--gemm-mode', choices=['f32', 'f16x3'], default='f32',
+                    help='products of the large projections behind `value`: v_mfma_f32_32x32x2_f32 '
+                         '(default: fp32 arithmetic) or the 3-term f16 split on the f16 matrix cores')
+    ap.add_argument('--no-second-leg', action='store_true',
+                    help='N=1: skip re-timing the workload in the other GEMM mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-timing', action='store_true',
@@ -72,9 +79,56 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(ds, par_order, dims, use_layernorm, n_steps, seed):
-    """The oracle (oracle/gist_oracle.py, numpy + OpenBLAS + OpenMP C SpMM) on the host
-    cores, same workload: first `n_steps` batches of the epoch, full step each."""
+# --------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the rank processes from here (before any GPU call)
+# --------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """Parent of a self-launched N-rank run: never imports torch, never touches the GPU.  One
+    child per rank with the torchrun environment contract; children share stdout/stderr (rank
+    0 prints the JSON line).  Any child failing -> the others are terminated, exit code != 0."""
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print('bench: rank process %d exited with %d; stopping the others'
+                      % (procs.index(p), code), file=sys.stderr, flush=True)
+                for q in alive:
+                    q.terminate()
+    return rc
+
+
+# --------------------------------------------------------------------------------------------
+# CPU baseline (the oracle) -- the only place this file touches oracle/
+# --------------------------------------------------------------------------------------------
+def cpu_baseline(ds, par_order, dims, use_layernorm, p_drop, n_steps, seed, threads):
+    """The oracle (oracle/gist_oracle.py, numpy + OpenBLAS + OpenMP C SpMM) on `threads` host
+    threads, same workload: the first batches of the epoch, full step each (extraction, forward
+    with dropout masks, CE, backward, Adam).  Returns the median step time of n_steps steps
+    after one warm-up step (threads == 1: no warm-up step, to bound the run)."""
+    from threadpoolctl import threadpool_limits
     from oracle import gist_oracle as O
     from oracle import train_oracle as TO
     g = ds.g
@@ -89,14 +143,36 @@ def cpu_baseline(ds, par_order, dims, use_layernorm, n_steps, seed):
                        rs.uniform(-stdv, stdv, o).astype(np.float32)))
     opt = O.new_opt_state(params)
     times = []
-    for j in range(n_steps + 1):
-        ids = np.concatenate(par_order[j * 20:(j + 1) * 20]).astype(np.int64)
-        t0 = time.time()
-        rpb, clb, trp, tcl, x, y = tg.batch(ids)
-        O.train_step(rpb, clb, trp, tcl, x, y, params, opt, use_layernorm, 0.01)
-        times.append(time.time() - t0)
-    step = float(np.median(times[1:]))           # first step = warm-up
-    return step
+    warm = 1 if threads != 1 else 0
+    with threadpool_limits(limits=threads):
+        from threadpoolctl import threadpool_info
+        pools = sorted('%s:%d' % (p_.get('internal_api', '?'), p_.get('num_threads', 0))
+                       for p_ in threadpool_info())
+        for j in range(n_steps + warm):
+            ids = np.concatenate(par_order[j * 20:(j + 1) * 20]).astype(np.int64)
+            t0 = time.time()
+            rpb, clb, trp, tcl, x, y = tg.batch(ids)
+            masks = None
+            if p_drop > 0:      # nn.Dropout on the concatenated [h | ah] of every layer
+                masks = [(rs.random_sample((len(ids), 2 * i)) >= p_drop).astype(np.float32)
+                         for (i, o) in dims]
+            O.train_step(rpb, clb, trp, tcl, x, y, params, opt, use_layernorm, 0.01,
+                         drop_masks=masks, drop_p=p_drop)
+            times.append(time.time() - t0)
+    return float(np.median(times[warm:])), pools
+
+
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a
+    GPU box hands a 1-GPU job a share of the host, not all of os.cpu_count())."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def measured_copy_gbs(dev, n_bytes=1 << 30, reps=5):
@@ -120,17 +196,30 @@ def measured_copy_gbs(dev, n_bytes=1 << 30, reps=5):
         return 0.0
 
 
+def _traffic(name):
+    """HBM/fabric bytes per launch from a committed PMC profile (NOT measured in this run)."""
+    tf = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(tf):
+        return None, None
+    try:
+        return json.load(open(tf)).get('hbm_bytes_per_launch'), 'profiles/' + name + \
+            ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)'
+    except Exception:
+        return None, None
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
-                             '--nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     # GIST_BENCH_SHARED_GPU=1 (validation only, never a reported number): every rank uses
     # cuda:0 and the collectives are staged through the host over gloo, so the N>1 logic can
     # be exercised on a 1-GPU box.  The product path is RCCL (backend "nccl").
@@ -148,7 +237,10 @@ def main():
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
 
-    hip.gemm_mode(args.gemm_mode)       # before any workspace is sized
+    # workspaces are sized for the split path (a superset of what mode f32 needs), then the
+    # requested mode is selected for the headline run
+    second_leg = world == 1 and not args.no_second_leg
+    hip.gemm_mode('f16x3' if (second_leg or args.gemm_mode == 'f16x3') else 'f32')
     seed = 0
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -189,19 +281,7 @@ def main():
                 stdv = 1.0 / np.sqrt(2 * i)
                 base_init.append((rs.uniform(-stdv, stdv, (o, 2 * i)).astype(np.float32),
                                   rs.uniform(-stdv, stdv, o).astype(np.float32)))
-        comm = None
-        if shared_gpu:
-            class HostStagedComm(ist.TorchDistComm):       # validation shim, see above
-                def all_gather_flat(self, out, inp):
-                    o = torch.empty(out.shape, dtype=out.dtype)
-                    dist.all_gather_into_tensor(o, inp.cpu())
-                    out.copy_(o)
-
-                def broadcast(self, t, src=0):
-                    c = t.cpu()
-                    dist.broadcast(c, src=src)
-                    t.copy_(c)
-            comm = HostStagedComm()
+        comm = ist.HostStagedComm() if shared_gpu else None      # default: TorchDistComm (RCCL)
         ist_model = ist.DistributedGNNWrapper(ns, None, in_feats, n_classes, dev,
                                               base_init=base_init, n_max=it.n_max, seed=seed,
                                               comm=comm)
@@ -209,11 +289,13 @@ def main():
         engine = ist_model.engine
         dims = ist_model.sub_dims
     it.bind(engine)
+    hip.gemm_mode(args.gemm_mode)
     lr = 0.01
+    native = engine.plan is not None
+    every = max(args.timing_every, 1) if native else 1
 
-    timed_ids = []          # id slices of the timed batches (replayed AFTER timing for nnz stats)
-    n_log = []
     state = dict(total_iter=0, epoch=0)
+    sync_ms = []            # HIP-event time of every sync (+ re-dispatch) inside a timed region
 
     def batches():
         while True:
@@ -223,7 +305,7 @@ def main():
 
     gen = batches()
 
-    def run_steps(count, log_from=None, sample_timer=None):
+    def run_steps(count, sample_timer=None, ids_log=None, n_log=None, loss_log=None):
         for s in range(count):
             b = next(gen)
             ti = state['total_iter']
@@ -231,15 +313,21 @@ def main():
                 if state['epoch'] > 0:                       # no re-dispatch in epoch 0 (:401-403)
                     ist_model.dispatch_model()
                 ist_model.sub.reset_optimizer()              # fresh Adam (:405-407)
-            if sample_timer is not None:    # HIP events around this step's SpMM/GEMM launches?
-                engine.plan.timer = sample_timer if (s % args.timing_every == 0) else None
+            if native:      # HIP events around this step's SpMM/GEMM launches?
+                engine.plan.timer = sample_timer if (sample_timer is not None and s % every == 0) else None
             engine.train_step(b, lr, 0.0)
-            if log_from is not None:        # bookkeeping only: no device work in the timed region
-                timed_ids.append(b.ids)
+            if ids_log is not None:         # bookkeeping only: no device work in the timed region
+                ids_log.append(b.ids)
                 n_log.append(b.n)
+            if loss_log is not None and (s == 0 or s == count - 1):
+                loss_log.append(engine.loss.clone())         # device copy, no host sync
             state['total_iter'] = ti + 1
             if ist_model is not None and state['total_iter'] % args.iter_per_site == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 ist_model.sync_model()                       # :422-427
+                e1.record()
+                sync_ms.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -247,72 +335,166 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run_steps(args.warmup)
-    fence()
-    timing = not args.no_kernel_timing
-    native = engine.plan is not None
-    sample_timer = None
-    if timing:
-        if native:          # HIP events recorded by the native step driver on the launch stream
-            sample_timer = engine.enable_timer(
-                (args.steps // max(args.timing_every, 1) + 1) * (12 * len(dims) + 4))
-        else:
+    def timed_region(steps, with_timer):
+        """Exactly `steps` steps between two fences; returns (elapsed, kernel records, logs)."""
+        sample_timer = None
+        if with_timer and native:   # HIP events recorded by the native step driver on the launch stream
+            sample_timer = engine.enable_timer((steps // every + 1) * (12 * len(dims) + 4))
+        elif with_timer:
             hip.profile_begin()
-    t0 = time.time()
-    run_steps(args.steps, log_from=0, sample_timer=sample_timer)
-    fence()
-    elapsed = time.time() - t0
-    prof = None
-    if timing and native:
-        rec = engine.read_timer()
-        prof = {'gemm': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 1],
-                'h3': [(ms, ('x', m, n, k)) for (ms, kind, m, n, k) in rec if kind == 2],
-                'pre': [ms for (ms, kind, m, n, k) in rec if kind == 3],
-                'spmm': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 0]}
-        engine.disable_timer()
-    elif timing:
-        prof = hip.profile_end()
+        ids_log, n_log, loss_log = [], [], []
+        fence()
+        t0 = time.time()
+        run_steps(steps, sample_timer, ids_log, n_log, loss_log)
+        fence()
+        elapsed = time.time() - t0
+        prof = None
+        if with_timer and native:
+            rec = engine.read_timer()
+            prof = {'gemm': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 1],
+                    'h3': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 2],
+                    'pre': [ms for (ms, kind, m, n, k) in rec if kind == 3],
+                    'spmm': [(ms, (m, n, k)) for (ms, kind, m, n, k) in rec if kind == 0]}
+            engine.disable_timer()
+        elif with_timer:
+            p = hip.profile_end()
+            prof = {'gemm': [(ms, s[1:]) for ms, s in p['gemm']], 'h3': [], 'pre': [],
+                    'spmm': p['spmm']}
+        return elapsed, prof, ids_log, n_log, loss_log
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if shared_gpu else dev)
+    def gemm_roofline(prof, elapsed, steps, mode):
+        """`roofline` of the dominant kernel of a timed region run in GEMM mode `mode`."""
+        n_instr = len(range(0, steps, every))               # instrumented steps of the region
+        step_ms = elapsed * 1e3 / steps
+        share = lambda ms: round(ms / (n_instr * step_ms), 4) if n_instr else None
+        gem = prof['gemm']
+        g_ms = sum(ms for ms, _ in gem) + sum(prof['pre'])       # + split work outside the calls
+        g_flop = sum(2.0 * m * n * k for _, (m, n, k) in gem)
+        ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        sampled = 'every %d-th timed step (%d of %d)' % (every, n_instr, steps)
+        h3 = prof['h3']
+        if mode == 'f16x3' and h3:
+            # the split GEMM's main kernel, bracketed on its own.  achieved = ALGORITHMIC flops
+            # (2mnk) / its time; it executes 3 f16 MFMA flops per algorithmic flop.
+            h_ms = sum(ms for ms, _ in h3)
+            h_flop = sum(2.0 * m * n * k for _, (m, n, k) in h3)
+            h_ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+            traffic, src = _traffic('gemm_h3_traffic.json')
+            shapes = set(s for _, s in h3)
+            return {
+                'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_16x16x32_f16, 3 MFMA flops per '
+                          'algorithmic flop: ah.bh + ah.bl + al.bh)',
+                'bound': 'mfma', 'achieved': round(h_ach, 3), 'peak': MFMA_F16_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(h_ach / MFMA_F16_PEAK_TFLOPS, 4),
+                'mfma_flops_per_algorithmic_flop': 3,
+                'mfma_rate_tflops': round(3 * h_ach, 1),
+                'frac_mfma_rate_of_peak': round(3 * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
+                'traffic': traffic, 'traffic_source': src, 'launches': len(h3), 'sampled': sampled,
+                'avg_launch_ms': round(h_ms / max(len(h3), 1), 5), 'share_of_step': share(h_ms),
+                # every projection call of the step: split pre-pass + main kernel, and the
+                # class-layer GEMMs that stay on gist::gemm_f32_kernel
+                'all_projection_calls': {
+                    'achieved': round(ach, 3), 'unit': 'TFLOP/s (algorithmic)',
+                    'calls': len(gem), 'avg_call_ms': round(g_ms / max(len(gem), 1), 5),
+                    'share_of_step': share(g_ms),
+                    'split_prepass_share_of_step': share(
+                        sum(ms for ms, s in gem if s in shapes) - h_ms + sum(prof['pre'])),
+                },
+            }
+        traffic, src = _traffic('gemm_f32_traffic.json')
+        return {
+            'kernel': 'gist::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; NT/NN/TN)',
+            'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            'traffic': traffic, 'traffic_source': src, 'launches': len(gem), 'sampled': sampled,
+            'avg_launch_ms': round(g_ms / max(len(gem), 1), 5), 'share_of_step': share(g_ms),
+        }
+
+    # ---- headline: W untimed warm-up steps, then exactly K timed steps ------------------------
+    run_steps(args.warmup)
+    timing = not args.no_kernel_timing
+    elapsed_local, prof, timed_ids, n_log, loss_log = timed_region(args.steps, timing)
+    n_sync_timed = len(sync_ms)
+
+    stats = torch.tensor([elapsed_local], dtype=torch.float64, device='cpu' if shared_gpu else dev)
+    per_rank = [stats.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    loss_val = float(engine.loss.item())
+        dist.all_gather(per_rank, stats)
+    else:
+        per_rank = [stats]
+    per_rank_s = [float(t.item()) for t in per_rank]
+    elapsed = max(per_rank_s)                                   # MAX over ranks
+    loss_first, loss_last = (float(loss_log[0].item()), float(loss_log[-1].item()))
 
-    # the same workload on the fp32 matrix-core path, same process (workspaces stay sized for
-    # the split path, which is a superset)
-    f32_rerun = None
-    if world == 1 and args.gemm_mode == 'f16x3' and not args.no_f32_rerun:
-        hip.gemm_mode('f32')
-        engine.plan.timer = None
-        n_re = max(args.steps // 3, 10)
+    # ---- weight exchange, measured on its own (outside the timed region) ----------------------
+    sync_info = None
+    if ist_model is not None:
+        reps = 3
+        fence()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+               torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        rstate = random.getstate()                   # dispatch consumes python `random`: restore
+        for a, b_, c in ev:
+            a.record()
+            ist_model.sync_model()
+            b_.record()
+            ist_model.dispatch_model()
+            c.record()
+        random.setstate(rstate)
+        fence()
+        s_ms = float(np.median([a.elapsed_time(b_) for a, b_, c in ev]))
+        d_ms = float(np.median([b_.elapsed_time(c) for a, b_, c in ev]))
+        t = torch.tensor([s_ms, d_ms], dtype=torch.float64, device='cpu' if shared_gpu else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s_ms, d_ms = float(t[0].item()), float(t[1].item())
+        P = ist_model.sub.numel
+        sync_info = {
+            'sync_ms_per_exchange': round(s_ms, 4), 'dispatch_ms': round(d_ms, 4),
+            'measured': 'median of %d sync_model + dispatch_model pairs after the timed region, '
+                        'max over ranks (HIP events)' % reps,
+            'all_gather_bytes_per_rank': int(4 * P), 'all_gather_bytes_total': int(4 * P * world),
+            'syncs_inside_timed_region': n_sync_timed,
+            'sync_ms_inside_timed_region': [round(a.elapsed_time(b_), 4) for a, b_ in sync_ms],
+            'amortized_ms_per_step': round((s_ms + d_ms) / args.iter_per_site, 5),
+        }
+
+    # ---- N=1: the same workload in the other GEMM mode, same process --------------------------
+    leg = None
+    if second_leg:
+        other = 'f16x3' if args.gemm_mode == 'f32' else 'f32'
+        hip.gemm_mode(other)
+        n_re = max(args.steps // 2, 10)
         run_steps(3)
-        fence()
-        t1 = time.time()
-        run_steps(n_re)
-        fence()
-        e1 = time.time() - t1
-        f32_rerun = {'value': round(n_re / STEPS_PER_EPOCH / e1, 4), 'unit': 'epochs/s',
-                     'ms_per_step': round(e1 / n_re * 1e3, 4), 'steps': n_re,
-                     'gemm': 'every projection on v_mfma_f32_32x32x2_f32 (--gemm-mode f32)'}
-        hip.gemm_mode('f16x3')
+        e2, prof2, _, _, _ = timed_region(n_re, timing)
+        hip.gemm_mode(args.gemm_mode)
+        leg = {'value': round(n_re / STEPS_PER_EPOCH / e2, 4), 'unit': 'epochs/s',
+               'ms_per_step': round(e2 / n_re * 1e3, 4), 'steps': n_re, 'gemm_mode': other,
+               'dtype': 'f32' if other == 'f32' else
+                        'f32 storage/accumulation; projection products as 3 f16-split MFMA terms '
+                        '(22 of 24 operand bits)',
+               'note': 'same process, same workload, re-timed after the headline run; not `value`'}
+        if prof2 is not None:
+            leg['roofline'] = gemm_roofline(prof2, e2, n_re, other)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # every rank runs `steps` iterations of its own sub-GCN: S * steps / 75 epochs of work
         value = world * args.steps / STEPS_PER_EPOCH / elapsed
+        f32 = args.gemm_mode == 'f32'
         out = {
             'metric': 'epochs/sec', 'value': round(value, 4), 'unit': 'epochs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32' if args.gemm_mode == 'f32' else
+            'dtype': 'f32' if f32 else
                      'f32 (projection products as 3 f16-split MFMA terms, fp32 accumulation)',
-            'arithmetic_note': None if args.gemm_mode == 'f32' else
-                     'storage, accumulation and every non-GEMM kernel are fp32; the large projections '
-                     'split each fp32 operand into two f16 halves (22 bits) and accumulate ah.bh + '
-                     'ah.bl + al.bh in fp32: error vs float64 <= the fp32-MFMA kernel\'s '
-                     '(tests/test_gemm_h3_gpu.py); `f32_mfma` = same run with --gemm-mode f32',
+            'arithmetic_note':
+                'fp32 storage, products and accumulation everywhere: every projection on '
+                'v_mfma_f32_32x32x2_f32' if f32 else
+                'storage, accumulation and every non-GEMM kernel are fp32; the large projections '
+                'split each fp32 operand into two f16 halves (22 bits) and accumulate ah.bh + '
+                'ah.bl + al.bh in fp32',
             'data': 'synthetic',
             'config': {
                 'workload': 'Reddit-like synthetic (N_train=153431, F=602, C=41, 1500 parts, '
@@ -328,114 +510,67 @@ def main():
                 'psize': psize, 'steps_per_epoch': STEPS_PER_EPOCH,
                 'epochs_per_sec_per_rank': round(value / world, 4),
             },
-            'final_loss': round(loss_val, 5),
+            'rccl_ranks': (dist.get_world_size() if world > 1 else 1),
+            'backend': ('gloo, host-staged (validation)' if shared_gpu else 'nccl (RCCL)') if world > 1 else None,
+            'per_rank_ms_per_step': [round(s / args.steps * 1e3, 4) for s in per_rank_s],
+            'loss_first': round(loss_first, 5), 'loss_last': round(loss_last, 5),
+            'loss_note': 'CE of the first and last timed batch (ln 41 = 3.71 for uniform logits); '
+                         'the first steps at lr=0.01 overshoot before the loss comes down',
             **({'INVALID': 'GIST_BENCH_SHARED_GPU validation run: ranks share one GPU, host-staged gloo'} if shared_gpu else {}),
             'host_path': 'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',
         }
+        if sync_info is not None:
+            out['weight_sync'] = sync_info
         if prof is not None:
+            out['roofline'] = gemm_roofline(prof, elapsed_local, args.steps, args.gemm_mode)
             # in-batch edge counts of the timed batches: re-extract them now, outside the timing
             nnz = np.zeros(args.steps, np.int64)
             for i, ids in enumerate(timed_ids):
                 bb = it.batcher.extract(ids, engine.z0_left(ids.numel()))
                 nnz[i] = int(bb.rowptr[bb.n].item())
-            gem = prof['gemm']
-            g_ms = sum(ms for ms, _ in gem) + sum(prof.get('pre', []))   # + split work outside the calls
-            g_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in gem)
-            ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-            every = args.timing_every if native else 1
-            h3 = prof.get('h3', [])
-            if h3:
-                # dominant kernel: the split GEMM's main kernel, bracketed on its own.  achieved =
-                # ALGORITHMIC flops (2mnk) / its time; it executes 3 f16 MFMA flops per
-                # algorithmic flop, so its ceiling is the dense f16 peak / 3.
-                h_ms = sum(ms for ms, _ in h3)
-                h_flop = sum(2.0 * m * n * k for _, (_, m, n, k) in h3)
-                h_ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
-                h_traffic = None
-                tf = os.path.join(ROOT, 'profiles', 'gemm_h3_traffic.json')
-                if os.path.exists(tf):
-                    try:
-                        h_traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
-                    except Exception:
-                        h_traffic = None
-                out['roofline'] = {
-                    'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_16x16x32_f16, 3 MFMA flops per '
-                              'algorithmic flop: ah.bh + ah.bl + al.bh)',
-                    'bound': 'mfma', 'achieved': round(h_ach, 3), 'peak': MFMA_F16_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(h_ach / MFMA_F16_PEAK_TFLOPS, 4),
-                    'mfma_flops_per_algorithmic_flop': 3,
-                    'mfma_rate_tflops': round(3 * h_ach, 1),
-                    'frac_mfma_rate_of_peak': round(3 * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
-                    # fabric bytes per launch from PMC (profiles/gemm_h3_traffic.json; Infinity-Cache
-                    # hits are counted): up to 8 XCDs x (8 + 8) operand panels, 2.6-3.6x the operand bytes
-                    'traffic': h_traffic, 'launches': len(h3),
-                    'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
-                    'avg_launch_ms': round(h_ms / max(len(h3), 1), 5),
-                    'share_of_step': round(h_ms * every / (elapsed * 1e3), 4),
-                    # every projection call of the step: split pre-pass + main kernel, and the
-                    # class-layer GEMMs that stay on gist::gemm_f32_kernel
-                    'all_projection_calls': {
-                        'achieved': round(ach, 3), 'unit': 'TFLOP/s (algorithmic)',
-                        'vs_f32_mfma_peak': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                        'calls': len(gem), 'avg_call_ms': round(g_ms / max(len(gem), 1), 5),
-                        'share_of_step': round(g_ms * every / (elapsed * 1e3), 4),
-                        'split_prepass_share_of_step': round(
-                            (sum(ms for ms, (_, m, n, k) in gem
-                                 if any((m, n, k) == s[1:] for _, s in h3)) - h_ms
-                             + sum(prof.get('pre', []))) * every / (elapsed * 1e3), 4),
-                    },
-                }
-            else:
-                out['roofline'] = {
-                    'kernel': 'gist::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; NT/NN/TN)',
-                    'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    'traffic': None, 'launches': len(gem),
-                    'sampled': 'every %d-th timed step' % args.timing_every if native else 'every step',
-                    'avg_launch_ms': round(g_ms / max(len(gem), 1), 5),
-                    'share_of_step': round(g_ms * every / (elapsed * 1e3), 4),
-                }
-            if f32_rerun is not None:
-                out['f32_mfma'] = f32_rerun
             sp = prof['spmm']
             per_step = 2 * len(dims) - 1                 # SpMM launches per instrumented step
-            stride = args.timing_every if native else 1  # which timed step a record belongs to
             s_ms = sum(ms for ms, _ in sp)
             s_bytes = 0.0
             for idx, (ms, (n, n_src, d)) in enumerate(sp):
-                z = int(nnz[min((idx // per_step) * stride, args.steps - 1)])
+                z = int(nnz[min((idx // per_step) * every, args.steps - 1)])
                 s_bytes += 4.0 * (n + 1) + 4.0 * z + 4.0 * n_src * d + 4.0 * n * d
             s_ach = s_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
-            traffic = None
-            tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
-                except Exception:
-                    traffic = None
+            traffic, src = _traffic('spmm_traffic.json')
             copy_gbs = measured_copy_gbs(dev)
+            n_instr = len(range(0, args.steps, every))
             out['roofline_spmm'] = {
                 'kernel': 'gist::spmm_csr_rowsplit_kernel', 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
                 # achievable HBM bandwidth on this box: a 1 GiB device-to-device copy (read+write)
                 'peak_measured_copy': round(copy_gbs, 1),
                 'frac_of_measured_copy': round(s_ach / copy_gbs, 4) if copy_gbs > 0 else None,
-                'traffic': traffic, 'launches': len(sp),
+                'traffic': traffic, 'traffic_source': src, 'launches': len(sp),
                 'avg_launch_ms': round(s_ms / max(len(sp), 1), 5),
                 'avg_algorithmic_bytes': round(s_bytes / max(len(sp), 1), 1),
-                'share_of_step': round(s_ms * (args.timing_every if native else 1) / (elapsed * 1e3), 4),
+                'share_of_step': round(s_ms / (n_instr * elapsed_local * 1e3 / args.steps), 4),
                 'mean_batch_rows': round(float(np.mean(n_log)), 1),
                 'mean_batch_nnz': round(float(nnz.mean()), 1),
             }
+        if leg is not None:
+            out['f16x3_split' if leg['gemm_mode'] == 'f16x3' else 'f32_mfma'] = leg
         if world == 1 and not args.no_cpu_baseline:
             try:
-                step_s = cpu_baseline(ds, first_epoch_order, dims, use_ln, args.cpu_steps, seed)
+                ncpu = host_cores()
+                t_all, pools_all = cpu_baseline(ds, first_epoch_order, dims, use_ln, args.dropout,
+                                                args.cpu_steps, seed, ncpu)
+                t_one, pools_one = cpu_baseline(ds, first_epoch_order, dims, use_ln, args.dropout,
+                                                1, seed, 1)
                 out['cpu_baseline'] = {
-                    'value': round(1.0 / (STEPS_PER_EPOCH * step_s), 6), 'unit': 'epochs/s',
-                    'cores': os.cpu_count(), 'kind': 'port',
-                    'sample': 'oracle (numpy/OpenBLAS + OpenMP C SpMM) full training step on the '
-                              'first %d batches of the same workload after 1 warm-up step, '
-                              'median %.3f s/step, dropout off' % (args.cpu_steps, step_s),
+                    'value': round(1.0 / (STEPS_PER_EPOCH * t_all), 6), 'unit': 'epochs/s',
+                    'cores': ncpu, 'kind': 'port', 'thread_pools': pools_all,
+                    'sample': 'oracle (numpy/OpenBLAS + OpenMP C SpMM) full training step with '
+                              'dropout masks on the first %d batches of the same workload after 1 '
+                              'warm-up step, %d threads, median %.3f s/step'
+                              % (args.cpu_steps, ncpu, t_all),
+                    'one_thread': {'value': round(1.0 / (STEPS_PER_EPOCH * t_one), 6),
+                                   'unit': 'epochs/s', 'cores': 1, 'thread_pools': pools_one,
+                                   'sample': 'same step, 1 batch, 1 thread, no warm-up: %.2f s/step' % t_one},
                 }
             except Exception as e:                          # report, never fake
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GistLibraryError(RuntimeError):
@@ -40,6 +40,8 @@ SIGNATURES = {
     'gist_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'gist_gemm_set_mode': (_int, [_int]),
     'gist_gemm_get_mode': (_int, []),
+    'gist_tuning_set': (_int, [_int, ctypes.c_double]),
+    'gist_tuning_get': (ctypes.c_double, [_int]),
     'gist_gemm_nt_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_gemm_nn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_gemm_tn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
@@ -73,10 +75,10 @@ SIGNATURES = {
 }
 
 GIST_MAX_LAYERS = 16
+TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_splits': 4,
+        'spmm_chunk': 5}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
-GIST_STEP_OVERLAP_ADAM = 4
-GIST_STEP_OVERLAP_DW = 8
 
 
 class LayerDesc(ctypes.Structure):

@@ -11,10 +11,22 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static std::atomic<double> g_tune[GIST_TUNE_COUNT];
+double tune(int knob) { return g_tune[knob].load(std::memory_order_relaxed); }
 }  // namespace gist
 
+extern "C" int gist_tuning_set(int knob, double value) {
+    GIST_REQUIRE(knob >= 0 && knob < GIST_TUNE_COUNT, "gist_tuning_set: unknown knob %d", knob);
+    GIST_REQUIRE(value >= 0.0, "gist_tuning_set: negative value");
+    gist::g_tune[knob].store(value, std::memory_order_relaxed);
+    return GIST_OK;
+}
+extern "C" double gist_tuning_get(int knob) {
+    return knob >= 0 && knob < GIST_TUNE_COUNT ? gist::tune(knob) : -1.0;
+}
+
 extern "C" const char *gist_last_error(void) { return gist::g_err; }
-extern "C" int gist_abi_version(void) { return 5; }
+extern "C" int gist_abi_version(void) { return 6; }
 extern "C" int gist_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/gist_hip.h"
 
@@ -75,6 +78,29 @@ int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t l
                    float *rowmax, hipStream_t st);
 int colsum_ex(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, float *out,
               float *pmax, float *outmax, hipStream_t st);
+
+// Tuning hooks (gist_tuning_set, include/gist_hip.h): explicit process-wide overrides of the
+// launchers' own choices, for sweeps and for tests that must reach both variants of a kernel.
+// 0 = the launcher decides.  The library never reads the environment on a launch path.
+double tune(int knob);
+
+// Per-device one-time setup (hipFuncSetAttribute applies to the current device only).  Usage:
+//   static DeviceOnce once;  int dev;  if (once.needed(&dev)) { ...set...; once.done(dev); }
+// Racing threads may both run the setup, which is idempotent.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool needed(int *dev) {
+        if (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev > 63) { *dev = -1; return true; }
+        return ((mask.load(std::memory_order_acquire) >> *dev) & 1ULL) == 0;
+    }
+    void done(int dev) {
+        if (dev >= 0) mask.fetch_or(1ULL << dev, std::memory_order_release);
+    }
+};
+
+// XCDs of the device the library runs on (gfx950: 8); blockIdx -> tile maps deal work round-robin
+// to XCDs the way the hardware dispatches consecutive workgroups.
+constexpr int kXcds = 8;
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }

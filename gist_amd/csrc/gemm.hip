@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     // ---- block -> output tile, 8x8 super-tiles per XCD ------------------------
     const int nwg = g.tiles_m * g.tiles_n;
     const int orig = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
-    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
+    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
     constexpr int GM = 8;
     const int width = GM * g.tiles_n;
     const int group = L / width;
@@ -603,13 +603,12 @@ int64_t h3_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
     const int64_t kt = ceil_div(k, 32);      // the model counts k in units of 32
-    // developer override for tuning sweeps (scripts/gemm_sweep.py); not used in production
-    static const char *env_tile = getenv("GIST_GEMM_TILE");
-    static const char *env_split = getenv("GIST_GEMM_SPLITS");
-    if (env_tile && env_split) {
-        int sp = atoi(env_split);
+    // explicit override for tuning sweeps (scripts/gemm_sweep.py) and tests; 0 = the model decides
+    const int t_tile = (int)tune(GIST_TUNE_GEMM_TILE), t_split = (int)tune(GIST_TUNE_GEMM_SPLITS);
+    if (t_tile && t_split) {
+        int sp = t_split;
         while (sp > 1 && kt / sp < 1) sp >>= 1;
-        return GemmCfg{atoi(env_tile) == 64 ? 64 : 128, sp < 1 ? 1 : sp};
+        return GemmCfg{t_tile == 64 ? 64 : 128, sp < 1 ? 1 : sp};
     }
     static const double eff128[3] = {0.0, 0.90, 1.00};
     static const double eff64[5] = {0.0, 0.60, 0.80, 0.92, 1.00};
@@ -640,8 +639,9 @@ static int launch_tile(const char *name, GemmArgs &g, bool aligned, int splits, 
     constexpr int TA = A_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
     constexpr int TB = B_KC ? Img<T, BK>::KC : Img<T, BK>::MC;
     const size_t smem = (size_t)2 * (TA + TB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;       // one per template instance
+    int dev;
+    if (once.needed(&dev)) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&gemm_f32_kernel<A_KC, B_KC, true, T>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -653,7 +653,7 @@ static int launch_tile(const char *name, GemmArgs &g, bool aligned, int splits, 
             set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return GIST_ELAUNCH;
         }
-        attr_set = true;
+        once.done(dev);
     }
     g.tiles_m = (int)ceil_div(g.m, T);
     g.tiles_n = (int)ceil_div(g.n, T);
@@ -688,8 +688,7 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
     const bool aligned = aligned16(a) && (lda % 4 == 0) && lda >= 4 && aligned16(b) &&
                          (ldb % 4 == 0) && ldb >= 4 && k > 0;
-    static const int env_prio = getenv("GIST_GEMM_SETPRIO") ? atoi(getenv("GIST_GEMM_SETPRIO")) : 1;
-    g.setprio = env_prio;
+    g.setprio = 1;
     GemmCfg cfg = choose_cfg(m, n, k);
     int splits = cfg.splits;
     if (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits = 1;

@@ -387,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(H3Args g) {
 
     const int nwg = g.tiles_m * g.tiles_n;
     const int orig = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
-    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
+    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
     constexpr int GM = 8;
     const int width = GM * g.tiles_n;
     const int group = L / width;
@@ -578,8 +578,9 @@ int64_t h3_kpad(int64_t k) { return ceil_div(k, H3_BK) * H3_BK; }
 // Everything else stays on the fp32 kernel.
 static bool h3_shape_ok(int64_t m, int64_t n, int64_t k, double default_min_gflop) {
     if (h3_mode() != 1) return false;
-    const double min_gflop = getenv("GIST_H3_MIN_GFLOP") ? atof(getenv("GIST_H3_MIN_GFLOP")) : default_min_gflop;
-    const int min_tiles = getenv("GIST_H3_MIN_TILES") ? atoi(getenv("GIST_H3_MIN_TILES")) : 64;
+    const double t_gflop = tune(GIST_TUNE_H3_MIN_GFLOP), t_tiles = tune(GIST_TUNE_H3_MIN_TILES);
+    const double min_gflop = t_gflop > 0.0 ? t_gflop : default_min_gflop;
+    const int min_tiles = t_tiles > 0.0 ? (int)t_tiles : 64;
     if (m < 64 || n < 64 || k < 64) return false;
     if (ceil_div(m, H3_T) * ceil_div(n, H3_T) < min_tiles) return false;
     if (2.0 * (double)m * (double)n * (double)k < min_gflop * 1e9) return false;
@@ -601,8 +602,9 @@ int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, c
                      const float *inv_b, const float *bias, float *c, int64_t ldc, int64_t m,
                      int64_t n, int64_t k, hipStream_t st) {
     const int64_t kpad = h3_kpad(k);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3_kernel<128>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * H3_BUF_BYTES);
@@ -613,15 +615,15 @@ int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, c
             set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return GIST_ELAUNCH;
         }
-        attr_set = true;
+        once.done(dev);
     }
     H3Args g;
     g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.inv_a = inv_a; g.inv_b = inv_b; g.bias = bias;
     g.c = c; g.ldc = ldc; g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
     g.tiles_n = (int)ceil_div(n, H3_T);
     // 64-row A tiles when 128-row tiles would leave CUs without a second workgroup
-    const char *env_tm = getenv("GIST_H3_TM");       // dev: force 64 / 128
-    const bool tm64 = env_tm ? atoi(env_tm) == 64 : ceil_div(m, 128) * g.tiles_n < 512;
+    const int t_tm = (int)tune(GIST_TUNE_H3_TM);      // 0 = auto, 64 / 128 = forced
+    const bool tm64 = t_tm ? t_tm == 64 : ceil_div(m, 128) * g.tiles_n < 512;
     g.tiles_m = (int)ceil_div(m, tm64 ? 64 : 128);
     const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel alone
     if (tm64)

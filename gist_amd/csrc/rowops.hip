@@ -653,8 +653,7 @@ extern "C" int gist_gemm_nn_dropout_f32(const float *g, int64_t ldg, const float
     const bool narrow = k >= 1 && k <= 64 && m > 0 && n > 0 && g && w && z && n % 4 == 0 &&
                         ldw % 4 == 0 && ldz % 4 == 0 && aligned16(w) && aligned16(z) &&
                         (offset & 1) == 0 && ldg >= k && ldw >= n && ldz >= n &&
-                        m < (1LL << 31) && n < (1LL << 31) &&
-                        !(getenv("GIST_NARROW_NN") && atoi(getenv("GIST_NARROW_NN")) == 0);   // dev A/B
+                        m < (1LL << 31) && n < (1LL << 31);
     if (!narrow) {      // any other shape: the projection kernel, then the mask in place
         const int rc = gist_gemm_nn_f32(g, ldg, w, ldw, z, ldz, m, n, k, workspace, workspace_bytes, stream);
         if (rc != GIST_OK || p == 0.f) return rc;

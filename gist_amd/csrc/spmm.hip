@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int rb, ct;
     const int b = blockIdx.x;
     if (xcd_tiles) {  // tiles dealt to XCDs: blocks b, b+8, b+16.. share an L2
-        const int xcd = b & 7, i = b >> 3;
-        ct = xcd + 8 * (i / n_row_blocks);
+        const int xcd = b % kXcds, i = b / kXcds;
+        ct = xcd + kXcds * (i / n_row_blocks);
         rb = i % n_row_blocks;
         if (ct >= n_col_tiles) return;
     } else {
@@ -192,10 +192,10 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
     // rows an XCD gathers are the ones its own L2 already holds, instead of every L2
     // missing on all of X.  (Speed only: the result does not depend on placement.)
     const int b = blockIdx.x;
-    const int xcd = b & 7, i = b >> 3;
+    const int xcd = b % kXcds, i = b / kXcds;
     const int per = chunk_rows * n_col_tiles;
     const int rem = i % per;
-    const int row = (xcd + 8 * (i / per)) * chunk_rows + rem / n_col_tiles;
+    const int row = (xcd + kXcds * (i / per)) * chunk_rows + rem / n_col_tiles;
     const int ct = rem % n_col_tiles;
     if (row >= n_rows) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -549,9 +549,9 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
     const int n_row_blocks = (int)ceil_div(n_rows, kSpmmWavesPerBlock);
     const int xcd_tiles = n_col_tiles >= 8 ? 1 : 0;
     if (lpr == 64) {   // wide rows: one workgroup per (row, column tile), waves share the row
-        static const int chunk_rows = getenv("GIST_SPMM_CHUNK") ? atoi(getenv("GIST_SPMM_CHUNK")) : 128;
+        const int chunk_rows = tune(GIST_TUNE_SPMM_CHUNK) > 0.0 ? (int)tune(GIST_TUNE_SPMM_CHUNK) : 128;
         const int64_t n_chunks = ceil_div(n_rows, chunk_rows);
-        const int64_t g2 = 8 * ceil_div(n_chunks, 8) * chunk_rows * n_col_tiles;
+        const int64_t g2 = kXcds * ceil_div(n_chunks, kXcds) * chunk_rows * n_col_tiles;
         if (g2 > 0x7fffffffLL) {
             set_error("gist_spmm_csr_f32: grid too large");
             return GIST_EINVAL;
@@ -561,7 +561,7 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
                            src_scale, accumulate, n_col_tiles, chunk_rows);
         return launch_status("gist_spmm_csr_f32");
     }
-    const int64_t grid = xcd_tiles ? (int64_t)8 * ceil_div(n_col_tiles, 8) * n_row_blocks
+    const int64_t grid = xcd_tiles ? (int64_t)kXcds * ceil_div(n_col_tiles, kXcds) * n_row_blocks
                                    : (int64_t)n_row_blocks * n_col_tiles;
     if (grid > 0x7fffffffLL) {
         set_error("gist_spmm_csr_f32: grid too large");
@@ -595,8 +595,9 @@ static int launch_spmm_blocked(const int32_t *rowptr, const int32_t *col, const 
     const int64_t grid = nb * row_split * n_col_tiles;
     if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
     const size_t smem = LdsLayout<VEC>::total;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&spmm_csr_lds_kernel<VEC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -604,7 +605,7 @@ static int launch_spmm_blocked(const int32_t *rowptr, const int32_t *col, const 
             set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return GIST_ELAUNCH;
         }
-        attr_set = true;
+        once.done(dev);
     }
     hipLaunchKernelGGL((spmm_csr_lds_kernel<VEC>), dim3((unsigned)grid), dim3(kLdsThreads), smem, st,
                        rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale, src_scale,

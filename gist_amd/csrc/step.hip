@@ -149,7 +149,9 @@ H3Step h3_layout(const gist_step_plan *p, char *base) {
         H3Layer &hl = h.layer[k];
         const double bound = k == 0 ? (double)p->feat_absmax * keep
                                     : (p->use_layernorm ? sqrt((double)(l.n_in > 1 ? l.n_in - 1 : 1)) * keep : 0.0);
-        hl.on = bound > 0.0 && h3_eligible_kept(n, o, i2) && h3_eligible_kept(o, i2, n) &&
+        // the class layer (k == L1-1) stays on the per-call path: its dY = dlogits comes from the CE
+        // kernel, which writes no row maxima for the gradient split
+        hl.on = k < L1 - 1 && bound > 0.0 && h3_eligible_kept(n, o, i2) && h3_eligible_kept(o, i2, n) &&
                 (k == 0 || h3_eligible_kept(n, i2, o)) && l.ldz % 4 == 0 && l.ldy % 4 == 0 &&
                 aligned16(l.W) && aligned16(l.Z) && aligned16(l.Y) && aligned16(l.dW);
         if (!hl.on) continue;
@@ -200,8 +202,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     // Split operands kept by the step (see gist_step_plan.h3_workspace); off = per-call splits
     // inside gist_gemm_*.
     H3Step h3{};
-    if (p->h3_workspace != nullptr && aligned16(p->h3_workspace) && n <= p->n_max &&
-        (flags & (GIST_STEP_OVERLAP_ADAM | GIST_STEP_OVERLAP_DW)) == 0) {
+    if (p->h3_workspace != nullptr && aligned16(p->h3_workspace) && n <= p->n_max) {
         h3 = h3_layout(p, static_cast<char *>(p->h3_workspace));
         if (h3.bytes > p->h3_workspace_bytes) h3 = H3Step{};
     }
@@ -289,23 +290,6 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     if (!train) return GIST_OK;
 
     // ---- backward --------------------------------------------
-    // Adam is HBM-bound, the backward GEMMs are MFMA-bound: with GIST_STEP_OVERLAP_ADAM each
-    // layer's parameter slice [W_k | b_k] is updated on a side stream as soon as dW_k, db_k
-    // exist and W_k has been read for the last time (dZ = dY.W_k), concurrently with the
-    // rest of the backward; the step joins the side stream before it returns.
-    const bool overlap = (flags & GIST_STEP_OVERLAP_ADAM) != 0 && L1 > 1;
-    const bool overlap_dw = (flags & GIST_STEP_OVERLAP_DW) != 0 && !overlap && p->workspace2 != nullptr;
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_ready[GIST_MAX_LAYERS], ev_done = nullptr;
-    if ((overlap || overlap_dw) && side == nullptr) {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) {
-            set_error("gist_sage_step: cannot create the Adam side stream");
-            return GIST_ELAUNCH;
-        }
-        for (int k = 0; k < GIST_MAX_LAYERS; ++k)
-            (void)hipEventCreateWithFlags(&ev_ready[k], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&ev_done, hipEventDisableTiming);
-    }
     for (int k = L1 - 1; k >= 0; --k) {
         const gist_layer_desc &l = p->layer[k];
         const float *dy;
@@ -355,57 +339,23 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
             continue;
         }
-        if (overlap_dw) {
-            // dY_k is complete on the main stream: fork dW_k / db_k to the side stream, where
-            // all weight-gradient work is serialised (one split-K scratch, one colsum scratch).
-            (void)hipEventRecord(ev_ready[k], st);
-            (void)hipStreamWaitEvent(side, ev_ready[k], 0);
-            {
-                Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, side);
-                GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
-                                          2 * l.n_in, n, p->workspace2, p->workspace2_bytes,
-                                          (gist_stream_t)side));
-            }
-            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, (gist_stream_t)side));
-        }
-        if (k > 0) {      // dZ (before dW on the main stream: it is the last reader of W_k),
-                          // with its dropout mask
+        if (k > 0) {      // dZ with its dropout mask
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
             GIST_TRY(gist_gemm_nn_dropout_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
                                               2 * l.n_in, l.n_out, drop ? p->p_drop : 0.f, p->seed,
                                               offs[k], p->workspace, p->workspace_bytes, s));
         }
-        if (!overlap_dw) {
-            {
-                Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
-                GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
-                                          2 * l.n_in, n, p->workspace, p->workspace_bytes, s));
-            }
-            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
+        {
+            Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
+            GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
+                                      2 * l.n_in, n, p->workspace, p->workspace_bytes, s));
         }
-        if (overlap) {
-            const int64_t off = l.W - p->params;                 // [W_k | b_k] is contiguous
-            const int64_t cnt = l.n_out * 2 * l.n_in + l.n_out;
-            (void)hipEventRecord(ev_ready[k], st);
-            (void)hipStreamWaitEvent(side, ev_ready[k], 0);
-            GIST_TRY(gist_adam_f32(p->params + off, p->grads + off, p->exp_avg + off,
-                                   p->exp_avg_sq + off, cnt, lr, beta1, beta2, eps, weight_decay,
-                                   adam_step, (gist_stream_t)side));
-        }
+        GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
         if (k > 0) {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
             GIST_TRY(gist_spmm_csr_f32(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
                                        2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
         }
-    }
-    if (overlap) {
-        (void)hipEventRecord(ev_done, side);
-        (void)hipStreamWaitEvent(st, ev_done, 0);
-        return launch_status("gist_sage_step");
-    }
-    if (overlap_dw) {       // every dW / db must exist before Adam reads the gradient arena
-        (void)hipEventRecord(ev_done, side);
-        (void)hipStreamWaitEvent(st, ev_done, 0);
     }
     GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
                            beta2, eps, weight_decay, adam_step, s));

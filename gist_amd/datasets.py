@@ -90,18 +90,35 @@ def toy(seed=2, n=2400, n_blocks=24, n_feats=32, n_classes=5, train_frac=0.7):
                               seed=seed, train_frac=train_frac)
 
 
+SYNTHETIC = ('reddit-synth', 'amazon-synth', 'cora-synth', 'toy')
+
+
 def load_dataset(name, data_root=None):
-    """Real data when `data_root` (or $GIST_DATA_ROOT) holds it (gist_amd/ingest.py), else the
-    seeded synthetic stand-in with the documented statistics."""
+    """Real data for the reference's dataset names (`reddit`, `reddit-self-loop`, `amazon2m`:
+    utils.load_data, cluster_gcn/utils.py:83-124) from `data_root` / $GIST_DATA_ROOT through
+    gist_amd/ingest.py -- and an error naming what is missing when it is not there.  The seeded
+    synthetic stand-ins are returned ONLY for their own explicit names (`reddit-synth`,
+    `amazon-synth`, `cora-synth`, `toy`): a run under a real dataset's name never reports
+    accuracies of fake data."""
     import os
     from . import ingest
-    real = ingest.try_load(name, data_root or os.environ.get('GIST_DATA_ROOT'))
-    if real is not None:
-        return real
-    if name in ('reddit-synth', 'reddit-self-loop', 'reddit'):
+    root = data_root or os.environ.get('GIST_DATA_ROOT')
+    if name == 'reddit-synth':
         return reddit_synth(n=232965, train_frac=0.6586)      # 153431 / 232965 like Reddit
-    if name in ('amazon-synth', 'amazon2m'):
+    if name == 'amazon-synth':
         return amazon_synth(n=2449029, train_frac=0.6982)
+    if name == 'cora-synth':
+        return cora_synth()
     if name == 'toy':
         return toy()
-    raise ValueError('gist_amd: unknown dataset %r (no real datasets offline)' % name)
+    real = ingest.try_load(name, root)          # reddit / reddit-self-loop / amazon2m / {name}-G.json
+    if real is not None:
+        return real
+    synth = {'reddit': 'reddit-synth', 'reddit-self-loop': 'reddit-synth', 'amazon2m': 'amazon-synth'}
+    raise FileNotFoundError(
+        'gist_amd: dataset %r not found under data root %r (--data-root / $GIST_DATA_ROOT must hold '
+        'reddit_data.npz + reddit[_self_loop]_graph.npz, or GraphSAGE-format %s-G.json, -feats.npy, '
+        '-id_map.json, -class_map.json; gist_amd/ingest.py).%s Synthetic names: %s'
+        % (name, root, name,
+           ' For the seeded synthetic stand-in ask for it by name: --dataset %s.' % synth[name]
+           if name in synth else '', ', '.join(SYNTHETIC)))

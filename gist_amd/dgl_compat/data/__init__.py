@@ -5,8 +5,9 @@ from . import utils  # noqa: F401
 def register_data_args(parser):
     parser.add_argument('--dataset', type=str, required=False, default='reddit-synth',
                         help='dataset name: reddit / reddit-self-loop / amazon2m read real files from '
-                             '--data-root (or $GIST_DATA_ROOT) when present; otherwise, and for '
-                             'reddit-synth / amazon-synth / toy, a seeded synthetic stand-in')
+                             '--data-root (or $GIST_DATA_ROOT) and fail if they are missing; '
+                             'reddit-synth / amazon-synth / cora-synth / toy are seeded synthetic '
+                             'stand-ins')
     parser.add_argument('--data-root', type=str, default=None,
                         help='directory with reddit_data.npz + reddit[_self_loop]_graph.npz, or '
                              'GraphSAGE-format {name}-G.json/-feats.npy/-id_map.json/-class_map.json')

@@ -182,12 +182,6 @@ class SageEngine(object):
         # inference-only reassociation of the last layer (see forward); GIST_PROJECT_FIRST=0
         # keeps the reference's aggregate-then-project order
         self.project_first = os.environ.get('GIST_PROJECT_FIRST', '1') != '0'
-        # measured NEGATIVE on MI355X (H=4096: 4.47 -> 4.60 ms/step, h=512: 0.47 -> 0.57): the
-        # concurrent Adam traffic slows the L2-bound SpMM and the stream joins add latency
-        self.overlap_adam = False
-        # dW GEMM + column sum on a side stream next to dZ -> dropout -> SpMM: also measured
-        # negative (h=512: 0.39 -> 0.41 ms, H=4096: 4.40 -> 4.44); env knob for experiments
-        self.overlap_dw = os.environ.get('GIST_OVERLAP_DW', '0') == '1'
 
     # ------------------------------------------------------------------
     def attach_batcher(self, batcher):
@@ -283,10 +277,6 @@ class SageEngine(object):
         from . import _lib
         L = _lib.load()
         flags = (_lib.GIST_STEP_TRAIN if train else 0) | (0 if b.ready else _lib.GIST_STEP_EXTRACT)
-        if self.overlap_adam:
-            flags |= _lib.GIST_STEP_OVERLAP_ADAM
-        if self.overlap_dw:
-            flags |= _lib.GIST_STEP_OVERLAP_DW
         off = self.drop_calls
         if train and self.p_drop > 0.0:
             for (i, o) in self.dims:

@@ -175,6 +175,16 @@ def gemm_mode(mode=None):
     return 'f16x3' if L.gist_gemm_get_mode() == 1 else 'f32'
 
 
+def tuning(knob, value=None):
+    """Get (and with a value, set) a tuning hook (include/gist_hip.h gist_tuning_set): explicit
+    overrides of the launchers' choices for sweeps and tests; 0 = the launcher decides."""
+    L = _lib.load()
+    code = _lib.TUNE[knob]
+    if value is not None:
+        _lib.check(L.gist_tuning_set(code, float(value)), 'gist_tuning_set')
+    return L.gist_tuning_get(code)
+
+
 def gemm_nt(a, w, bias, y):
     """y = a @ w.T + bias"""
     L = _lib.load()

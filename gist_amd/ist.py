@@ -79,18 +79,32 @@ class TorchDistComm(object):
         return dist.get_rank(self.group)
 
     def all_gather_flat(self, out, inp):
-        try:
-            dist.all_gather_into_tensor(out, inp, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            n = inp.numel()
-            dist.all_gather([out[i * n:(i + 1) * n] for i in range(self.world_size())], inp,
-                            group=self.group)
+        # one collective; a failure (RCCL error, wrong sizes) propagates to the caller
+        dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def broadcast(self, t, src=0):
         dist.broadcast(t, src=src, group=self.group)
 
     def barrier(self):
         dist.barrier(group=self.group)
+
+
+class HostStagedComm(TorchDistComm):
+    """VALIDATION ONLY: S ranks that share ONE GPU (a 1-GPU box; the reference's launcher does
+    the same with `--cuda-id 0`, script/reddit/run_ist_distrib.sh:16-18).  RCCL refuses two
+    ranks on one device, so the process group is `gloo` and the payloads are staged through the
+    host; everything around the collective -- HipBlocks gather/scatter, the replicated base, the
+    schedule -- is the product path.  Never used for a reported number."""
+
+    def all_gather_flat(self, out, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+        out.copy_(o)
+
+    def broadcast(self, t, src=0):
+        c = t.cpu()
+        dist.broadcast(c, src=src, group=self.group)
+        t.copy_(c)
 
 
 class LocalCommGroup(object):

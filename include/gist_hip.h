@@ -142,6 +142,21 @@ int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
 int gist_gemm_set_mode(int mode);
 int gist_gemm_get_mode(void);
 
+/* Tuning hooks: explicit, process-wide overrides of choices the launchers otherwise make
+ * themselves (value 0 = the launcher decides; the default for every knob).  They exist for
+ * sweeps (scripts/) and so that tests reach both variants of a kernel on one shape; the library
+ * never reads the environment on a launch path.  No reference counterpart (the reference has no
+ * native code); results are the same whatever the setting, within each kernel's tolerance. */
+#define GIST_TUNE_H3_MIN_GFLOP 0  /* smallest projection (GFLOP) the split path takes           */
+#define GIST_TUNE_H3_MIN_TILES 1  /* smallest number of 128x128 output tiles for the split path */
+#define GIST_TUNE_H3_TM 2         /* A-tile height of the split GEMM: 64 or 128                 */
+#define GIST_TUNE_GEMM_TILE 3     /* fp32 GEMM tile (64 or 128); needs GEMM_SPLITS too          */
+#define GIST_TUNE_GEMM_SPLITS 4   /* fp32 GEMM split-K factor                                   */
+#define GIST_TUNE_SPMM_CHUNK 5    /* rows per XCD chunk of the row-split SpMM                   */
+#define GIST_TUNE_COUNT 8
+int gist_tuning_set(int knob, double value);
+double gist_tuning_get(int knob);
+
 /* ---------------------------------------------------------------------------
  * Row-wise epilogues of one ISTSAGELayer
  * ------------------------------------------------------------------------- */
@@ -321,7 +336,7 @@ typedef struct gist_step_plan {
     float *partials;               /* colsum scratch                                */
     float *row_loss, *loss;        /* [n_max], [1]                                  */
     void *workspace; int64_t workspace_bytes;   /* split-K scratch                  */
-    void *workspace2; int64_t workspace2_bytes; /* second scratch for GIST_STEP_OVERLAP_DW  */
+    void *workspace2; int64_t workspace2_bytes; /* reserved (second scratch), may be NULL    */
     float *params, *grads, *exp_avg, *exp_avg_sq; int64_t n_params;   /* flat arenas */
     /* resident training graph + the batch buffers the extraction fills */
     const int32_t *g_rowptr, *g_col, *g_t_rowptr, *g_t_col;
@@ -364,14 +379,6 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
 
 #define GIST_STEP_EXTRACT 1   /* build the batch from ids (else: batch buffers already valid) */
 #define GIST_STEP_TRAIN 2     /* dropout on, backward + Adam (else: forward + loss only)      */
-#define GIST_STEP_OVERLAP_DW 8   /* dW = dY^T.Z (+ bias column sum) of every layer on a side
-                                    stream, concurrent with dZ = dY.W -> dropout -> SpMM on the
-                                    main stream (they only share the read of dY); joined before
-                                    Adam.  Pays where one GEMM cannot fill the chip (small
-                                    widths); needs workspace2 for the side stream's split-K   */
-#define GIST_STEP_OVERLAP_ADAM 4 /* per-layer Adam on a side stream under the backward GEMMs;
-                                    same result (each slice is updated exactly once, after
-                                    its last reader), joined before the call's work ends     */
 
 /* One iteration of the reference's training loop on the batch whose node ids (in the
  * training graph) are ids[0..n): induced subgraph + feature/label gather

@@ -1,10 +1,13 @@
-"""Dev tool: one GEMM shape under the tile/split override (GIST_GEMM_TILE / GIST_GEMM_SPLITS are
-read once per process, so run one process per configuration)."""
+"""Dev tool: one GEMM shape under the tile/split override (GIST_GEMM_TILE / GIST_GEMM_SPLITS in
+the environment of THIS script are passed to the library's tuning hooks)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gist_amd import hip
 dev = torch.device('cuda', 0)
+if os.environ.get('GIST_GEMM_TILE') and os.environ.get('GIST_GEMM_SPLITS'):
+    hip.tuning('gemm_tile', int(os.environ['GIST_GEMM_TILE']))
+    hip.tuning('gemm_splits', int(os.environ['GIST_GEMM_SPLITS']))
 lay, m, n, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 torch.manual_seed(0)
 if lay == 'nt':

@@ -13,10 +13,13 @@ SHAPES = [('nt', 2046, 4096, 8192), ('nt', 2046, 4096, 1204), ('tn', 4096, 1204,
           ('tn', 512, 1204, 2046), ('nt', 2046, 41, 1024), ('tn', 41, 1024, 2046), ('nn', 2046, 1024, 41),
           ('nt', 2046, 256, 1204), ('nt', 2046, 256, 512), ('tn', 256, 512, 2046), ('nn', 2046, 512, 256)]
 CHILD = r'''
-import sys, json, torch
+import sys, json, os, torch
 sys.path.insert(0, %r)
 from gist_amd import hip
 dev = torch.device('cuda', 0)
+if os.environ.get('GIST_GEMM_TILE') and os.environ.get('GIST_GEMM_SPLITS'):
+    hip.tuning('gemm_tile', int(os.environ['GIST_GEMM_TILE']))
+    hip.tuning('gemm_splits', int(os.environ['GIST_GEMM_SPLITS']))
 shapes = json.loads(sys.argv[1])
 out = []
 for (lay, m, n, k) in shapes:

@@ -626,6 +626,53 @@ def test_step_kept_split_operands_equal_per_call_splits(monkeypatch):
         hip.gemm_mode(prev)
 
 
+def test_wide_class_layer_stays_off_the_kept_split_path():
+    """A class layer wide enough for the split projections (C=256, 8400 batch rows, hidden
+    2048): its dY = dlogits has no row maxima from a LayerNorm backward, so the step must not
+    split it with the kept-operand scales (it takes the per-call path, which computes its own).
+    The f16x3 step must equal the f32 step: finite, losses within 2e-5, parameters close."""
+    from gist_amd import datasets, hip
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+    prev = hip.gemm_mode()
+    try:
+        runs = {}
+        ds = datasets.make_block_dataset('wide-c', 8400, 4, 64, 256, intra_deg=6, inter_deg=2, seed=11)
+        g = ds.g
+        for mode in ('f32', 'f16x3'):
+            hip.gemm_mode(mode)
+            random.seed(5)
+            it = EngineClusterIter(ds.name, g, len(ds.par_li), 4,
+                                   np.arange(g.number_of_nodes(), dtype=np.int64),
+                                   par_li=[p.copy() for p in ds.par_li], device=DEV)
+            dims = dims_for(64, 2048, 256, 2)
+            eng = SageEngine(dims, True, 0.0, it.n_max, DEV)
+            rs = np.random.RandomState(7)
+            eng.arena.load([(rs.uniform(-1, 1, (o, 2 * i)).astype(np.float32) / np.sqrt(2 * i),
+                             rs.uniform(-1, 1, o).astype(np.float32) / np.sqrt(2 * i))
+                            for (i, o) in dims])
+            # stale "row maxima" of another tensor would sit in the split workspace: poison it
+            it.bind(eng)
+            if mode == 'f16x3':
+                assert eng.plan.h3_workspace is not None      # layer 1 keeps its split operands
+                eng._h3_ws.view(torch.float32).fill_(float('nan'))
+            losses = []
+            for j, batch in enumerate(it):
+                assert batch.n >= 8192
+                losses.append(float(eng.train_step(batch, 0.01, 0.0).item()))
+                if j == 1:
+                    break
+            runs[mode] = (losses, eng.arena.params.clone())
+        la, lb = runs['f32'][0], runs['f16x3'][0]
+        assert all(np.isfinite(lb)) and torch.isfinite(runs['f16x3'][1]).all()
+        assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+        d = (runs['f32'][1] - runs['f16x3'][1]).abs()
+        assert d.mean().item() < 1e-5 and (d > TOL).float().mean().item() < 2e-2, \
+            (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+    finally:
+        hip.gemm_mode(prev)
+
+
 def test_cluster_iter_partitions_on_cache_miss(tmp_path, monkeypatch):
     """sampler.py:44-53: without a cache file ClusterIter partitions the train graph itself
     (here: gist_partition_graph instead of METIS), writes the reference's .npy format and

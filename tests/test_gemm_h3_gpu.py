@@ -14,15 +14,11 @@ DEV = 'cuda:0'
 def hip():
     from gist_amd import hip as h
     assert h.device_count() >= 1
-    import os
-    prev, prev_env = h.gemm_mode(), os.environ.get('GIST_H3_MIN_GFLOP')
-    os.environ['GIST_H3_MIN_GFLOP'] = '1'      # also exercise shapes below the production threshold
+    prev = h.gemm_mode()
+    h.tuning('h3_min_gflop', 1)      # also exercise shapes below the production threshold
     yield h
     h.gemm_mode(prev)
-    if prev_env is None:
-        del os.environ['GIST_H3_MIN_GFLOP']
-    else:
-        os.environ['GIST_H3_MIN_GFLOP'] = prev_env
+    h.tuning('h3_min_gflop', 0)
 
 
 def _run(hip, form, a, w, bias, m, n):
@@ -69,12 +65,12 @@ SHAPES = [('nt', 2046, 4096, 1204), ('nt', 2046, 4096, 8192), ('nn', 2046, 8192,
 
 
 @pytest.fixture(params=['auto', 'a_tile_64', 'a_tile_128'])
-def tile(request, monkeypatch):
-    """Both A-tile heights of the main kernel on every shape (GIST_H3_TM is read per call;
-    'auto' = the launcher's own choice)."""
-    if request.param != 'auto':
-        monkeypatch.setenv('GIST_H3_TM', request.param.split('_')[-1])
-    return request.param
+def tile(request, hip):
+    """Both A-tile heights of the main kernel on every shape (tuning hook h3_tm; 'auto' = the
+    launcher's own choice)."""
+    hip.tuning('h3_tm', 0 if request.param == 'auto' else int(request.param.split('_')[-1]))
+    yield request.param
+    hip.tuning('h3_tm', 0)
 
 
 @pytest.mark.parametrize('form,m,n,k', SHAPES)

@@ -99,3 +99,18 @@ def test_dgl_reddit_files(tmp_path):
 def test_falls_back_to_synthetic_without_files(tmp_path):
     assert ingest.try_load('reddit-self-loop', str(tmp_path)) is None
     assert ingest.try_load('amazon2m', None) is None
+
+
+def test_real_dataset_names_never_fall_back_to_synthetic(tmp_path):
+    """A missing or mistyped data root under a real dataset's name is an error that names the
+    missing files -- never a silent synthetic graph (its accuracies would be reported under the
+    real dataset's name)."""
+    import pytest
+    from gist_amd import datasets
+    for name in ('reddit', 'reddit-self-loop', 'amazon2m'):
+        with pytest.raises(FileNotFoundError) as e:
+            datasets.load_dataset(name, str(tmp_path))
+        assert 'synth' in str(e.value) and name in str(e.value)
+        with pytest.raises(FileNotFoundError):
+            datasets.load_dataset(name, None)
+    assert datasets.load_dataset('toy').name == 'toy'

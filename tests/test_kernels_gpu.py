@@ -484,42 +484,37 @@ def test_block_gather_scatter(hip):
 
 
 @pytest.mark.parametrize('tile,splits', [(128, 1), (128, 4), (64, 1), (64, 2), (64, 8)])
-def test_gemm_forced_configs(tile, splits):
+def test_gemm_forced_configs(hip, tile, splits):
     """Every (block tile, split-K) configuration the chooser can pick is correct on ragged
-    shapes for all three layouts (the override is read once per process -> subprocess)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from gist_amd import hip
-dev = torch.device('cuda', 0)
-hip.workspace(64 << 20, dev)
-rs = np.random.RandomState(0)
-worst = 0.0
-for (m, n, k) in [(130, 129, 300), (257, 41, 1204), (70, 520, 2046), (2046, 96, 200)]:
-    a = rs.randn(m, k).astype(np.float32); w = rs.randn(n, k).astype(np.float32)
-    b = rs.randn(n).astype(np.float32)
-    y = torch.full((m, n), float('nan'), device=dev)
-    hip.gemm_nt(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), y)
-    worst = max(worst, float(np.abs(y.cpu().numpy() - (a.astype(np.float64) @ w.T + b)).max()))
-    g = rs.randn(m, k).astype(np.float32); w2 = rs.randn(k, n).astype(np.float32)
-    z = torch.full((m, n), float('nan'), device=dev)
-    hip.gemm_nn(torch.from_numpy(g).to(dev), torch.from_numpy(w2).to(dev), z)
-    worst = max(worst, float(np.abs(z.cpu().numpy() - g.astype(np.float64) @ w2).max()))
-    gt = rs.randn(k, m).astype(np.float32); at = rs.randn(k, n).astype(np.float32)
-    d = torch.full((m, n), float('nan'), device=dev)
-    hip.gemm_tn(torch.from_numpy(gt).to(dev), torch.from_numpy(at).to(dev), d)
-    worst = max(worst, float(np.abs(d.cpu().numpy() - gt.T.astype(np.float64) @ at).max()))
-print('WORST', worst)
-''' % root
-    env = dict(os.environ, GIST_GEMM_TILE=str(tile), GIST_GEMM_SPLITS=str(splits))
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
-                         timeout=300)
-    assert out.returncode == 0, out.stderr[-800:]
-    worst = float([l for l in out.stdout.split('\n') if l.startswith('WORST')][0].split()[1])
+    shapes for all three layouts (tuning hooks gemm_tile / gemm_splits)."""
+    dev = torch.device(DEV)
+    hip.workspace(64 << 20, dev)
+    prev_mode = hip.gemm_mode()
+    hip.gemm_mode('f32')
+    hip.tuning('gemm_tile', tile)
+    hip.tuning('gemm_splits', splits)
+    try:
+        rs = np.random.RandomState(0)
+        worst = 0.0
+        for (m, n, k) in [(130, 129, 300), (257, 41, 1204), (70, 520, 2046), (2046, 96, 200)]:
+            a = rs.randn(m, k).astype(np.float32); w = rs.randn(n, k).astype(np.float32)
+            b = rs.randn(n).astype(np.float32)
+            y = torch.full((m, n), float('nan'), device=dev)
+            hip.gemm_nt(torch.from_numpy(a).to(dev), torch.from_numpy(w).to(dev),
+                        torch.from_numpy(b).to(dev), y)
+            worst = max(worst, float(np.abs(y.cpu().numpy() - (a.astype(np.float64) @ w.T + b)).max()))
+            g = rs.randn(m, k).astype(np.float32); w2 = rs.randn(k, n).astype(np.float32)
+            z = torch.full((m, n), float('nan'), device=dev)
+            hip.gemm_nn(torch.from_numpy(g).to(dev), torch.from_numpy(w2).to(dev), z)
+            worst = max(worst, float(np.abs(z.cpu().numpy() - g.astype(np.float64) @ w2).max()))
+            gt = rs.randn(k, m).astype(np.float32); at = rs.randn(k, n).astype(np.float32)
+            d = torch.full((m, n), float('nan'), device=dev)
+            hip.gemm_tn(torch.from_numpy(gt).to(dev), torch.from_numpy(at).to(dev), d)
+            worst = max(worst, float(np.abs(d.cpu().numpy() - gt.T.astype(np.float64) @ at).max()))
+    finally:
+        hip.tuning('gemm_tile', 0)
+        hip.tuning('gemm_splits', 0)
+        hip.gemm_mode(prev_mode)
     assert worst < 5e-4, worst          # |sum of 2046 N(0,1) products| ~ 45, fp32 accumulation
 
 
