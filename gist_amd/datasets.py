@@ -90,6 +90,73 @@ def toy(seed=2, n=2400, n_blocks=24, n_feats=32, n_classes=5, train_frac=0.7):
                               seed=seed, train_frac=train_frac)
 
 
+class CitationDataset(object):
+    """The legacy DGL citation-dataset object gcn/train.py reads (:38-45,64): numpy `features`
+    [N, F], `labels` [N], `train_mask` / `val_mask` / `test_mask` [N], `num_labels`, and `graph`
+    = a networkx DiGraph (both directions of every citation, no self loops)."""
+
+    def __init__(self, name, features, labels, train_mask, val_mask, test_mask, num_labels, src, dst):
+        import networkx as nx
+        self.name = name
+        self.features, self.labels = features, labels
+        self.train_mask, self.val_mask, self.test_mask = train_mask, val_mask, test_mask
+        self.num_labels = int(num_labels)
+        self.src, self.dst = src, dst
+        g = nx.DiGraph()
+        g.add_nodes_from(range(features.shape[0]))
+        g.add_edges_from(zip(src.tolist(), dst.tolist()))
+        self.graph = g
+
+
+def citation_synth(name='cora-synth', n=2708, n_undirected=5278, n_feats=1433, n_classes=7,
+                   train_per_class=20, n_val=500, n_test=1000, nnz_per_row=18, seed=2):
+    """Cora-like citation graph: `n_undirected` distinct undirected
+    edges without self loops, 80 % of them inside a class -- 2 * 5278 + 2708 self loops (added
+    by the training script, gcn/train.py:66-68) = 13264 directed edges at the defaults; sparse
+    0/1 bag-of-words features whose vocabulary is class-correlated, rows normalised to sum 1;
+    Planetoid-style masks (20 per class / 500 / 1000)."""
+    rs = np.random.RandomState(seed)
+    labels = rs.randint(0, n_classes, n).astype(np.int64)
+    by_class = [np.nonzero(labels == c)[0] for c in range(n_classes)]
+    seen, src, dst = set(), [], []
+    while len(src) < n_undirected:
+        u = int(rs.randint(0, n))
+        if rs.rand() < 0.8:
+            peers = by_class[labels[u]]
+            v = int(peers[rs.randint(0, len(peers))])
+        else:
+            v = int(rs.randint(0, n))
+        if u == v or (min(u, v), max(u, v)) in seen:
+            continue
+        seen.add((min(u, v), max(u, v)))
+        src.append(u)
+        dst.append(v)
+    src, dst = np.array(src, np.int64), np.array(dst, np.int64)
+    feats = np.zeros((n, n_feats), np.float32)
+    block = max(n_feats // n_classes, 1)
+    for i in range(n):
+        k_own = nnz_per_row * 2 // 3
+        own = (labels[i] * block + rs.randint(0, block, k_own)) % n_feats
+        other = rs.randint(0, n_feats, nnz_per_row - k_own)
+        feats[i, own] = 1.0
+        feats[i, other] = 1.0
+    feats /= feats.sum(1, keepdims=True)
+    train = np.zeros(n, bool)
+    for c in range(n_classes):
+        train[by_class[c][:train_per_class]] = True
+    rest = np.nonzero(~train)[0]
+    rest = rest[rs.permutation(len(rest))]
+    val, test = np.zeros(n, bool), np.zeros(n, bool)
+    val[rest[:n_val]] = True
+    test[rest[n_val:n_val + n_test]] = True
+    return CitationDataset(name, feats, labels, train, val, test, n_classes,
+                           np.concatenate([src, dst]), np.concatenate([dst, src]))
+
+
+def cora_synth(seed=2):
+    return citation_synth('cora-synth', seed=seed)
+
+
 SYNTHETIC = ('reddit-synth', 'amazon-synth', 'cora-synth', 'toy')
 
 

@@ -14,7 +14,13 @@ def register_data_args(parser):
 
 
 def load_data(args):
+    """dgl.data.load_data (cluster_gcn/utils.py:122; gcn/train.py:36): cluster datasets are
+    Dataset tuples, the citation graphs of gcn/train.py legacy objects (`.features`, `.graph` ...)."""
     from ...datasets import load_dataset
+    if args.dataset in ('cora', 'citeseer', 'pubmed'):
+        raise FileNotFoundError(
+            'gist_amd: the %s citation files are not available offline and there is no reader for '
+            'them here; the seeded Cora-like stand-in is --dataset cora-synth' % args.dataset)
     return load_dataset(args.dataset, getattr(args, 'data_root', None))
 
 

@@ -15,6 +15,8 @@ UNCHANGED and records inputs + outputs as small .npz fixtures:
   G3_sampler.npz   ClusterIter batch order + batch 0 subgraph (sampler.py, partition_utils.py)
   G4_ist_*.npz     create_partition, dispatch/sync under gloo (cluster_gcn_ist_distrib.py:51-367)
   G5_graphconv.npz gcn/gcn.py forward on the stub's GraphConv  (parity UNPINNED: DGL recalled)
+  G5_train_*.npz   gcn/train.py main() end to end (BASELINE config 1, Cora plumbing): per-epoch
+                   losses, accuracies, initial and final parameters on a small citation graph
   G6_e2e_*.npz     whole training runs of cluster_gcn.py main() and
                    cluster_gcn_ist_distrib.py train() on a toy graph
 
@@ -336,6 +338,88 @@ def gen_G5():
     sys.modules.pop('gcn', None)
 
 
+def gen_G5_train():
+    """gcn/train.py main() UNCHANGED on a small Cora-like citation graph (CPU), recorded
+    through three spies: the GCN constructor (initial + final parameters), the loss module
+    (per-epoch training loss) and evaluate() (val / test accuracy per epoch)."""
+    import contextlib
+    import importlib.util
+    import io
+    import torch
+    if REPO not in sys.path:
+        sys.path.append(REPO)
+    from gist_amd.datasets import citation_synth          # pure numpy data generator
+    gdir = os.path.join(REF, 'gcn')
+    sys.path.insert(0, gdir)
+    sys.modules.pop('gcn', None)
+    spec = importlib.util.spec_from_file_location('ref_gcn_train', os.path.join(gdir, 'train.py'))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cases = [('ln1_L1', dict(use_layernorm='True', n_layers=1, n_hidden=16, lr_scheduler=False,
+                             weight_decay=5e-4, n_epochs=12, lr=0.01)),
+             ('ln0_L2', dict(use_layernorm='False', n_layers=2, n_hidden=24, lr_scheduler=True,
+                             weight_decay=0.0, n_epochs=8, lr=0.02))]
+    for tag, cfg in cases:
+        data = citation_synth('cora-mini', n=300, n_undirected=700, n_feats=60, n_classes=7,
+                              train_per_class=5, n_val=60, n_test=100, nnz_per_row=9, seed=12)
+        state = {}
+        real_gcn, real_eval, real_ce = ref.GCN, ref.evaluate, torch.nn.CrossEntropyLoss
+        losses, accs = [], []
+
+        def spy_gcn(*a, **k):
+            m = real_gcn(*a, **k)
+            state['model'] = m
+            state['init'] = [(l.weight.detach().numpy().copy(), l.bias.detach().numpy().copy())
+                             for l in m.layers]
+            return m
+
+        class SpyCE(real_ce):
+            def forward(self, inp, tgt):
+                out = super().forward(inp, tgt)
+                losses.append(float(out.detach()))
+                return out
+
+        def spy_eval(*a, **k):
+            acc = real_eval(*a, **k)
+            accs.append(acc)
+            return acc
+
+        ref.GCN, ref.evaluate, ref.load_data = spy_gcn, spy_eval, (lambda args: data)
+        torch.nn.CrossEntropyLoss = SpyCE
+        args = argparse.Namespace(dataset='cora', dropout=0.0, gpu=-1, self_loop='True', **cfg)
+        torch.manual_seed(21)
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                ref.main(args)
+        finally:
+            ref.GCN, ref.evaluate = real_gcn, real_eval
+            torch.nn.CrossEntropyLoss = real_ce
+        tail = [l for l in buf.getvalue().strip().split('\n') if 'Accuracy' in l]
+        m = state['model']
+        n_ep = cfg['n_epochs']
+        assert len(losses) == n_ep and len(accs) == 2 * n_ep + 1
+        rec = dict(src=data.src, dst=data.dst, n=data.features.shape[0], feat=data.features,
+                   label=data.labels, train_mask=data.train_mask, val_mask=data.val_mask,
+                   test_mask=data.test_mask, n_classes=data.num_labels,
+                   losses=np.array(losses, np.float32),
+                   val_accs=np.array(accs[0:2 * n_ep:2]), test_accs=np.array(accs[1:2 * n_ep:2]),
+                   final_test=accs[-1], n_edges_with_loops=m.g.number_of_edges(),
+                   tail_keys=np.array([t.split(':')[0] for t in tail]),
+                   tail_vals=np.array([float(t.split(':')[1]) for t in tail]),
+                   use_layernorm=cfg['use_layernorm'] == 'True', n_layers=cfg['n_layers'],
+                   n_hidden=cfg['n_hidden'], lr=cfg['lr'], weight_decay=cfg['weight_decay'],
+                   n_epochs=n_ep, lr_scheduler=cfg['lr_scheduler'], seed=21)
+        for k, (W, b) in enumerate(state['init']):
+            rec['init_W%d' % k], rec['init_b%d' % k] = W, b
+        for k, l in enumerate(m.layers):
+            rec['final_W%d' % k] = l.weight.detach().numpy()
+            rec['final_b%d' % k] = l.bias.detach().numpy()
+        np.savez_compressed(os.path.join(OUT, 'G5_train_%s.npz' % tag), **rec)
+    sys.path.remove(gdir)
+    sys.modules.pop('gcn', None)
+
+
 # ---------------------------------------------------------------------------
 def _patch_data(mod, g, ncls):
     from collections import namedtuple
@@ -512,8 +596,8 @@ def main():
     assert os.path.isdir(REF), 'golden generation needs /root/reference'
     _setup_paths()
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['G1', 'G2', 'G3', 'G4', 'G5', 'G6s', 'G6i']
-    fns = dict(G1=gen_G1, G2=gen_G2, G3=gen_G3, G4=gen_G4, G5=gen_G5,
+    which = sys.argv[1:] or ['G1', 'G2', 'G3', 'G4', 'G5', 'G5t', 'G6s', 'G6i']
+    fns = dict(G1=gen_G1, G2=gen_G2, G3=gen_G3, G4=gen_G4, G5=gen_G5, G5t=gen_G5_train,
                G6s=gen_G6_single, G6i=gen_G6_ist)
     for w in which:
         print('generating', w, flush=True)

@@ -259,3 +259,32 @@ def test_G6_e2e_ist(golden_dir, S):
     assert abs(res['val_accs'][-1] - tail['Last Val']) < 1e-4
     assert abs(max(res['val_accs']) - tail['Best Val']) < 1e-4
     assert abs(res['test_accs'][-1] - tail['Last Test']) < 1e-4
+
+
+@pytest.mark.parametrize('tag', ['ln1_L1', 'ln0_L2'])
+def test_G5_train_cora_loop(golden_dir, tag):
+    """BASELINE config 1: the oracle's restatement of gcn/train.py's loop (oracle/gcn_oracle.py)
+    against a run of the reference's main() on a small citation graph -- per-epoch training
+    loss, val/test accuracy per epoch, final parameters, the three printed accuracies."""
+    from oracle import gcn_oracle as G
+    d = _load(golden_dir, 'G5_train_%s.npz' % tag)
+    n, L = int(d['n']), int(d['n_layers'])
+    src, dst = G.with_self_loops(d['src'], d['dst'], n)
+    assert len(src) == int(d['n_edges_with_loops'])
+    g = G.CitationGraph(src, dst, n)
+    init = [(d['init_W%d' % k], d['init_b%d' % k]) for k in range(L + 1)]
+    losses, record, params = G.train(g, d['feat'], d['label'], d['train_mask'], d['val_mask'],
+                                     d['test_mask'], init, bool(d['use_layernorm']), float(d['lr']),
+                                     float(d['weight_decay']), int(d['n_epochs']),
+                                     lr_scheduler=bool(d['lr_scheduler']))
+    assert np.abs(losses - d['losses']).max() < 1e-4
+    assert np.allclose([r[0] for r in record], d['val_accs'], atol=1e-9)
+    assert np.allclose([r[1] for r in record], d['test_accs'], atol=1e-9)
+    for k, (W, b) in enumerate(params):
+        assert np.abs(W - d['final_W%d' % k]).max() < 1e-4, k
+        assert np.abs(b - d['final_b%d' % k]).max() < 1e-4, k
+    tail = dict(zip([str(k) for k in d['tail_keys']], d['tail_vals']))
+    assert abs(record[-1][1] - tail['Final Test Accuracy']) < 1e-4
+    assert abs(max(r[0] for r in record) - tail['Best Val Accuracy']) < 1e-4
+    assert abs(max(r[1] for r in record) - tail['Best Test Accuracy']) < 1e-4
+    assert losses[-1] < losses[0]                       # it trains
