@@ -562,7 +562,7 @@ static int g_h3_mode = -1;      // -1: read GIST_GEMM_MODE on first use
 int h3_mode() {
     if (g_h3_mode < 0) {
         const char *e = getenv("GIST_GEMM_MODE");
-        g_h3_mode = 1;
+        g_h3_mode = 0;      // default: fp32 products (v_mfma_f32_32x32x2_f32), like the reference's nn.Linear
         if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) g_h3_mode = 0;
         else if (e && (!strcmp(e, "f16x3") || !strcmp(e, "1"))) g_h3_mode = 1;
     }

@@ -575,7 +575,6 @@ extern "C" int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t l
     GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_ln_relu_fwd_f32: negative size");
     if (n_rows == 0 || d == 0) return GIST_OK;
     GIST_REQUIRE(y && out, "gist_ln_relu_fwd_f32: null pointer");
-    GIST_REQUIRE(!use_lynorm || rstd, "gist_ln_relu_fwd_f32: rstd is NULL with use_lynorm");
     GIST_REQUIRE(ldy >= d && ldo >= d, "gist_ln_relu_fwd_f32: leading dimension < d");
     GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_ln_relu_fwd_f32: size >= 2^31");
     const bool v4 = d % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out);

@@ -164,8 +164,9 @@ def _ws_for(m, n, k, device):
 
 def gemm_mode(mode=None):
     """Get (and with an argument, set) how large projections form their products:
-    'f32' = v_mfma_f32_32x32x2_f32 everywhere, 'f16x3' = split operands on the f16 matrix cores
-    (fp32-level accuracy, include/gist_hip.h gist_gemm_set_mode).  Process-wide."""
+    'f32' (default) = v_mfma_f32_32x32x2_f32 everywhere, fp32 arithmetic like the reference;
+    'f16x3' (opt-in) = split operands on the f16 matrix cores (22-bit operands, fp32-level
+    accuracy on the step's data; include/gist_hip.h gist_gemm_set_mode).  Process-wide."""
     L = _lib.load()
     if mode is not None:
         code = {'f32': 0, 'f16x3': 1, 0: 0, 1: 1}.get(mode)

@@ -285,7 +285,8 @@ def train(ist_model, args, cluster_iterator, evaluator=None, log=print):
     is_rank0 = models[0].rank == 0
     local_epochs = args.n_epochs // args.num_subnet                      # :385
     losses = [[] for _ in models]
-    events, val_accs, test_accs = [], [], []
+    events, val_accs, test_accs, trn_losses = [], [], [], []
+    loss_mark = 0
     total_iter, total_time = 0, 0.0
     n_iters = len(cluster_iterator)
     dev = models[0].device
@@ -330,12 +331,16 @@ def train(ist_model, args, cluster_iterator, evaluator=None, log=print):
                     if is_rank0 and evaluator is not None:
                         val_accs.append(evaluator.accuracy('val_mask'))
                         test_accs.append(evaluator.accuracy('test_mask'))
+                        # :432-433,446 -- mean training loss of rank 0 since the last evaluation
+                        seg = losses[0][loss_mark:]
+                        trn_losses.append(float(torch.stack(seg).mean().item()) if seg else 0.0)
+                        loss_mark = len(losses[0])
                     sync_dev()
                     start_time = time.time()
     if multi:
         comm.barrier()
     return dict(total_time=total_time, losses=losses, events=events, val_accs=val_accs,
-                test_accs=test_accs)
+                test_accs=test_accs, trn_losses=trn_losses)
 
 
 def print_results(res, log=print):

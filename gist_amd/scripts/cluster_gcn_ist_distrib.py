@@ -52,7 +52,23 @@ def build_parser():
     return parser
 
 
-def main(args=None, dataset=None, log=print):
+def save_results(args, res, log=print):
+    """:455-473 -- with --save_results the reference writes `{fig_name}_result.pckl` (total_time,
+    trn_losses, val_accs, test_accs) under --fig-dir, which its sweep drivers read back
+    (script/reddit/run_ist_sweep_reddit.py), INSTEAD of printing the five result lines.  The
+    validation-accuracy PNG of :457-461 is not produced (matplotlib reporting is out of scope)."""
+    import os
+    import pickle
+    os.makedirs(args.fig_dir, exist_ok=True)
+    results = {'total_time': res['total_time'], 'trn_losses': res['trn_losses'],
+               'val_accs': res['val_accs'], 'test_accs': res['test_accs']}
+    path = os.path.join(args.fig_dir, args.fig_name + '_result.pckl')
+    with open(path, 'wb') as f:
+        pickle.dump(results, f)
+    return path
+
+
+def main(args=None, dataset=None, log=print, ultra_wide=False):
     from gist_amd import ist
     from gist_amd.dgl_compat.data import load_data
     from gist_amd.modules import GCN
@@ -61,6 +77,14 @@ def main(args=None, dataset=None, log=print):
     if args is None:
         args = build_parser().parse_args()
     assert (args.n_hidden % args.num_subnet) == 0
+    if args.use_pp:
+        raise NotImplementedError(
+            'gist_amd: --use-pp cannot work with GCN / ISTSAGELayer in the reference either (the '
+            'feature width doubles after in_feats was read, SURVEY.md appendix C.8); the layer-0 '
+            'pre-aggregation is offered as ClusterIter(..., use_pp=True) + GraphSAGE-style layers')
+    if args.use_f1:
+        log('note: --use-f1 reports micro-F1, which equals argmax accuracy for single-label '
+            'classification (cluster_gcn/utils.py:47-67)', flush=True)
     log('Setting seeds', flush=True)
     torch.manual_seed(args.rnd_seed)                        # :570-572, same seed on every rank
     np.random.seed(args.rnd_seed)
@@ -98,10 +122,16 @@ def main(args=None, dataset=None, log=print):
     it.bind(model.engine)
     evaluator = None
     if args.rank == 0:
-        evaluator = FullGraphEvaluator(g, model.base_dims, args.use_layernorm, model.base, device)
+        # ultra-wide (cluster_gcn_ist_ultra_wide.py:500-504 evaluates on the CPU because [N, 2H]
+        # does not fit its GPU): the evaluator works block of rows by block of rows in HBM
+        evaluator = FullGraphEvaluator(g, model.base_dims, args.use_layernorm, model.base, device,
+                                       block_bytes=(1 << 30) if ultra_wide else (4 << 30))
     res = ist.train(model, args, it, evaluator=evaluator, log=log)
     if args.rank == 0:
-        ist.print_results(res, log=log)                      # :475-479
+        if args.save_results:
+            log('results written to %s' % save_results(args, res, log=log), flush=True)
+        else:
+            ist.print_results(res, log=log)                  # :475-479
     dist.destroy_process_group()
     return res
 

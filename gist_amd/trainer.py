@@ -26,17 +26,84 @@ def full_graph_batch(g, labels_i32):
 
 class FullGraphEvaluator(object):
     """utils.evaluate (cluster_gcn/utils.py:70-80): eval-mode forward over the WHOLE graph
-    with the current parameters, accuracy over a mask.  Shares the training arena."""
+    with the current parameters, accuracy over a mask.  Shares the training arena.
 
-    def __init__(self, g, dims, use_layernorm, arena, device):
+    Inference-only layout, sized so that the ultra-wide model (H = 32768: cluster_gcn_ist_
+    ultra_wide.py moves this evaluation to the CPU, :500-504) runs in HBM: two [N, H] activation
+    buffers (ping-pong) and ONE row block of the concatenated operand [rows, 2*in] -- a layer is
+    evaluated block of rows by block of rows (aggregate the block's rows over the full graph,
+    project, normalise), never materialising [N, 2*in].  The narrowing class layer aggregates
+    its C-wide projection instead of the H-wide activations ([h | A^h] W^T = h W1^T + A^(h W2^T)).
+    Reddit at H = 32768: 2 x 30.5 GB + 4 GB instead of ~250 GB."""
+
+    def __init__(self, g, dims, use_layernorm, arena, device, row_block=None,
+                 block_bytes=4 << 30):
         self.g = g if g.device == device else g.to(device)
+        self.dims = [(int(i), int(o)) for i, o in dims]
+        self.use_layernorm = bool(use_layernorm)
+        self.arena, self.device = arena, device
         n = self.g.number_of_nodes()
-        self.eng = SageEngine(dims, use_layernorm, 0.0, n_max=n, device=device, arena=arena)
+        self.n = n
         self.feat = self.g.ndata['feat']
         lab = self.g.ndata['label']
         self.labels = (lab if lab.dtype == torch.int32 else lab.to(torch.int32)).contiguous()
-        self.batch = full_graph_batch(self.g, self.labels)
+        self.norm = self.g.norm()
+        f32 = dict(dtype=torch.float32, device=device)
+        L1 = len(self.dims)
+        self.n_classes = self.dims[-1][1]
+        self.ldc = (self.n_classes + 3) // 4 * 4
+        # the class layer is evaluated projection-first when it narrows (always, in practice)
+        self.project_first = self.dims[-1][1] < self.dims[-1][0]
+        blocked = self.dims[:-1] if self.project_first else self.dims
+        max_in = max([i for (i, o) in blocked] + [1])
+        max_out = max([o for (i, o) in blocked] + [1])
+        if row_block is None:
+            row_block = max(4096, int(block_bytes // (8 * max_in)))
+        self.row_block = int(min(max(row_block, 1), n))
+        hidden = max([o for (i, o) in self.dims[:-1]] + [1])
+        self.h = [torch.empty(n, hidden, **f32) for _ in range(2 if L1 > 2 else 1)] if L1 > 1 else []
+        self.zb = torch.empty(self.row_block, 2 * max_in, **f32) if blocked else None
+        self.yb = torch.empty(self.row_block, max_out, **f32) if blocked else None
+        self.logits = torch.empty(n, self.ldc, **f32)
+        self.pbuf = torch.empty(n, self.ldc, **f32) if self.project_first else None
+        self.correct = torch.zeros(1, dtype=torch.int32, device=device)
+        need = 0
+        L = hip._lib.load()
+        for (i, o) in self.dims:
+            need = max(need, L.gist_gemm_workspace_bytes(self.row_block, o, 2 * i),
+                       L.gist_gemm_workspace_bytes(n, o, i))
+        hip.workspace(need, device)
         self.masks = {}
+
+    def forward(self):
+        """GCN.forward (modules.py:310-314) in eval mode over the full graph -> logits [N, C]."""
+        g, A, n = self.g, self.arena, self.n
+        L1 = len(self.dims)
+        cur = self.feat
+        for k, (i, o) in enumerate(self.dims):
+            last = k == L1 - 1
+            W, b = A.W[k], A.b[k]
+            if last and self.project_first:
+                p = self.pbuf[:, :o]
+                out = self.logits[:, :o]
+                hip.gemm_nt(cur[:, :i], W[:, i:], None, p)
+                hip.gemm_nt(cur[:, :i], W[:, :i], b, out)
+                hip.spmm(g.rowptr, g.col, p, out, out_scale=self.norm, accumulate=True)
+                break
+            dst = self.logits if last else self.h[k % len(self.h)]
+            for r0 in range(0, n, self.row_block):
+                r1 = min(r0 + self.row_block, n)
+                z = self.zb[:r1 - r0, :2 * i]
+                hip.block_gather(cur[r0:r1, :i], None, None, z[:, :i])
+                hip.spmm(g.rowptr[r0:r1 + 1], g.col, cur[:, :i], z[:, i:], out_scale=self.norm[r0:r1])
+                if last:
+                    hip.gemm_nt(z, W, b, dst[r0:r1, :o])
+                else:
+                    y = self.yb[:r1 - r0, :o]
+                    hip.gemm_nt(z, W, b, y)
+                    hip.ln_relu_fwd(y, dst[r0:r1, :o], None, self.use_layernorm, True)
+            cur = dst
+        return self.logits[:, :self.n_classes]
 
     def accuracy(self, mask_name):
         if mask_name not in self.masks:
@@ -45,12 +112,10 @@ class FullGraphEvaluator(object):
         m, total = self.masks[mask_name]
         if total == 0:
             return -1
-        n = self.batch.n
-        hip.block_gather(self.feat, None, None, self.eng.z0_left(n))
-        self.eng.forward(self.batch, training=False)
-        self.eng.correct.zero_()
-        self.eng.count_correct(self.batch, m)
-        return self.eng.correct.item() / total
+        logits = self.forward()
+        self.correct.zero_()
+        hip.argmax_correct(logits, self.labels, m, self.correct)
+        return self.correct.item() / total
 
 
 class ClusterGCNTrainer(object):

@@ -128,17 +128,20 @@ int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
                      float *d, int64_t ldd, int64_t m, int64_t n, int64_t k,
                      void *workspace, int64_t workspace_bytes, gist_stream_t stream);
 
-/* How the three entry points above form their products on shapes large enough to fill the
- * chip (>= 64 output tiles of 128x128, >= 16 GFLOP, 16-byte aligned operands, workspace of
- * gist_gemm_workspace_bytes): mode 1 (default; GIST_GEMM_MODE=f16x3) splits each fp32 operand
- * once into two f16 halves under one power-of-two scale per operand row (22 significant bits)
- * and accumulates ah.bh + ah.bl + al.bh in fp32 on v_mfma_f32_16x16x32_f16 -- fp32-level
- * accuracy (error against fp64 equal to mode 0's, tests/test_gemm_h3_gpu.py) at 1/5 of the
- * matrix-core time; mode 0 (GIST_GEMM_MODE=f32) keeps every shape on v_mfma_f32_32x32x2_f32.
- * Inputs and outputs are fp32 in both modes; small and skinny shapes always take mode 0's
- * kernel.  A NaN or Inf in an operand row makes the corresponding output row / column
- * non-finite (NaN where fp32 would give Inf) and leaves all other outputs unchanged.  Process-wide; set it before sizing workspaces.  Both replace the same call,
- * self.linear(h), cluster_gcn/modules.py:233, and its autograd. */
+/* How the three entry points above form their products.  Mode 0 (the default; GIST_GEMM_MODE=f32
+ * read once at first use) keeps every shape on v_mfma_f32_32x32x2_f32: fp32 products and fp32
+ * accumulation, the arithmetic of the reference's nn.Linear.  Mode 1 (opt-in; GIST_GEMM_MODE=f16x3)
+ * changes shapes large enough to fill the chip (>= 64 output tiles of 128x128, >= 16 GFLOP,
+ * 16-byte aligned operands, workspace of gist_gemm_workspace_bytes): each fp32 operand is split
+ * once into two f16 halves under one power-of-two scale per operand row (22 of fp32's 24
+ * significant bits) and ah.bh + ah.bl + al.bh is accumulated in fp32 on v_mfma_f32_16x16x32_f16 --
+ * error against fp64 at mode 0's level on the step's operands (tests/test_gemm_h3_gpu.py) at
+ * about half the time, but narrower operand arithmetic than fp32 by construction.  Inputs and
+ * outputs are fp32 in both modes; small and skinny shapes always take mode 0's kernel.  In mode 1
+ * a NaN or Inf in an operand row makes the corresponding output row / column non-finite (NaN
+ * where fp32 would give Inf) and leaves all other outputs unchanged.  Process-wide; set it
+ * before sizing workspaces.  Both replace the same call, self.linear(h),
+ * cluster_gcn/modules.py:233, and its autograd. */
 int gist_gemm_set_mode(int mode);
 int gist_gemm_get_mode(void);
 
@@ -166,7 +169,7 @@ double gist_tuning_get(int knob);
  * cluster_gcn/modules.py:209,234), then out = relu ? max(yhat,0) : yhat is written
  * to `out` (ldo) -- normally the LEFT half of the next layer's [h | ah] buffer.
  * y keeps yhat (needed by the backward); rstd[n_rows] receives 1/sqrt(var+eps)
- * (may be NULL when !use_lynorm).  Replaces modules.py:234-236. */
+ * (NULL: not stored -- inference, or !use_lynorm).  Replaces modules.py:234-236. */
 int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t ldo,
                          float *rstd, int64_t n_rows, int64_t d,
                          int use_lynorm, int relu, float eps, gist_stream_t stream);

@@ -126,3 +126,58 @@ def test_zero_edit_drop_in_script_matches_engine_path():
         assert np.abs(layer.linear.weight.detach().cpu().numpy() - W).max() < 1e-4
         assert np.abs(layer.linear.bias.detach().cpu().numpy() - b).max() < 1e-4
     assert abs(tr.evaluate('val_mask') - acc_script) < 1e-9
+
+
+def test_ultra_wide_cli_and_save_results(tmp_path):
+    """cluster_gcn_ist_ultra_wide.py's flags are cluster_gcn_ist_distrib.py's; here it is the same
+    wrapper and loop with the row-blocked evaluator.  --save_results writes the pickle the
+    reference's sweep drivers read ({fig_name}_result.pckl: total_time, trn_losses, val_accs,
+    test_accs; cluster_gcn_ist_distrib.py:463-473) instead of the five lines; --use-pp is
+    rejected loudly (it cannot work with ISTSAGELayer in the reference either)."""
+    import pickle
+    from gist_amd import datasets
+    from gist_amd.scripts import cluster_gcn_ist_distrib as ref_cli
+    from gist_amd.scripts import cluster_gcn_ist_ultra_wide as cli
+    assert vars(cli.build_parser().parse_args([])) == vars(ref_cli.build_parser().parse_args([]))
+    argv = ['--dataset', 'toy', '--num_subnet', '1', '--n-epochs', '2', '--batch-size', '4',
+            '--n-hidden', '64', '--n-layers', '2', '--iter_per_site', '3', '--use_layernorm', 'True',
+            '--dropout', '0.0', '--weight-decay', '0', '--fig-dir', str(tmp_path), '--fig-name', 'uw']
+    lines = []
+    log = lambda *a, **k: lines.append(' '.join(map(str, a)))
+    res = cli.main(cli.build_parser().parse_args(argv + ['--dist-url', 'tcp://127.0.0.1:29879']),
+                   dataset=datasets.toy(), log=log)
+    assert [l.split(':')[0] for l in lines[-5:]] == TAIL
+    assert len(res['trn_losses']) == len(res['val_accs']) and all(l > 0 for l in res['trn_losses'])
+    lines.clear()
+    res2 = cli.main(cli.build_parser().parse_args(argv + ['--save_results', '--dist-url',
+                                                          'tcp://127.0.0.1:29880']),
+                    dataset=datasets.toy(), log=log)
+    assert not any(l.startswith('Last Val') for l in lines)          # pickle instead of the lines
+    got = pickle.load(open(tmp_path / 'uw_result.pckl', 'rb'))
+    assert sorted(got) == ['test_accs', 'total_time', 'trn_losses', 'val_accs']
+    assert got['val_accs'] == res2['val_accs'] and got['trn_losses'] == res2['trn_losses']
+    with pytest.raises(NotImplementedError):
+        cli.main(cli.build_parser().parse_args(argv + ['--use-pp']), dataset=datasets.toy(), log=log)
+
+
+def test_evaluator_row_blocks_agree():
+    """FullGraphEvaluator evaluates a layer block of rows by block of rows (what lets the
+    ultra-wide model evaluate in HBM): any row block gives the same logits as one block."""
+    from gist_amd import datasets
+    from gist_amd.engine import ParamArena, dims_for
+    from gist_amd.trainer import FullGraphEvaluator
+    dev = torch.device('cuda', 0)
+    ds = datasets.toy(seed=3)
+    g = ds.g
+    dims = dims_for(g.ndata['feat'].shape[1], 96, ds.num_classes, 3)
+    arena = ParamArena(dims, dev, with_grads=False)
+    gen = torch.Generator().manual_seed(2)
+    arena.load([((torch.rand(o, 2 * i, generator=gen) - 0.5) * 0.4, (torch.rand(o, generator=gen) - 0.5) * 0.4)
+                for (i, o) in dims])
+    whole = FullGraphEvaluator(g, dims, True, arena, dev, row_block=g.number_of_nodes())
+    ref = whole.forward().clone()
+    for rb in (1000, 257, 64):
+        ev = FullGraphEvaluator(g, dims, True, arena, dev, row_block=rb)
+        assert ev.row_block == rb
+        assert (ev.forward() - ref).abs().max().item() < 1e-5
+        assert abs(ev.accuracy('val_mask') - whole.accuracy('val_mask')) < 1e-9

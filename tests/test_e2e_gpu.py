@@ -354,6 +354,109 @@ def test_ist_wide_block_algebra_properties():
         assert torch.equal(m.sub.b[L], models[0].base.b[L])
 
 
+def test_config5_ultra_wide_H32768_S8():
+    """BASELINE config 5 at its full size on one GPU: n_hidden 32768, 8 sub-GCNs of width 4096,
+    n_layers 2 -- an 8.8 GB base model per site, resident in HBM (cluster_gcn_ist_ultra_wide.py
+    keeps it on the host, :84).  (1) dispatch -> sync without training is the bit-exact identity
+    on every replica; (2) one training step of a 4096-wide sub-GCN on its dispatched weights
+    equals the oracle's; (3) after a perturbation of every sub-model only the 8 diagonal blocks
+    of W1 [32768, 65536] change, by exactly the perturbation, and the shared class bias becomes
+    the mean; (4) a re-dispatch hands every site the block of the synced base it indexes."""
+    from gist_amd import datasets, ist
+    from gist_amd.engine import dims_for
+    from gist_amd.sampler import EngineClusterIter
+    from oracle import gist_oracle as O
+    from oracle import train_oracle as TO
+    S, H, L, F, C = 8, 32768, 2, 602, 41
+    random.seed(6)
+    ds = datasets.make_block_dataset('uw-toy', 6000, 60, F, C, intra_deg=6, inter_deg=2, seed=13)
+    g = ds.g
+    it = EngineClusterIter(ds.name, g, len(ds.par_li), 5, np.arange(g.number_of_nodes(), dtype=np.int64),
+                           par_li=[p.copy() for p in ds.par_li], device=DEV)
+    group = ist.LocalCommGroup(S)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    base_dims = dims_for(F, H, C, L)
+    base_init = [((torch.rand(o, 2 * i, device=DEV, generator=gen) * 2 - 1) / np.sqrt(2 * i),
+                  (torch.rand(o, device=DEV, generator=gen) * 2 - 1) / np.sqrt(2 * i))
+                 for (i, o) in base_dims]
+    models = []
+    for r in range(S):
+        args = argparse.Namespace(num_subnet=S, n_hidden=H, n_layers=L, rank=r, dropout=0.0,
+                                  use_layernorm=True)
+        models.append(ist.DistributedGNNWrapper(args, None, F, C, DEV,
+                                                base_init=base_init if r == 0 else None,
+                                                comm=group.handle(r),
+                                                n_max=it.n_max if r == 0 else None))
+    del base_init
+    assert models[0].base.numel * 4 > 8.7e9 and models[0].sub_dims == dims_for(F, 4096, C, L)
+    part = models[0].sample_partitions()
+    for m in models:
+        m.ini_sync_dispatch_model(part)
+    base0 = models[0].base.params.clone()
+    # (1) identity
+    for m in models:
+        m.sync_gather()
+    for m in models:
+        m.sync_apply()
+    for m in models:
+        assert torch.equal(m.base.params, base0)
+    # (2) one sub-model step (h = 4096) against the oracle, then put the weights back
+    m0 = models[0]
+    saved = m0.sub.params.clone()
+    params = m0.sub.export()
+    it.bind(m0.engine)
+    batch = next(iter(it))
+    loss = m0.engine.train_step(batch, 0.01, 0.0)
+    logits = m0.engine.logits(batch.n).cpu().numpy()
+    tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
+                       g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
+    b = tg.batch(it.batch_ids(0))
+    opt = O.new_opt_state(params)
+    ref_loss, ref_logits, _ = O.train_step(b[0], b[1], b[2], b[3], b[4], b[5], params, opt, True, 0.01)
+    assert abs(float(loss.item()) - float(ref_loss)) < TOL
+    assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max())
+    errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in zip(m0.sub.export(), params)])
+    assert float(errs.mean()) < 1e-5 and float((errs > TOL).mean()) < 2e-2
+    m0.sub.params.copy_(saved)
+    m0.sub.reset_optimizer()
+    del saved, params, errs
+    # (3) perturb, sync, block structure of W1 [H, 2H]
+    for r, m in enumerate(models):
+        m.sub.params.add_(1.0 + r)
+    for m in models:
+        m.sync_gather()
+    for m in models:
+        m.sync_apply()
+    for m in models[1:]:
+        assert torch.equal(m.base.params, models[0].base.params)
+    w0, w1 = models[0].base.offsets[1]
+    W1_old = base0[w0:w1].view(H, 2 * H)
+    W1_new = models[0].base.W[1]
+    expect = torch.zeros(H, 2 * H, dtype=torch.bool, device=DEV)
+    for s in range(S):
+        rows = part[1][s][0].to(DEV)
+        cols = part[0][s][1].to(DEV)
+        expect[rows[:, None], cols[None, :]] = True
+        blk = W1_new[rows[:, None], cols[None, :]] - W1_old[rows[:, None], cols[None, :]]
+        assert torch.allclose(blk, torch.full_like(blk, 1.0 + s), atol=1e-6)
+        del blk
+    assert torch.equal(W1_new != W1_old, expect)
+    assert int(expect.sum().item()) == S * (H // S) * (2 * H // S)
+    del expect
+    bL_old = base0[models[0].base.offsets[L][1]:models[0].base.offsets[L][1] + C]
+    assert torch.allclose(models[0].base.b[L], bL_old + 1.0 + (S - 1) / 2.0, atol=1e-5)
+    # (4) re-dispatch under a new partition: every site gets the block it indexes
+    part2 = models[0].sample_partitions()
+    for m in models:
+        m.dispatch_model(part2)
+    for s in (0, 5):
+        rows = part2[1][s][0].to(DEV)
+        cols = part2[0][s][1].to(DEV)
+        assert torch.equal(models[s].sub.W[1], models[s].base.W[1][rows[:, None], cols[None, :]])
+        assert torch.equal(models[s].sub.W[0], models[s].base.W[0][part2[0][s][0].to(DEV)])
+        assert torch.equal(models[s].sub.W[2], models[s].base.W[2][:, part2[1][s][1].to(DEV)])
+
+
 def test_drop_in_evaluate_matches_engine_evaluator():
     """gist_amd.utils.evaluate(model, g, labels, mask) (cluster_gcn/utils.py:70-80 signature)
     on the nn.Module path == FullGraphEvaluator on the engine path, same parameters."""
