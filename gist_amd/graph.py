@@ -163,18 +163,13 @@ class Graph(object):
             self._remap = torch.empty(self._n, dtype=torch.int32, device=dev)
             hip.fill_i32_(self._remap, -1)
         remap = self._remap
-        hip.induced_mark(ids, remap)
-        srp = torch.empty(nb + 1, dtype=torch.int32, device=dev)
-        trp = torch.empty(nb + 1, dtype=torch.int32, device=dev)
-        hip.induced_rowptr(self.rowptr, self.col, ids, remap, srp)
-        hip.induced_rowptr(self.t_rowptr, self.t_col, ids, remap, trp)
-        nnz = int(srp[-1].item())            # one host sync: this generic path sizes exactly
-        scl = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-        tcl = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-        hip.induced_fill(self.rowptr, self.col, ids, remap, srp, scl)
-        hip.induced_fill(self.t_rowptr, self.t_col, ids, remap, trp, tcl)
-        hip.induced_mark(ids, remap, unmark=True)
-        sg = Graph(srp, scl[:nnz], trp, tcl[:nnz], nb, self._idtype)
+        from . import ops  # noqa: F401  (registers torch.ops.gist.*)
+        # the generic path sizes the column arrays exactly: one host sync per structure (the
+        # training loop's batches come from gist_extract_batch inside the step instead)
+        srp, scl = torch.ops.gist.induced_subgraph(self.rowptr, self.col, ids, remap)
+        trp, tcl = torch.ops.gist.induced_subgraph(self.t_rowptr, self.t_col, ids, remap)
+        nnz = scl.numel()
+        sg = Graph(srp, scl, trp, tcl, nb, self._idtype)
         sg._nnz = nnz
         idl = None
         for k, v in self.ndata.items():

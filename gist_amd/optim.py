@@ -8,7 +8,7 @@ one launch; otherwise one launch per tensor.
 """
 import torch
 
-from . import hip
+from . import ops  # noqa: F401  (registers torch.ops.gist.*)
 
 
 class Adam(object):
@@ -40,5 +40,5 @@ class Adam(object):
                                  torch.zeros_like(p.data, memory_format=torch.contiguous_format))
             m, v = self.state[i]
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            hip.adam_(p.data, g, m, v, self.step_count, lr, self.betas[0], self.betas[1],
-                      self.eps, self.weight_decay)
+            torch.ops.gist.adam_step_(p.data, g, m, v, self.step_count, lr, self.betas[0],
+                                      self.betas[1], self.eps, self.weight_decay)
