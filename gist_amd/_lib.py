@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GistLibraryError(RuntimeError):
@@ -76,7 +76,7 @@ SIGNATURES = {
 
 GIST_MAX_LAYERS = 16
 TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_splits': 4,
-        'spmm_chunk': 5}
+        'spmm_chunk': 5, 'spmm_split': 6}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 
@@ -101,7 +101,7 @@ class StepPlan(ctypes.Structure):
                 ('rowptr', _p), ('col', _p), ('t_rowptr', _p), ('t_col', _p),
                 ('col_capacity', _i64), ('norm', _p), ('labels', _p), ('timer', _p),
                 ('n_max', _i64), ('feat_absmax', _f), ('h3_workspace', _p),
-                ('h3_workspace_bytes', _i64)]
+                ('h3_workspace_bytes', _i64), ('row_blocks', _p), ('n_row_blocks', _i64)]
 
 
 _lib = None

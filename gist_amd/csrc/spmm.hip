@@ -279,253 +279,343 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// LDS-staged kernel for cluster batches.  Rows come in LOCALITY BLOCKS (a METIS part of a
-// Cluster-GCN batch: ~100 consecutive rows whose neighbours are mostly in the same part).
-// A 512-thread workgroup (8 waves) owns (row block, row split, column tile) and stages, with
-// coalesced loads, into LDS:
-//   * the block's X tile [<=128 rows x 64*VEC floats], PRE-SCALED by src_scale (backward
-//     form), plus one all-zero row;
-//   * for the rows it computes: a 1-BYTE local row index per neighbour (zero row for a
-//     cross-block neighbour or padding), and up to 8 (global id, scale) pairs of its
-//     cross-block neighbours per row.
-// Per neighbour the inner loop is then v_readlane + shift + v_add + ds_read_b128 + adds --
-// no scale, no branch, no global memory; the few cross-block rows are prefetched from
-// global memory BEFORE the LDS pass and consumed after it.  Every element of X leaves
-// L2/HBM once per workgroup; nnz*D*4 bytes of L2 gather traffic become LDS reads.
-// Rows whose lists do not fit (hubs) take a per-row generic path; results never depend on
-// how rows are split into blocks.
-constexpr int kLdsRB = 128;          // rows staged per block
-constexpr int kLdsListCap = 8192;    // neighbour entries (1 byte each) per workgroup
-constexpr int kLdsRemCap = 8;        // cross-block neighbours kept per row
-constexpr int kLdsThreads = 512;
+// LDS-staged kernel (the one the training step uses for wide rows): gist_spmm_csr_blocked_f32.
+//
+// Unit of work = (locality block of <= 128 consecutive rows -- a METIS part of the cluster
+// batch --, 256-float column tile, row split).  One 1024-thread workgroup (16 waves, the whole
+// CU: the 128 KiB tile allows one) per unit:
+//   start-up, all global loads in flight together, ONE barrier
+//     * the block's X tile [rows x 1 KiB] -> LDS, pre-scaled by src_scale (backward form), one
+//       all-zero row behind it; the block's row pointers and out scales -> LDS;
+//     * a 1-BYTE local row index per neighbour of the block's rows -> LDS (cross-block
+//       neighbour: 128 = the zero row): it depends on the neighbour and the block only, so the
+//       whole workgroup classifies the block's edge range in one flat coalesced pass and the
+//       row loop reads no column ids from memory;
+//   rows longer than 128 neighbours (hubs of a power-law graph) first, split over all 16 waves in
+//   64-neighbour chunks, partial sums added in wave order through LDS;
+//   every other row by one wave: per neighbour v_readlane + v_add + ds_read_b128 + 2 v_pk_add_f32,
+//   groups of 8 reads software-pipelined and fully unrolled (constant lanes: address arithmetic on
+//   the scalar unit, which issues one instruction per SIMD every 4 cycles, was the first
+//   bottleneck); the next row's indices are read before the current row is gathered; cross-block
+//   neighbours (a ballot mask) come from global memory, 4 rows in flight.
+// X leaves L2/HBM once per unit instead of once per neighbour: at D = 4096 on a Reddit-like
+// batch nnz*D*4 = 2.1 GB of L2 gather traffic becomes LDS reads.  Measured (scripts/
+// spmm_probe.py, scripts/lds_gather_probe.hip): 82 -> 51 us at D = 4096;
+// the gather loop itself runs at ~6 cycles per KiB per CU (LDS peak 4), the rest is the
+// start-up of each unit, which one workgroup per CU cannot hide.  Tried and dropped: 512-thread
+// workgroups that loop over column tiles with the next tile prefetched into registers (8 waves
+// do not cover the LDS latency: 64 us), and 40-KiB workgroups (4 per CU) on 64-float tiles where
+// one ds_read_b128 serves four neighbours with v_add_u32_dpp row_newbcast addressing (73 us).
+// Results do not depend on the block boundaries, the row split or the placement.
+constexpr int kL2Rows = 128;                 // rows of X staged per block
+constexpr int kL2Threads = 1024;
+constexpr int kL2Waves = kL2Threads / kWave;
+constexpr int kL2Pre = kL2Rows / kL2Waves;   // rows of the tile each wave stages
+constexpr int kL2Long = 128;                 // rows with more neighbours are shared by all waves
+constexpr int kL2ZeroOff = kL2Rows * 1024;   // byte offset of the zero row
+constexpr size_t kL2PartOff = (size_t)(kL2Rows + 1) * 1024;            // 16 x 1 KiB partial sums
+constexpr size_t kL2RpOff = kL2PartOff + (size_t)kL2Waves * 1024;      // row pointers of the block
+constexpr size_t kL2ScOff = kL2RpOff + (kL2Rows + 4) * 4;              // out_scale of the block's rows
+constexpr size_t kL2MaskOff = kL2ScOff + kL2Rows * 4;                  // 2 x 64-bit: long rows
+constexpr size_t kL2IdxOff = kL2MaskOff + 16;                          // 1-byte neighbour indices
+constexpr int kL2IdxCap = 13312;
+constexpr size_t kL2LdsBytes = kL2IdxOff + kL2IdxCap;
+static_assert(kL2LdsBytes <= 160 * 1024, "LDS budget of one CU");
 
-template <int VEC>
-struct LdsLayout {
-    static constexpr int CW = kWave * VEC;
-    static constexpr size_t tile_bytes = (size_t)(kLdsRB + 1) * CW * 4;
-    static constexpr size_t idx_off = tile_bytes;
-    static constexpr size_t rp_off = idx_off + kLdsListCap;
-    static constexpr size_t rid_off = rp_off + (kLdsRB + 4) * 4;
-    static constexpr size_t rsc_off = rid_off + (size_t)kLdsRB * kLdsRemCap * 4;
-    static constexpr size_t rcn_off = rsc_off + (size_t)kLdsRB * kLdsRemCap * 4;
-    static constexpr size_t total = rcn_off + kLdsRB * 4;
+struct L2Args {
+    const int32_t *rowptr, *col;
+    const float *x; int64_t ldx;
+    float *y; int64_t ldy;
+    int n_rows, d;
+    const float *out_scale, *src_scale;
+    int accumulate;
+    const int32_t *row_blocks;
+    int n_blocks, n_col_tiles, row_split;
 };
 
-template <int VEC>
-__global__ __launch_bounds__(512) void spmm_csr_lds_kernel(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
-    int n_rows, int d, const float *__restrict__ out_scale,
-    const float *__restrict__ src_scale, int accumulate,
-    const int32_t *__restrict__ row_blocks, int n_col_tiles, int row_split) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    using LL = LdsLayout<VEC>;
-    constexpr int CW = LL::CW;
-    constexpr int NW = kLdsThreads / kWave;
-    constexpr int SH = VEC == 4 ? 10 : (VEC == 2 ? 9 : 8);        // log2(CW * 4)
-    float *tile = reinterpret_cast<float *>(smem_b);
-    unsigned char *idx8 = smem_b + LL::idx_off;
-    int32_t *rp = reinterpret_cast<int32_t *>(smem_b + LL::rp_off);
-    int32_t *rid = reinterpret_cast<int32_t *>(smem_b + LL::rid_off);
-    float *rsc = reinterpret_cast<float *>(smem_b + LL::rsc_off);
-    int32_t *rcn = reinterpret_cast<int32_t *>(smem_b + LL::rcn_off);
+#ifdef L2_PROBE_NO_LDS
+#define L2_LDS_READ(o) make_float4(__builtin_bit_cast(float, o), 0.f, 0.f, 0.f)
+#else
+#define L2_LDS_READ(o) (*reinterpret_cast<const float4 *>(tb + (o)))
+#endif
+#ifdef L2_PROBE_NO_ADD
+#define L2_ADD(v) acc[0] += (v).x
+#else
+#define L2_ADD(v) acc[0] += (v).x; acc[1] += (v).y; acc[2] += (v).z; acc[3] += (v).w
+#endif
 
-    const int ct = blockIdx.x % n_col_tiles;
-    const int rest = blockIdx.x / n_col_tiles;
-    const int half = rest % row_split;
-    const int rbk = rest / row_split;
+// Sum the neighbours [base, base + cnt) of one row into acc: `off` holds, per lane, the LDS
+// byte offset of neighbour base + lane (zero row if it is not in the tile).
+__device__ __forceinline__ void l2_local(const unsigned char *tb, int cnt, int off, float (&acc)[4]) {
+    // 8 groups of 8 neighbours, fully unrolled so that every v_readlane has a constant lane and
+    // the loop costs no scalar instructions beyond one branch per group; group g + 1 is issued
+    // before group g is summed (16 row reads in flight per wave, 128 per CU: the LDS pipe always
+    // has work queued)
+    float4 v[2][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[0][t] = L2_LDS_READ(__builtin_amdgcn_readlane(off, t));
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const bool more = (g + 1) * 8 < cnt;                   // wave-uniform
+        if (g < 7 && more) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                v[(g + 1) & 1][t] = L2_LDS_READ(__builtin_amdgcn_readlane(off, ((g + 1) * 8 + t) & 63));
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { L2_ADD(v[g & 1][t]); }
+        if (!more) break;
+    }
+}
+
+// Cross-block neighbours of a chunk: lanes in rmask hold the id `u` and scale `us` of one; 4 row
+// reads from global memory in flight (the mask is wave-uniform).
+__device__ __forceinline__ void l2_remote(const float *xc, int64_t ldx, bool active,
+                                          unsigned long long rmask, int u, float us, float (&acc)[4]) {
+    while (rmask) {
+        float4 rv[4];
+        float rs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool on = rmask != 0;
+            const int j = on ? __builtin_ctzll(rmask) : 0;
+            if (on) rmask &= rmask - 1;
+            const int uu = __builtin_amdgcn_readlane(u, j);
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                            __builtin_bit_cast(int, us), j));
+            rs[t] = on ? s0 : 0.f;
+            rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on && active) rv[t] = *reinterpret_cast<const float4 *>(xc + (int64_t)uu * ldx);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = fmaf(rs[t], rv[t].x, acc[0]); acc[1] = fmaf(rs[t], rv[t].y, acc[1]);
+            acc[2] = fmaf(rs[t], rv[t].z, acc[2]); acc[3] = fmaf(rs[t], rv[t].w, acc[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    // ---- workgroup -> unit: units of one block stay on one XCD (blocks b, b + 8, .. share one)
+    const int total = a.n_blocks * a.n_col_tiles * a.row_split;
+    const int per_xcd = (total + kXcds - 1) / kXcds;
+    const int unit = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    if (unit >= total) return;
+    const int rs = unit % a.row_split;
+    const int ct = (unit / a.row_split) % a.n_col_tiles;
+    const int rbk = unit / (a.row_split * a.n_col_tiles);
     int r0, r1;
-    if (row_blocks) { r0 = row_blocks[rbk]; r1 = row_blocks[rbk + 1]; }
-    else { r0 = rbk * kLdsRB; r1 = min(n_rows, r0 + kLdsRB); }
-    r1 = min(r1, n_rows);
+    if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
+    else { r0 = rbk * kL2Rows; r1 = r0 + kL2Rows; }
+    r1 = min(r1, a.n_rows);
     const int nrow = r1 - r0;
     if (nrow <= 0) return;
-    const int nloc = min(nrow, kLdsRB);
+    const int nloc = min(nrow, kL2Rows);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c0 = ct * CW + lane * VEC;
-    const bool active = c0 < d;
+    const int c0 = ct * 256 + lane * 4;
+    const bool active = c0 < a.d;
+    const float *xc = a.x + c0;
+    unsigned char *tb = smem_b + lane * 16;
+    unsigned char *part = smem_b + kL2PartOff;
+    int32_t *rp = reinterpret_cast<int32_t *>(smem_b + kL2RpOff);
+    float *rsc = reinterpret_cast<float *>(smem_b + kL2ScOff);
+    unsigned long long *lmask = reinterpret_cast<unsigned long long *>(smem_b + kL2MaskOff);
+    unsigned char *idx8 = smem_b + kL2IdxOff;
+    const int step = a.row_split * kL2Waves;
 
-    // ---- stage 1: row pointers, X tile (pre-scaled), zero row ----------------------------
-    for (int i = threadIdx.x; i <= nloc; i += kLdsThreads) rp[i] = rowptr[r0 + i];
+    // ---- start-up: row pointers, out scales, long rows; the tile (pre-scaled); neighbour indices --
+    if (wave == 0) *reinterpret_cast<float4 *>(tb + kL2ZeroOff) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < kL2Rows) {                  // waves 0 and 1
+        const int t = threadIdx.x;
+        const int b0 = t < nloc ? a.rowptr[r0 + t] : 0;
+        const int b1 = t < nloc ? a.rowptr[r0 + t + 1] : 0;
+        if (t < nloc) {
+            rp[t] = b0;
+            rsc[t] = a.out_scale ? a.out_scale[r0 + t] : 1.f;
+        }
+        if (t == nloc - 1) rp[nloc] = b1;
+        const bool lg = t < nloc && (b1 - b0) > kL2Long && (t % a.row_split) == rs;
+        const unsigned long long m = __ballot(lg);
+        if (lane == 0) lmask[wave] = m;
+    }
+#ifndef L2_PROBE_NO_STAGE
     {
-        float z[VEC];
+        float4 v[kL2Pre];
+        float sc[kL2Pre];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) z[k] = 0.f;
-        if (wave == 0) vstore<VEC>(tile + kLdsRB * CW + lane * VEC, z);
-    }
-    for (int rr = wave; rr < nloc; rr += 8 * NW) {       // eight row loads in flight per wave
-        float v[8][VEC];
-        float sc[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int r = rr + t * NW;
-            const int rc = min(r, nloc - 1);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[t][k] = 0.f;
-            if (active) vload<VEC>(x + (int64_t)(r0 + rc) * ldx + c0, v[t]);
-            sc[t] = src_scale ? src_scale[r0 + rc] : 1.f;
+        for (int t = 0; t < kL2Pre; ++t) {
+            const int r = min(wave + t * kL2Waves, nloc - 1);
+            v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) v[t] = *reinterpret_cast<const float4 *>(xc + (int64_t)(r0 + r) * a.ldx);
+            sc[t] = a.src_scale ? a.src_scale[r0 + r] : 1.f;
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int r = rr + t * NW;
+        for (int t = 0; t < kL2Pre; ++t) {
+            const int r = wave + t * kL2Waves;
             if (r < nloc) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) v[t][k] *= sc[t];
-                vstore<VEC>(tile + r * CW + lane * VEC, v[t]);
+                v[t].x *= sc[t]; v[t].y *= sc[t]; v[t].z *= sc[t]; v[t].w *= sc[t];
+                *reinterpret_cast<float4 *>(tb + (r << 10)) = v[t];
             }
         }
     }
-    __syncthreads();
-
-    // ---- stage 2: classify the neighbours of the rows THIS workgroup computes ----------------
-    const int cbeg = rp[0];
-    for (int lr = half + row_split * wave; lr < nloc; lr += row_split * NW) {
-        const int beg = rp[lr], end = rp[lr + 1];
-        int nrem = 0;
-        const bool fits = (end - cbeg) <= kLdsListCap;
-        for (int base = beg; base < end && fits; base += kWave) {
-            const int e = base + lane;
-            const bool in = e < end;
-            const int u = in ? col[e] : r0;
-            const unsigned lu = (unsigned)(u - r0);
-            const bool local = lu < (unsigned)nloc;
-            if (in) idx8[e - cbeg] = (unsigned char)(local ? lu : kLdsRB);
-            const unsigned long long m = __ballot(in && !local);
-            if (in && !local) {
-                const int pos = nrem + __popcll(m & ((1ULL << lane) - 1ULL));
-                if (pos < kLdsRemCap) {
-                    rid[lr * kLdsRemCap + pos] = u;
-                    rsc[lr * kLdsRemCap + pos] = src_scale ? src_scale[u] : 1.f;
-                }
-            }
-            nrem += __popcll(m);
+#endif
+    // 1-byte local index of EVERY neighbour of the block's rows (128: not in the tile): it depends
+    // on the neighbour and the block only, so all threads classify the block's edge range in one
+    // flat coalesced pass whose loads fly together with the tile's
+    const int e0 = a.rowptr[r0];
+    {
+        const int e1 = min(a.rowptr[r0 + nloc], e0 + kL2IdxCap);
+        for (int e = e0 + threadIdx.x; e < e1; e += kL2Threads) {
+            const unsigned lu = (unsigned)(a.col[e] - r0);
+            idx8[e - e0] = (unsigned char)(lu < (unsigned)nloc ? lu : kL2Rows);
         }
-        if (lane == 0) rcn[lr] = fits ? nrem : -1;       // -1 / > cap: generic path for the row
     }
     __syncthreads();
+#ifdef L2_PROBE_NO_GATHER
+    return;
+#endif
+    unsigned long long lm[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned long long m = lmask[h];
+        lm[h] = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    }
 
-    // ---- compute -----------------------------------------------------------------------------
-    const float *xc = x + c0;
-    const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile) + lane * VEC * 4;
-    for (int lr = half + row_split * wave; lr < nrow; lr += row_split * NW) {
-        const int row = r0 + lr;
-        float acc[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        const int nrem = lr < nloc ? rcn[lr] : -1;
-        if (nrem >= 0 && nrem <= kLdsRemCap) {
-            const int beg = __builtin_amdgcn_readfirstlane(rp[lr]);
-            const int end = __builtin_amdgcn_readfirstlane(rp[lr + 1]);
-            // cross-block rows first: their global loads fly under the LDS pass
-            float rv[kLdsRemCap][VEC];
-            float rs[kLdsRemCap];
-            const int rc = __builtin_amdgcn_readfirstlane(nrem);
-            const int my_id = lane < kLdsRemCap ? rid[lr * kLdsRemCap + lane] : row;
-            const float my_sc = lane < kLdsRemCap ? rsc[lr * kLdsRemCap + lane] : 0.f;
-            if (rc > 0) {
-#pragma unroll
-                for (int t = 0; t < kLdsRemCap; ++t) {
-                    const bool on = t < rc;                                  // wave-uniform
-                    const int u = on ? __builtin_amdgcn_readlane(my_id, t) : row;
-                    rs[t] = on ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                                               __builtin_bit_cast(int, my_sc), t))
-                               : 0.f;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) rv[t][k] = 0.f;
-                    if (on && active) vload<VEC>(xc + (int64_t)u * ldx, rv[t]);
-                }
-            }
-            for (int base = beg; base < end; base += kWave) {
-                const int e = base + lane;
-                const int mine = (e < end) ? (int)idx8[e - cbeg] : kLdsRB;   // pad -> zero row
-                const int cnt = min(kWave, end - base);
-                // groups of 8 LDS row reads, software pipelined: group g+1 is issued before
-                // group g is summed, so the LDS pipe always has work queued
-                float va[8][VEC], vb[8][VEC];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int li = __builtin_amdgcn_readlane(mine, t);
-                    vload<VEC>(reinterpret_cast<const float *>(tb + ((unsigned)li << SH)), va[t]);
-                }
-                for (int j = 0; j < cnt; j += 16) {
-                    if (j + 8 < cnt) {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const int li = __builtin_amdgcn_readlane(mine, (j + 8 + t) & 63);
-                            vload<VEC>(reinterpret_cast<const float *>(tb + ((unsigned)li << SH)), vb[t]);
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] += va[t][k];
-                    if (j + 8 < cnt) {
-                        if (j + 16 < cnt) {
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) {
-                                const int li = __builtin_amdgcn_readlane(mine, (j + 16 + t) & 63);
-                                vload<VEC>(reinterpret_cast<const float *>(tb + ((unsigned)li << SH)), va[t]);
-                            }
-                        }
-#pragma unroll
-                        for (int t = 0; t < 8; ++t)
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) acc[k] += vb[t][k];
-                    }
-                }
-            }
-            if (rc > 0) {
-#pragma unroll
-                for (int t = 0; t < kLdsRemCap; ++t)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(rs[t], rv[t][k], acc[k]);
-            }
+    // one 64-neighbour chunk [base, end) of a row: the lane's neighbour as an LDS byte offset, and
+    // whether it is a cross-block row (then `u` is its id)
+    auto classify = [&](int base, int end, bool staged, int &off, bool &rem, int &u) {
+        const int e = base + lane;
+        const bool in = e < end;
+        u = r0;
+        if (staged) {                                      // wave-uniform: indices in LDS
+            const int li = in ? (int)idx8[e - e0] : kL2Rows;
+            off = li << 10;
+            rem = in && li == kL2Rows;
         } else {
-            // generic path: hub rows / oversize blocks -- gather everything from global memory
-            const int beg = __builtin_amdgcn_readfirstlane(rowptr[row]);
-            const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
-            for (int base = beg; base < end; base += kWave) {
-                const int e = base + lane;
-                const int my = (e < end) ? col[e] : 0;
-                float mys = 1.f;
-                if (src_scale) mys = (e < end) ? src_scale[my] : 0.f;
-                const int cnt = min(kWave, end - base);
-                for (int j = 0; j < cnt; j += 4) {
-                    float v[4][VEC];
-                    float sc[4];
+            u = in ? a.col[e] : r0;
+            const unsigned lu = (unsigned)(u - r0);
+            const bool local = in && lu < (unsigned)nloc;
+            off = local ? (int)(lu << 10) : kL2ZeroOff;
+            rem = in && !local;
+        }
+    };
+    auto remote = [&](int base, int end, bool staged, bool rem, int u, float (&acc)[4]) {
+        const unsigned long long rmask = __ballot(rem);
+        if (!rmask) return;
+        if (staged) u = rem ? a.col[base + lane] : r0;
+        const float us = (rem && a.src_scale) ? a.src_scale[u] : 1.f;
+        l2_remote(xc, a.ldx, active, rmask, u, us, acc);
+    };
+    auto store = [&](int lr, float4 prev, float sx, float sy, float sz, float sw) {
+        if (!active) return;
+        const int row = r0 + lr;
+        const float os = lr < nloc ? rsc[lr] : (a.out_scale ? a.out_scale[row] : 1.f);
+        float4 *yp = reinterpret_cast<float4 *>(a.y + (int64_t)row * a.ldy + c0);
+        *yp = make_float4(fmaf(os, sx, prev.x), fmaf(os, sy, prev.y), fmaf(os, sz, prev.z),
+                          fmaf(os, sw, prev.w));
+    };
+    auto previous = [&](int lr) {                          // y's old value, read early (accumulate)
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.accumulate && active) p = *reinterpret_cast<const float4 *>(a.y + (int64_t)(r0 + lr) * a.ldy + c0);
+        return p;
+    };
+
+    // ---- long rows first (all waves in step): wave w takes the 64-neighbour chunks w, w + 16, ..;
+    //      the partial sums meet in LDS and are added in wave order by wave (k mod 16) ---------------
+#ifndef L2_PROBE_NO_LONG
+    if (lm[0] | lm[1]) {
+        int k = 0;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int jj = min(j + t, cnt - 1);
-                        const int u = __builtin_amdgcn_readlane(my, jj);
-                        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                                                        __builtin_bit_cast(int, mys), jj));
-                        sc[t] = (j + t < cnt) ? s0 : 0.f;
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) v[t][k] = 0.f;
-                        if (active) vload<VEC>(xc + (int64_t)u * ldx, v[t]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(sc[t], v[t][k], acc[k]);
+        for (int h = 0; h < 2; ++h) {
+            unsigned long long m = lm[h];
+            while (m) {
+                const int lr = 64 * h + __builtin_ctzll(m);
+                m &= m - 1;
+                const int beg = __builtin_amdgcn_readfirstlane(rp[lr]);
+                const int end = __builtin_amdgcn_readfirstlane(rp[lr + 1]);
+                const bool staged = end - e0 <= kL2IdxCap;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int base = beg + kWave * wave; base < end; base += kWave * kL2Waves) {
+                    int off, u;
+                    bool rem;
+                    classify(base, end, staged, off, rem, u);
+                    l2_local(tb, min(kWave, end - base), off, acc);
+                    remote(base, end, staged, rem, u, acc);
                 }
+                if (k > 0) __syncthreads();               // previous long row's partials consumed
+                *reinterpret_cast<float4 *>(part + wave * 1024 + lane * 16) =
+                    make_float4(acc[0], acc[1], acc[2], acc[3]);
+                __syncthreads();
+                if (wave == (k & (kL2Waves - 1))) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int w = 0; w < kL2Waves; ++w) {
+                        const float4 p = *reinterpret_cast<const float4 *>(part + w * 1024 + lane * 16);
+                        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+                    }
+                    store(lr, previous(lr), sum.x, sum.y, sum.z, sum.w);
+                }
+                ++k;
             }
         }
-        if (active) {
-            const float os = out_scale ? out_scale[row] : 1.f;
-            float *yp = y + (int64_t)row * ldy + c0;
-            float o[VEC];
-            if (accumulate) {
-                vload<VEC>(yp, o);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) o[k] = fmaf(os, acc[k], o[k]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
+    }
+#endif
+
+    // ---- the other rows of this unit, one wave per row; the next row's first chunk is classified
+    //      (its LDS index read issued) before the current row is gathered ----------------------------
+    {
+        int lr = rs + a.row_split * wave;
+        int beg = 0, end = 0, off = kL2ZeroOff, u = r0;
+        bool rem = false, staged = true;
+        auto open_row = [&](int r) {                       // first chunk of the next short row >= r
+            while (r < nloc) {
+                beg = __builtin_amdgcn_readfirstlane(rp[r]);
+                end = __builtin_amdgcn_readfirstlane(rp[r + 1]);
+                if (end - beg <= kL2Long) break;           // long rows were done above
+                r += step;
             }
-            vstore<VEC>(yp, o);
+            if (r < nloc) {
+                staged = end - e0 <= kL2IdxCap;
+                classify(beg, end, staged, off, rem, u);
+            }
+            return r;
+        };
+        lr = open_row(lr);
+        while (lr < nloc) {
+            const int cur = lr, cbeg = beg, cend = end, coff = off, cu = u;
+            const bool crem = rem, cstaged = staged;
+            const float4 prev = previous(cur);
+            lr = open_row(cur + step);                      // next row's indices on their way
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            l2_local(tb, min(kWave, cend - cbeg), coff, acc);
+            remote(cbeg, cend, cstaged, crem, cu, acc);
+            for (int base = cbeg + kWave; base < cend; base += kWave) {   // rows of 65..128 neighbours
+                int o2, u2;
+                bool r2;
+                classify(base, cend, cstaged, o2, r2, u2);
+                l2_local(tb, min(kWave, cend - base), o2, acc);
+                remote(base, cend, cstaged, r2, u2, acc);
+            }
+            store(cur, prev, acc[0], acc[1], acc[2], acc[3]);
         }
+    }
+    // rows of an oversize block beyond the staged ones (their row pointers are not in LDS)
+    for (int lr = kL2Rows + rs + a.row_split * wave; lr < nrow; lr += step) {
+        const int row = r0 + lr;
+        const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
+        const int end = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = beg; base < end; base += kWave) {
+            int off, u;
+            bool rem;
+            classify(base, end, false, off, rem, u);
+            l2_local(tb, min(kWave, end - base), off, acc);
+            remote(base, end, false, rem, u, acc);
+        }
+        store(lr, previous(lr), acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -581,35 +671,50 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
     return launch_status("gist_spmm_csr_f32");
 }
 
-template <int VEC>
-static int launch_spmm_blocked(const int32_t *rowptr, const int32_t *col, const float *x,
-                               int64_t ldx, float *y, int64_t ldy, int64_t n_rows, int64_t d,
-                               const float *out_scale, const float *src_scale, int accumulate,
-                               const int32_t *row_blocks, int64_t n_row_blocks, hipStream_t st) {
-    const int n_col_tiles = (int)ceil_div(d, kWave * VEC);
-    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, kLdsRB);
-    // split a block's rows over several workgroups (each stages the whole tile) until the
-    // grid can keep 256 CUs busy for a couple of rounds
-    int row_split = (int)ceil_div(640, nb * n_col_tiles);
-    row_split = row_split < 1 ? 1 : (row_split > 4 ? 4 : row_split);
-    const int64_t grid = nb * row_split * n_col_tiles;
+// Row split R of the second LDS design: units = blocks x column tiles x R on 256 CUs, one unit
+// per CU at a time; every split re-stages the tile (cost ~1) and gathers 1/R of the block's rows
+// (cost ~2.5 / R), fitted to scripts/spmm_probe.py on a Reddit-like batch.
+static int l2_row_split(int64_t nb, int n_col_tiles) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int r = 1; r <= 8; ++r) {
+        const double rounds = (double)ceil_div(nb * n_col_tiles * r, 256);
+        const double cost = rounds * (1.0 + 3.0 / r);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
+    }
+    return best;
+}
+
+static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
+                            float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
+                            const float *src_scale, int accumulate, const int32_t *row_blocks,
+                            int64_t n_row_blocks, hipStream_t st) {
+    L2Args a;
+    a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
+    a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
+    a.accumulate = accumulate; a.row_blocks = row_blocks;
+    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, kL2Rows);
+    a.n_blocks = (int)nb;
+    a.n_col_tiles = (int)ceil_div(d, 256);
+    a.row_split = tune(GIST_TUNE_SPMM_SPLIT) > 0.0 ? (int)tune(GIST_TUNE_SPMM_SPLIT)
+                                                    : l2_row_split(nb, a.n_col_tiles);
+    a.row_split = a.row_split < 1 ? 1 : (a.row_split > 64 ? 64 : a.row_split);
+    const int64_t total = nb * a.n_col_tiles * a.row_split;
+    const int64_t grid = kXcds * ceil_div(total, kXcds);
     if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
-    const size_t smem = LdsLayout<VEC>::total;
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&spmm_csr_lds_kernel<VEC>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_csr_lds2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kL2LdsBytes);
         if (e != hipSuccess) {
             set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return GIST_ELAUNCH;
         }
         once.done(dev);
     }
-    hipLaunchKernelGGL((spmm_csr_lds_kernel<VEC>), dim3((unsigned)grid), dim3(kLdsThreads), smem, st,
-                       rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale, src_scale,
-                       accumulate, row_blocks, n_col_tiles, row_split);
+    hipLaunchKernelGGL(spmm_csr_lds2_kernel, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 
@@ -672,11 +777,9 @@ extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *c
                                  accumulate, stream);
     hipStream_t st = as_stream(stream);
     if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
-        return launch_spmm_blocked<4>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale,
-                                      src_scale, accumulate, row_blocks, n_row_blocks, st);
-    if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y))
-        return launch_spmm_blocked<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale,
-                                      src_scale, accumulate, row_blocks, n_row_blocks, st);
+        return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                accumulate, row_blocks, n_row_blocks, st);
+    // other widths / alignments (the layer-0 aggregation of F = 602 features): the row-split kernel
     return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                              accumulate, stream);
 }

@@ -186,6 +186,16 @@ extern "C" int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan) {
     return h3_layout(plan, nullptr).bytes;
 }
 
+// The step's aggregations: the LDS-staged kernel when the batch comes with its locality blocks.
+static int step_spmm(const gist_step_plan *p, const int32_t *rowptr, const int32_t *col, const float *x,
+                     int64_t ldx, float *y, int64_t ldy, int64_t n, int64_t d, const float *out_scale,
+                     const float *src_scale, int accumulate, gist_stream_t s) {
+    if (p->row_blocks != nullptr && p->n_row_blocks > 0)
+        return gist_spmm_csr_blocked_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale,
+                                         accumulate, p->row_blocks, p->n_row_blocks, s);
+    return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale, accumulate, s);
+}
+
 extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64_t n,
                               uint64_t drop_offset, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int64_t adam_step, int flags,
@@ -249,8 +259,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         const gist_layer_desc &l = p->layer[k];
         {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
-            GIST_TRY(gist_spmm_csr_f32(p->rowptr, p->col, l.Z, l.ldz, l.Z + l.n_in, l.ldz, n,
-                                       l.n_in, p->norm, nullptr, 0, s));
+            GIST_TRY(step_spmm(p, p->rowptr, p->col, l.Z, l.ldz, l.Z + l.n_in, l.ldz, n, l.n_in,
+                               p->norm, nullptr, 0, s));
         }
         offs[k] = off;
         if (h3.layer[k].on) {
@@ -334,8 +344,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                     GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
                                               offs[k], s));
                 Scope sc(p->timer, 0, n, n, l.n_in, st);
-                GIST_TRY(gist_spmm_csr_f32(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                           2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+                GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
             }
             continue;
         }
@@ -353,8 +363,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
         if (k > 0) {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
-            GIST_TRY(gist_spmm_csr_f32(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                       2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+            GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                               2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
         }
     }
     GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,

@@ -82,10 +82,12 @@ class ParamArena(object):
 
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
-    __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready')
+    __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
+                 'row_blocks')
 
     def __init__(self):
         self.ready = True
+        self.row_blocks = None      # int32 [n_blocks + 1]: row ranges of the batch's METIS parts
 
 
 class ClusterBatcher(object):
@@ -285,6 +287,11 @@ class SageEngine(object):
         if train:
             self.arena.step += 1
         ids_ptr = b.ids.data_ptr() if b.ids is not None else None
+        rb = b.row_blocks
+        if rb is not None and rb.numel() > 1:
+            self.plan.row_blocks, self.plan.n_row_blocks = rb.data_ptr(), rb.numel() - 1
+        else:
+            self.plan.row_blocks, self.plan.n_row_blocks = None, 0
         rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
                               eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())
         _lib.check(rc, 'gist_sage_step')
@@ -324,7 +331,7 @@ class SageEngine(object):
                 hip.spmm(b.rowptr, b.col, p_buf, self.Y[k][:n, :o], out_scale=b.norm,
                          accumulate=True)
                 continue
-            hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm)
+            hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm, row_blocks=b.row_blocks)
             if training and self.p_drop > 0.0:
                 off = self._drop_offset(n * 2 * i)
                 self._drop_offsets.append(off)
@@ -368,7 +375,7 @@ class SageEngine(object):
                 else:
                     hip.gemm_nn_dropout_(dy, A.W[k], dz, 0.0, self.seed, 0)
                 hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
-                         accumulate=True)
+                         accumulate=True, row_blocks=b.row_blocks)
         return self.loss
 
     def adam_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):

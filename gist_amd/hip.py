@@ -104,38 +104,30 @@ def in_degree_norm(rowptr, out=None):
 def spmm(rowptr, col, x, y, out_scale=None, src_scale=None, accumulate=False, row_blocks=None,
          blocked=False):
     """y[v] (+)= out_scale[v] * sum_e src_scale[col[e]] * x[col[e]]; see gist_spmm_csr_f32.
-    row_blocks (int32 [n_blocks+1]) or blocked=True selects the LDS-staged kernel
-    (gist_spmm_csr_blocked_f32)."""
+    row_blocks (int32 [n_blocks+1]: locality blocks of the rows, <= 128 rows each) or blocked=True
+    (uniform 128-row blocks) selects the LDS-staged kernel (gist_spmm_csr_blocked_f32)."""
     L = _lib.load()
-    if row_blocks is not None or blocked:
-        n = rowptr.numel() - 1
-        xp, ldx = _mat(x, 'x')
-        yp, ldy = _mat(y, 'y')
-        d = x.shape[1]
-        if y.shape[0] != n or y.shape[1] != d:
-            raise ValueError('gist_amd: spmm output shape %s != (%d, %d)' % (tuple(y.shape), n, d))
-        nb = 0 if row_blocks is None else row_blocks.numel() - 1
-        with _Timed('spmm', (n, x.shape[0], d)):
-            rc = L.gist_spmm_csr_blocked_f32(
-                _vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32), xp, ldx, yp,
-                ldy, n, d, _opt(out_scale, 'out_scale', torch.float32, n),
-                _opt(src_scale, 'src_scale', torch.float32, x.shape[0]), int(bool(accumulate)),
-                _opt(row_blocks, 'row_blocks', torch.int32), nb, _stream())
-        _lib.check(rc, 'gist_spmm_csr_blocked_f32')
-        return y
     n = rowptr.numel() - 1
     xp, ldx = _mat(x, 'x')
     yp, ldy = _mat(y, 'y')
     d = x.shape[1]
     if y.shape[0] != n or y.shape[1] != d:
         raise ValueError('gist_amd: spmm output shape %s != (%d, %d)' % (tuple(y.shape), n, d))
+    common = (_vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n,
+              d, _opt(out_scale, 'out_scale', torch.float32, n),
+              _opt(src_scale, 'src_scale', torch.float32, x.shape[0]), int(bool(accumulate)))
     with _Timed('spmm', (n, x.shape[0], d)):
-        rc = L.gist_spmm_csr_f32(_vec(rowptr, 'rowptr', torch.int32),
-                                 _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n, d,
-                                 _opt(out_scale, 'out_scale', torch.float32, n),
-                                 _opt(src_scale, 'src_scale', torch.float32, x.shape[0]),
-                                 int(bool(accumulate)), _stream())
-    _lib.check(rc, 'gist_spmm_csr_f32')
+        if row_blocks is not None or blocked:
+            if x.shape[0] != n:
+                raise ValueError('gist_amd: the blocked spmm needs a square row/source set')
+            nb = 0 if row_blocks is None else row_blocks.numel() - 1
+            rc = L.gist_spmm_csr_blocked_f32(*common, _opt(row_blocks, 'row_blocks', torch.int32),
+                                             nb, _stream())
+            name = 'gist_spmm_csr_blocked_f32'
+        else:
+            rc = L.gist_spmm_csr_f32(*common, _stream())
+            name = 'gist_spmm_csr_f32'
+    _lib.check(rc, name)
     return y
 
 

@@ -160,6 +160,21 @@ class EngineClusterIter(ClusterIter):
         np.cumsum(per_batch, out=off[1:])
         self._epoch_ids = torch.from_numpy(ids).to(self.g.device, non_blocking=False)
         self._offsets = off
+        # locality blocks of every batch (row ranges of its METIS parts, cut at 128 rows: the
+        # LDS-staged aggregation stages one block's feature tile at a time), uploaded with the ids
+        blocks, boff = [], np.zeros(self.max + 1, np.int64)
+        for i in range(self.max):
+            edges, pos = [0], 0
+            for sz in sizes[i * self.batch_size:(i + 1) * self.batch_size]:
+                sz = int(sz)
+                for c in range(0, sz, 128):
+                    edges.append(pos + min(c + 128, sz))
+                pos += sz
+            blocks.append(np.asarray(edges, np.int32))
+            boff[i + 1] = boff[i] + len(edges)
+        self._epoch_blocks = torch.from_numpy(
+            np.concatenate(blocks) if blocks else np.zeros(0, np.int32)).to(self.g.device)
+        self._block_offsets = boff
 
     def __iter__(self):
         self.n = 0
@@ -175,6 +190,8 @@ class EngineClusterIter(ClusterIter):
                 batch = self.batcher.lazy(ids)
             else:
                 batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
+            batch.row_blocks = self._epoch_blocks[int(self._block_offsets[self.n]):
+                                                  int(self._block_offsets[self.n + 1])]
             self.n += 1
             return batch
         random.shuffle(self.par_li)

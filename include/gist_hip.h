@@ -156,6 +156,7 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_GEMM_TILE 3     /* fp32 GEMM tile (64 or 128); needs GEMM_SPLITS too          */
 #define GIST_TUNE_GEMM_SPLITS 4   /* fp32 GEMM split-K factor                                   */
 #define GIST_TUNE_SPMM_CHUNK 5    /* rows per XCD chunk of the row-split SpMM                   */
+#define GIST_TUNE_SPMM_SPLIT 6    /* row split of the LDS-staged SpMM (1..8)                    */
 #define GIST_TUNE_COUNT 8
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
@@ -361,6 +362,11 @@ typedef struct gist_step_plan {
     int64_t n_max;
     float feat_absmax;
     void *h3_workspace; int64_t h3_workspace_bytes;
+    /* Locality blocks of the CURRENT batch (set per call; the plan is host memory): rows
+     * [row_blocks[b], row_blocks[b+1]) = the b-th METIS part of the batch, at most 128 rows each
+     * (longer parts cut).  With it the wide aggregations run gist_spmm_csr_blocked_f32 (X tile of
+     * a part staged in LDS once); NULL = gist_spmm_csr_f32. */
+    const int32_t *row_blocks; int64_t n_row_blocks;
 } gist_step_plan;
 
 /* Bytes of h3_workspace the plan's shapes need (0: no layer qualifies, or mode 0). Host function. */

@@ -1,4 +1,6 @@
-"""Dev tool: plain vs LDS-staged SpMM on a real Reddit-like cluster batch."""
+"""Dev tool: row-split (plain) vs LDS-staged SpMM (first and second design) on a Reddit-like
+cluster batch; forward form (out_scale) and backward form (reversed CSR, src_scale, accumulate);
+also with the batch rows randomly permuted (no block locality: every neighbour cross-block)."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,21 +21,71 @@ sizes = [len(p) for p in it.par_li[:20]]
 rb = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
 assert int(rb[-1]) == n
 nnz = int(b.rowptr[n].item())
-def timeit(f, it_=20):
+rp, cl = b.rowptr.cpu().numpy(), b.col[:nnz].cpu().numpy()
+deg = np.diff(rp)
+rows = np.repeat(np.arange(n), deg)
+blk = np.searchsorted(rb.cpu().numpy(), np.arange(n), side='right') - 1
+print('batch: n=%d nnz=%d max deg %d; neighbours inside the row\'s own part: %.1f%%'
+      % (n, nnz, deg.max(), 100.0 * (blk[rows] == blk[cl]).mean()), flush=True)
+
+
+def timeit(f, it_=30):
     for _ in range(3): f()
     torch.cuda.synchronize(); ts = []
     for _ in range(it_):
         a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(); c.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(c))
     ts.sort(); return ts[len(ts) // 2]
-for d in (602, 256, 512, 1024, 2048, 4096):
-    z = torch.randn(n, 2 * d, device=dev)
-    t0 = timeit(lambda: hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm))
-    ref = z[:, d:].clone()
-    t1 = timeit(lambda: hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm, blocked=True))
-    e1 = (z[:, d:] - ref).abs().max().item()
-    t2 = timeit(lambda: hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm, row_blocks=rb))
-    e2 = (z[:, d:] - ref).abs().max().item()
-    alg = 4.0 * (n + 1) + 4.0 * nnz + 8.0 * n * d
-    print('D=%4d plain %.1f us (%.0f GB/s alg) | lds uniform128 %.1f us | lds parts %.1f us (%.0f GB/s alg)  err %.1e %.1e'
-          % (d, t0 * 1e3, alg / t0 / 1e6, t1 * 1e3, t2 * 1e3, alg / t2 / 1e6, e1, e2), flush=True)
+
+
+def run(tag, rowptr, col, t_rowptr, t_col, norm, blocks):
+    for d in (512, 1024, 2048, 4096):
+        z = torch.randn(n, 2 * d, device=dev)
+        alg = 4.0 * (n + 1) + 4.0 * nnz + 8.0 * n * d
+        out = {}
+        for form in ('fwd', 'bwd'):
+            if form == 'fwd':
+                call = lambda **kw: hip.spmm(rowptr, col, z[:, :d], z[:, d:], out_scale=norm, **kw)
+                res = lambda: z[:, d:]
+            else:
+                dz0 = torch.randn(n, 2 * d, device=dev)
+                dz = dz0.clone()
+                def call(**kw):
+                    return hip.spmm(t_rowptr, t_col, dz[:, d:], dz[:, :d], src_scale=norm,
+                                    accumulate=True, **kw)
+                def res():
+                    return dz[:, :d]
+            def once(**kw):
+                if form == 'bwd':
+                    dz.copy_(dz0)
+                call(**kw)
+                return res().clone()
+            ref = once()
+            t0 = timeit(lambda: call())
+            hip.tuning('spmm_lds', 1)
+            e1 = (once(row_blocks=blocks) - ref).abs().max().item()
+            t1 = timeit(lambda: call(row_blocks=blocks))
+            hip.tuning('spmm_lds', 0)
+            e2 = (once(row_blocks=blocks) - ref).abs().max().item()
+            t2 = timeit(lambda: call(row_blocks=blocks))
+            e3 = (once(blocked=True) - ref).abs().max().item()
+            t3 = timeit(lambda: call(blocked=True))
+            print('%s D=%4d %s: row-split %.1f us (%.0f GB/s) | lds1 parts %.1f us | lds2 parts %.1f us '
+                  '(%.0f GB/s = %.3f of 8 TB/s) | lds2 uniform128 %.1f us | err %.1e %.1e %.1e'
+                  % (tag, d, form, t0 * 1e3, alg / t0 / 1e6, t1 * 1e3, t2 * 1e3, alg / t2 / 1e6,
+                     alg / t2 / 1e6 / 8000, t3 * 1e3, e1, e2, e3), flush=True)
+        if d == 4096:
+            for R in (1, 2, 3, 4):
+                hip.tuning('spmm_split', R)
+                t = timeit(lambda: hip.spmm(rowptr, col, z[:, :d], z[:, d:], out_scale=norm, row_blocks=blocks))
+                print('   lds2 D=4096 fwd row_split=%d: %.1f us' % (R, t * 1e3), flush=True)
+            hip.tuning('spmm_split', 0)
+
+
+run('clustered', b.rowptr, b.col, b.t_rowptr, b.t_col, b.norm, rb)
+# no locality: relabel the batch rows by a random permutation
+perm = np.random.RandomState(0).permutation(n)
+from gist_amd.graph import Graph
+src = perm[cl]; dst = perm[rows]
+gp = Graph.from_edges(src, dst, n).to(dev)
+run('permuted ', gp.rowptr, gp.col, gp.t_rowptr, gp.t_col, gp.norm(), rb)
