@@ -65,6 +65,8 @@ SIGNATURES = {
     'gist_block_gather_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
     'gist_block_scatter_f32': (_int, [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
     'gist_mean_rows_f32': (_int, [_p, _i64, _i64, _i64, _p, _p]),
+    'gist_standard_scaler_workspace_bytes': (_i64, [_i64, _i64]),
+    'gist_standard_scaler_f32': (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
     'gist_timer_create': (_p, [_i64]),
     'gist_timer_destroy': (None, [_p]),
     'gist_timer_reset': (None, [_p]),

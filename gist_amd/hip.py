@@ -131,6 +131,24 @@ def spmm(rowptr, col, x, y, out_scale=None, src_scale=None, accumulate=False, ro
     return y
 
 
+def standard_scale_(feat, fit_rows=None):
+    """sklearn StandardScaler fit on rows `fit_rows` (int32 device tensor; None = all rows) and
+    applied IN PLACE to every row of `feat` [N, F] (cluster_gcn_ist_distrib.py:492-499).
+    Returns (mean, var) as float64 device tensors."""
+    L = _lib.load()
+    xp, ld = _mat(feat, 'feat')
+    n, d = feat.shape
+    n_fit = n if fit_rows is None else fit_rows.numel()
+    mean = torch.empty(d, dtype=torch.float64, device=feat.device)
+    var = torch.empty(d, dtype=torch.float64, device=feat.device)
+    need = L.gist_standard_scaler_workspace_bytes(n_fit, d)
+    ws = torch.empty(max(int(need), 8), dtype=torch.uint8, device=feat.device)
+    _lib.check(L.gist_standard_scaler_f32(xp, ld, n, d, _opt(fit_rows, 'fit_rows', torch.int32), n_fit,
+                                          mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _stream()), 'gist_standard_scaler_f32')
+    return mean, var
+
+
 # -- projection ------------------------------------------------------------------
 _ws = {}
 

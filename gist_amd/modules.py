@@ -55,6 +55,43 @@ class ISTSAGELayer(nn.Module):
         return g.norm().unsqueeze(1)
 
 
+class GraphSAGELayer(nn.Module):
+    """The reference's GraphSAGELayer (cluster_gcn/modules.py:100-159) -- the layer --use-pp was
+    written for: with use_pp=True and in training mode the input already is [h | A^h] (built once
+    by ClusterIter.precalc, sampler.py:58-69) and the layer only projects it; otherwise it
+    aggregates like ISTSAGELayer.  LayerNorm here is elementwise_affine=True (modules.py:123)."""
+
+    def __init__(self, in_feats, out_feats, activation, dropout, bias=True, use_pp=False,
+                 use_lynorm=True):
+        super().__init__()
+        self.linear = nn.Linear(2 * in_feats, out_feats, bias=bias)
+        self.activation = activation
+        self.use_pp = use_pp
+        self.dropout = nn.Dropout(p=dropout) if dropout else 0.
+        self.lynorm = nn.LayerNorm(out_feats, elementwise_affine=True) if use_lynorm else (lambda x: x)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.linear.weight.size(1))
+        self.linear.weight.data.uniform_(-stdv, stdv)
+        if self.linear.bias is not None:
+            self.linear.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, g, h):
+        if not self.use_pp or not self.training:               # modules.py:133-139
+            ah = autograd.spmm_sum(g, h, out_scale=g.norm())
+            h = torch.cat((h, ah), dim=1)
+        if self.dropout:
+            h = self.dropout(h)
+        h = autograd.matmul(h, self.linear.weight.t())
+        if self.linear.bias is not None:
+            h = h + self.linear.bias
+        h = self.lynorm(h)
+        if self.activation:
+            h = self.activation(h)
+        return h
+
+
 class GCN(nn.Module):
     """Layer sizing of the reference's GCN (modules.py:245-308)."""
 

@@ -63,10 +63,6 @@ class ClusterIter(object):
 
     def __init__(self, dn, g, psize, batch_size, seed_nid, use_pp=False, par_li=None,
                  device=None):
-        if use_pp:
-            raise NotImplementedError(
-                'gist_amd: use_pp doubles the feature width after in_feats was read and cannot '
-                'work with GCN/ISTSAGELayer in the reference either (SURVEY.md appendix C.8)')
         self.use_pp = use_pp
         if device is None:
             device = g.device if g.device.type == 'cuda' else torch.device(
@@ -75,6 +71,8 @@ class ClusterIter(object):
         if torch.is_tensor(seed_nid):
             seed_nid = seed_nid.cpu().numpy()
         self.g = gd.subgraph(np.asarray(seed_nid, np.int64))         # sampler.py:34
+        if use_pp:                                                   # sampler.py:37-40
+            self.precalc(self.g)
         self.psize = psize
         self.batch_size = batch_size
         if par_li is not None:
@@ -92,6 +90,21 @@ class ClusterIter(object):
         random.shuffle(self.par_li)                                  # sampler.py:55
         self.get_fn = get_subgraph
         self.n = 0
+
+    def precalc(self, g):
+        """sampler.py:58-69: the TRAIN graph's features become [X | A^ X] (A^ = mean over
+        in-neighbours), computed once on the device by the aggregation kernel, so that a layer built
+        with use_pp=True (gist_amd.modules.GraphSAGELayer, the reference's modules.py:100-159) skips
+        its own aggregation while training.  Not usable with GCN / ISTSAGELayer, whose first layer
+        aggregates itself (in the reference too: SURVEY.md appendix C.8)."""
+        x = g.ndata['feat']
+        n, f = x.shape
+        z = torch.empty(n, 2 * f, dtype=torch.float32, device=x.device)
+        hip.block_gather(x, None, None, z[:, :f])
+        xs = x if f % 4 == 0 else z[:, :f]                     # any 2-D view with unit inner stride
+        hip.spmm(g.rowptr, g.col, xs, z[:, f:], out_scale=g.norm())
+        g.ndata['norm'] = g.norm().unsqueeze(1)
+        g.ndata['feat'] = z
 
     def __len__(self):
         return self.max

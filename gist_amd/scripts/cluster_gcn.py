@@ -56,17 +56,16 @@ def main(args, dataset=None, log=print):
         raise NotImplementedError(f'{args.model_type} is not a supported model type')
     data = dataset if dataset is not None else load_data(args)
     g = data.g
-    if args.normalize:                                     # :36-42 StandardScaler on train rows
-        feats = g.ndata['feat']
-        tm = g.ndata['train_mask']
-        mu = feats[tm].mean(0, keepdim=True)
-        sd = feats[tm].std(0, unbiased=False, keepdim=True)
-        sd[sd == 0] = 1.0
-        g.ndata['feat'] = ((feats - mu) / sd).float()
-    in_feats = g.ndata['feat'].shape[1]
-    n_classes = data.num_classes
     device = torch.device('cuda', args.gpu)
     torch.cuda.set_device(device)
+    if args.normalize:                 # StandardScaler fit on the train rows, on the device
+        from gist_amd import hip
+        feats = g.ndata['feat'].to(device).contiguous()
+        fit = torch.nonzero(g.ndata['train_mask'].to(device)).flatten().to(torch.int32)
+        hip.standard_scale_(feats, fit)
+        g.ndata['feat'] = feats
+    in_feats = g.ndata['feat'].shape[1]
+    n_classes = data.num_classes
     par_li = getattr(data, 'par_li', None)
     psize = len(par_li) if par_li is not None else args.psize
     log('labels shape:', g.ndata['label'].shape)

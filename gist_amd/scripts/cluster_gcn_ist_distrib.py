@@ -97,12 +97,12 @@ def main(args=None, dataset=None, log=print, ultra_wide=False):
                             rank=args.rank, world_size=args.num_subnet)
     data = dataset if dataset is not None else load_data(args)
     g = data.g
-    if args.normalize:
-        feats, tm = g.ndata['feat'], g.ndata['train_mask']
-        mu = feats[tm].mean(0, keepdim=True)
-        sd = feats[tm].std(0, unbiased=False, keepdim=True)
-        sd[sd == 0] = 1.0
-        g.ndata['feat'] = ((feats - mu) / sd).float()
+    if args.normalize:                 # StandardScaler fit on the train rows, on the device
+        from gist_amd import hip
+        feats = g.ndata['feat'].to(device).contiguous()
+        fit = torch.nonzero(g.ndata['train_mask'].to(device)).flatten().to(torch.int32)
+        hip.standard_scale_(feats, fit)
+        g.ndata['feat'] = feats
     in_feats, n_classes = g.ndata['feat'].shape[1], data.num_classes
     train_nid = np.nonzero(g.ndata['train_mask'].numpy())[0].astype(np.int64)
     par_li = getattr(data, 'par_li', None)

@@ -316,6 +316,22 @@ int gist_mean_rows_f32(const float *src, int64_t stride, int64_t n_src, int64_t 
  * Whole training iteration in one call (native step driver)
  * ------------------------------------------------------------------------- */
 
+/* ---------------------------------------------------------------------------
+ * Data preparation
+ * ------------------------------------------------------------------------- */
+
+/* sklearn.preprocessing.StandardScaler as the reference applies it before training
+ * (cluster_gcn/cluster_gcn_ist_distrib.py:492-499, cluster_gcn/cluster_gcn.py:37-44), in place on
+ * the device-resident feature matrix x[n_rows, d]: mean[c] and the POPULATION variance var[c] of
+ * every column over the rows fit_rows[0..n_fit_rows) (the train nodes; NULL = the first n_fit_rows
+ * rows), accumulated in float64 in a fixed order; then every row becomes
+ * f32(f32(x - mean) / scale) with scale = sqrt(var), 1 where var == 0.  mean / var are outputs
+ * (float64 [d], device).  Workspace: gist_standard_scaler_workspace_bytes (host function). */
+int64_t gist_standard_scaler_workspace_bytes(int64_t n_fit_rows, int64_t d);
+int gist_standard_scaler_f32(float *x, int64_t ld, int64_t n_rows, int64_t d,
+                             const int32_t *fit_rows, int64_t n_fit_rows, double *mean, double *var,
+                             void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
 #define GIST_MAX_LAYERS 16
 
 /* One SAGE layer's buffers (all device pointers, all preallocated by the caller). */

@@ -515,6 +515,35 @@ def calc_acc(y_true, logits):
 
 
 # ----------------------------------------------------------------------------
+# data preparation (cluster_gcn_ist_distrib.py:492-499, sampler.py:58-69)
+# ----------------------------------------------------------------------------
+
+def standard_scaler(feats, fit_mask):
+    """sklearn.preprocessing.StandardScaler().fit(feats[fit_mask]).transform(feats) as the
+    reference applies it (cluster_gcn/cluster_gcn_ist_distrib.py:492-499): float64 mean and
+    POPULATION variance per column over the train rows, scale = sqrt(var) with 0 -> 1, and
+    sklearn's in-place float32 transform `X -= mean_; X /= scale_` (two roundings).  sklearn is
+    a third-party dependency: tests/test_oracle_golden.py checks this restatement against the
+    installed sklearn itself.  Returns (scaled float32 [N,F], mean, var)."""
+    x = _f32(feats)
+    fit = x[np.asarray(fit_mask, bool)].astype(np.float64)
+    mean = fit.mean(axis=0)
+    var = ((fit - mean) ** 2).mean(axis=0)
+    scale = np.sqrt(var)
+    scale[scale == 0.0] = 1.0
+    out = (x.astype(np.float64) - mean).astype(np.float32)
+    out = (out.astype(np.float64) / scale).astype(np.float32)
+    return out, mean, var
+
+
+def preaggregate(rowptr, col, feats):
+    """ClusterIter.precalc (cluster_gcn/sampler.py:58-69, --use-pp): [X | A^ X] with
+    A^ = diag(1/in_deg) A on the TRAIN graph (zero-degree rows -> 0)."""
+    x = _f32(feats)
+    return np.concatenate([x, spmm_sum(rowptr, col, x, out_scale=in_degree_norm(rowptr))], axis=1)
+
+
+# ----------------------------------------------------------------------------
 # small-graph GCN layer (gcn/gcn.py; DGL GraphConv, [DGL recalled] -- UNPINNED)
 # ----------------------------------------------------------------------------
 

@@ -559,3 +559,69 @@ def test_spmm_blocked_lds(hip, n, d, deg, hub, blocks):
     dh = np.ascontiguousarray(g[:, :d])
     O.spmm_sum(t_rp, t_cl, g[:, d:], src_scale=norm, out=dh, accumulate=True)
     close(gt[:, :d], dh)
+
+
+@pytest.mark.parametrize('n,f,n_fit', [(5000, 602, 3300), (700, 37, 700), (300, 100, 17)])
+def test_standard_scaler_on_device(hip, n, f, n_fit):
+    """gist_standard_scaler_f32 == the oracle's sklearn StandardScaler restatement (pinned to
+    sklearn itself on the CPU): statistics over the fit rows only, float64 mean / population
+    variance, zero-variance column -> scale 1, transform of every row."""
+    from oracle import gist_oracle as O
+    rs = np.random.RandomState(n + f)
+    x = (rs.randn(n, f) * rs.uniform(0.01, 30, f) + rs.uniform(-50, 50, f)).astype(np.float32)
+    x[:, f // 2] = -3.5
+    rows = np.sort(rs.choice(n, n_fit, replace=False))
+    mask = np.zeros(n, bool)
+    mask[rows] = True
+    want, mean, var = O.standard_scaler(x, mask)
+    xt = torch.from_numpy(x).to(DEV)
+    m, v = hip.standard_scale_(xt, torch.from_numpy(rows.astype(np.int32)).to(DEV))
+    assert np.allclose(m.cpu().numpy(), mean, rtol=1e-12, atol=1e-12)
+    assert np.allclose(v.cpu().numpy(), var, rtol=1e-9, atol=1e-12)
+    assert np.abs(xt.cpu().numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    assert np.array_equal(xt[:, f // 2].cpu().numpy(), want[:, f // 2])
+    if n_fit == n:                                     # rows = NULL: all rows
+        xt2 = torch.from_numpy(x).to(DEV)
+        hip.standard_scale_(xt2)
+        assert torch.equal(xt2, xt)
+
+
+def test_use_pp_preaggregation():
+    """--use-pp (sampler.py:58-69, modules.py:100-159): ClusterIter(use_pp=True) turns the train
+    graph's features into [X | A^X] once, on the device == the oracle; a GraphSAGELayer built with
+    use_pp=True then skips its own aggregation in training and gives the same output as the layer
+    that aggregates itself."""
+    import random
+    import torch.nn.functional as F
+    from gist_amd import datasets
+    from gist_amd.modules import GraphSAGELayer
+    from gist_amd.sampler import ClusterIter
+    from oracle import gist_oracle as O
+    ds = datasets.toy(seed=8, n_feats=30)
+    g = ds.g
+    train_nid = np.nonzero(g.ndata['train_mask'].numpy())[0].astype(np.int64)
+    random.seed(1)
+    it_pp = ClusterIter('toy', g, len(ds.par_li), 4, train_nid, use_pp=True,
+                        par_li=[p.copy() for p in ds.par_li], device=torch.device(DEV))
+    random.seed(1)
+    it = ClusterIter('toy', g, len(ds.par_li), 4, train_nid, use_pp=False,
+                     par_li=[p.copy() for p in ds.par_li], device=torch.device(DEV))
+    tg = it.g
+    want = O.preaggregate(tg.rowptr.cpu().numpy().astype(np.int64), tg.col.cpu().numpy().astype(np.int64),
+                          tg.ndata['feat'].cpu().numpy())
+    got = it_pp.g.ndata['feat'].cpu().numpy()
+    assert got.shape == (tg.number_of_nodes(), 60) and np.abs(got - want).max() < 1e-5
+    # the layer on the WHOLE train graph: pre-aggregated input == own aggregation
+    torch.manual_seed(0)
+    pp = GraphSAGELayer(30, 16, F.relu, 0.0, use_pp=True).to(DEV)
+    own = GraphSAGELayer(30, 16, F.relu, 0.0, use_pp=False).to(DEV)
+    own.load_state_dict(pp.state_dict())
+    pp.train(); own.train()
+    a = pp(it_pp.g, it_pp.g.ndata['feat'])
+    b = own(tg, tg.ndata['feat'])
+    assert (a - b).abs().max().item() < 1e-4
+    pp.eval()                                          # eval: aggregates itself (modules.py:133)
+    c = pp(tg, tg.ndata['feat'])
+    assert (c - b).abs().max().item() < 1e-4
+    sub = next(iter(it_pp))                            # batches carry the 2F-wide features
+    assert sub.ndata['feat'].shape[1] == 60

@@ -288,3 +288,31 @@ def test_G5_train_cora_loop(golden_dir, tag):
     assert abs(max(r[0] for r in record) - tail['Best Val Accuracy']) < 1e-4
     assert abs(max(r[1] for r in record) - tail['Best Test Accuracy']) < 1e-4
     assert losses[-1] < losses[0]                       # it trains
+
+
+def test_standard_scaler_matches_sklearn():
+    """The oracle's StandardScaler restatement against the installed sklearn (the reference's own
+    dependency, cluster_gcn_ist_distrib.py:492-499): zero-variance column, large offsets."""
+    sk = pytest.importorskip('sklearn.preprocessing')
+    rs = np.random.RandomState(3)
+    x = (rs.randn(500, 37) * rs.uniform(0.01, 50, 37) + rs.uniform(-100, 100, 37)).astype(np.float32)
+    x[:, 5] = 7.0                                      # zero variance -> scale 1
+    mask = rs.rand(500) < 0.6
+    scaler = sk.StandardScaler()
+    scaler.fit(x[mask])
+    want = scaler.transform(x)
+    got, mean, var = O.standard_scaler(x, mask)
+    assert want.dtype == np.float32
+    assert np.allclose(mean, scaler.mean_, rtol=1e-12, atol=1e-12)
+    assert np.allclose(var, scaler.var_, rtol=1e-9, atol=1e-12)
+    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    assert np.array_equal(got[:, 5], want[:, 5])
+
+
+def test_preaggregate_is_the_layer0_aggregation(golden_dir):
+    """sampler.py:58-69: [X | A^X] equals what ISTSAGELayer computes for its first layer
+    (G1 fixture's z = cat(h, ah))."""
+    d = _load(golden_dir, 'G1_layer_n64_ln1_act1.npz')
+    z = O.preaggregate(d['rowptr'], d['col'], d['h'])
+    _, cache = O.sage_layer_forward(d['rowptr'], d['col'], d['h'], d['W'], d['b'], True, True)
+    assert np.array_equal(z, cache['z'])
