@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--n-layers', type=int, default=2)
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--iter-per-site', type=int, default=100)
-    ap.add_argument('--gemm-mode', choices=['f32', 'f16x3'], default='f32',
+    ap.add_argument('--gemm-mode', choices=['f32', 'f16x3', 'bf16x3'], default='f32',
                     help='products of the large projections behind `value`: v_mfma_f32_32x32x2_f32 '
                          '(default: fp32 arithmetic) or the 3-term f16 split on the f16 matrix cores')
     ap.add_argument('--no-second-leg', action='store_true',
@@ -240,7 +240,8 @@ def main():
     # workspaces are sized for the split path (a superset of what mode f32 needs), then the
     # requested mode is selected for the headline run
     second_leg = world == 1 and not args.no_second_leg
-    hip.gemm_mode('f16x3' if (second_leg or args.gemm_mode == 'f16x3') else 'f32')
+    # (sized in the mode with the largest workspaces among the ones this run will use)
+    hip.gemm_mode('bf16x3' if (second_leg or args.gemm_mode == 'bf16x3') else args.gemm_mode)
     seed = 0
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -288,6 +289,8 @@ def main():
         ist_model.ini_sync_dispatch_model()
         engine = ist_model.engine
         dims = ist_model.sub_dims
+    if second_leg:
+        hip.gemm_mode('f16x3')       # the f16x3 leg's kept-split workspace is sized at bind time
     it.bind(engine)
     hip.gemm_mode(args.gemm_mode)
     lr = 0.01
@@ -373,22 +376,25 @@ def main():
         ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         sampled = 'every %d-th timed step (%d of %d)' % (every, n_instr, steps)
         h3 = prof['h3']
-        if mode == 'f16x3' and h3:
+        if mode in ('f16x3', 'bf16x3') and h3:
+            terms = 3 if mode == 'f16x3' else 6
             # the split GEMM's main kernel, bracketed on its own.  achieved = ALGORITHMIC flops
             # (2mnk) / its time; it executes 3 f16 MFMA flops per algorithmic flop.
             h_ms = sum(ms for ms, _ in h3)
             h_flop = sum(2.0 * m * n * k for _, (m, n, k) in h3)
             h_ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
-            traffic, src = _traffic('gemm_h3_traffic.json')
+            traffic, src = _traffic('gemm_h3_traffic.json') if terms == 3 else (None, None)
             shapes = set(s for _, s in h3)
             return {
-                'kernel': 'gist::gemm_h3_kernel (v_mfma_f32_16x16x32_f16, 3 MFMA flops per '
-                          'algorithmic flop: ah.bh + ah.bl + al.bh)',
+                'kernel': ('gist::gemm_h3_kernel (v_mfma_f32_16x16x32_f16, 3 MFMA flops per algorithmic '
+                           'flop: ah.bh + ah.bl + al.bh)') if terms == 3 else
+                          ('gist::gemm_b3_kernel (v_mfma_f32_16x16x32_bf16, 6 MFMA flops per algorithmic '
+                           'flop: three bf16 pieces per operand = all 24 bits, six cross terms)'),
                 'bound': 'mfma', 'achieved': round(h_ach, 3), 'peak': MFMA_F16_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(h_ach / MFMA_F16_PEAK_TFLOPS, 4),
-                'mfma_flops_per_algorithmic_flop': 3,
-                'mfma_rate_tflops': round(3 * h_ach, 1),
-                'frac_mfma_rate_of_peak': round(3 * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
+                'mfma_flops_per_algorithmic_flop': terms,
+                'mfma_rate_tflops': round(terms * h_ach, 1),
+                'frac_mfma_rate_of_peak': round(terms * h_ach / MFMA_F16_PEAK_TFLOPS, 4),
                 'traffic': traffic, 'traffic_source': src, 'launches': len(h3), 'sampled': sampled,
                 'avg_launch_ms': round(h_ms / max(len(h3), 1), 5), 'share_of_step': share(h_ms),
                 # every projection call of the step: split pre-pass + main kernel, and the
@@ -459,23 +465,28 @@ def main():
             'amortized_ms_per_step': round((s_ms + d_ms) / args.iter_per_site, 5),
         }
 
-    # ---- N=1: the same workload in the other GEMM mode, same process --------------------------
-    leg = None
+    # ---- N=1: the same workload in the other GEMM modes, same process --------------------------
+    legs = {}
     if second_leg:
-        other = 'f16x3' if args.gemm_mode == 'f32' else 'f32'
-        hip.gemm_mode(other)
-        n_re = max(args.steps // 2, 10)
-        run_steps(3)
-        e2, prof2, _, _, _ = timed_region(n_re, timing)
+        for other in ('f32', 'bf16x3', 'f16x3'):
+            if other == args.gemm_mode:
+                continue
+            hip.gemm_mode(other)
+            n_re = max(args.steps // 3, 10)
+            run_steps(3)
+            e2, prof2, _, _, _ = timed_region(n_re, timing)
+            leg = {'value': round(n_re / STEPS_PER_EPOCH / e2, 4), 'unit': 'epochs/s',
+                   'ms_per_step': round(e2 / n_re * 1e3, 4), 'steps': n_re, 'gemm_mode': other,
+                   'dtype': {'f32': 'f32',
+                             'bf16x3': 'f32 storage/accumulation; projection products from 3 bf16 pieces per '
+                                       'operand (all 24 bits), 6 cross terms on v_mfma_f32_16x16x32_bf16',
+                             'f16x3': 'f32 storage/accumulation; projection products as 3 f16-split MFMA '
+                                      'terms (22 of 24 operand bits)'}[other],
+                   'note': 'same process, same workload, re-timed after the headline run; not `value`'}
+            if prof2 is not None:
+                leg['roofline'] = gemm_roofline(prof2, e2, n_re, other)
+            legs[{'f32': 'f32_mfma', 'bf16x3': 'bf16x3_split', 'f16x3': 'f16x3_split'}[other]] = leg
         hip.gemm_mode(args.gemm_mode)
-        leg = {'value': round(n_re / STEPS_PER_EPOCH / e2, 4), 'unit': 'epochs/s',
-               'ms_per_step': round(e2 / n_re * 1e3, 4), 'steps': n_re, 'gemm_mode': other,
-               'dtype': 'f32' if other == 'f32' else
-                        'f32 storage/accumulation; projection products as 3 f16-split MFMA terms '
-                        '(22 of 24 operand bits)',
-               'note': 'same process, same workload, re-timed after the headline run; not `value`'}
-        if prof2 is not None:
-            leg['roofline'] = gemm_roofline(prof2, e2, n_re, other)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -552,8 +563,7 @@ def main():
                 'mean_batch_rows': round(float(np.mean(n_log)), 1),
                 'mean_batch_nnz': round(float(nnz.mean()), 1),
             }
-        if leg is not None:
-            out['f16x3_split' if leg['gemm_mode'] == 'f16x3' else 'f32_mfma'] = leg
+        out.update(legs)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 ncpu = host_cores()

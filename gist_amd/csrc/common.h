@@ -72,6 +72,23 @@ int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, c
                      const float *inv_b, const float *bias, float *c, int64_t ldc, int64_t m,
                      int64_t n, int64_t k, hipStream_t st);
 
+// gemm_b3.hip: the bf16x3 split projection path (all 24 operand bits, no scales).  Split operand =
+// [rows][b3_kpad(k)] elements of 6 bytes (three bf16 pieces per element, 16-byte chunks per 8 k).
+int h3_mode();                        // 0 fp32 MFMA, 1 f16x3, 2 bf16x3 (gist_gemm_set_mode)
+int64_t b3_kpad(int64_t k);
+bool b3_eligible(int64_t m, int64_t n, int64_t k);
+bool b3_eligible_kept(int64_t m, int64_t n, int64_t k);
+struct B3Dual {                       // one read of src[rows, cols] -> up to two split operands
+    const float *src; int64_t ld; int64_t rows, cols;
+    float p; uint64_t seed, offset;   // dropout applied on the fly (p = 0: none), gist_dropout_f32's stream
+    uint16_t *dst_r;                  // [rows][kpad(cols)]: k = columns of src   (NULL: skip)
+    uint16_t *dst_t;                  // [cols][kpad(rows)]: k = rows of src      (NULL: skip)
+    bool vec4;                        // set by b3_dual_split: 16-byte loads allowed
+};
+int b3_dual_split(const B3Dual &d, hipStream_t st);
+int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
+                     int64_t ldc, int64_t m, int64_t n, int64_t k, hipStream_t st);
+
 // rowops.hip: the C-ABI kernels with the extra outputs the split projection path consumes
 int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
                    float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,

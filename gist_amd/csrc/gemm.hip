@@ -600,6 +600,11 @@ int h3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
             int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
             void *ws, int64_t ws_bytes, hipStream_t st);
 int64_t h3_workspace_bytes(int64_t m, int64_t n, int64_t k);
+// gemm_b3.hip: the bf16x3 split path (all 24 operand bits on the bf16 matrix cores)
+int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda, const float *b,
+            int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+            void *ws, int64_t ws_bytes, hipStream_t st);
+int64_t b3_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
     const int64_t kt = ceil_div(k, 32);      // the model counts k in units of 32
@@ -680,7 +685,9 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
         set_error("%s: leading dimension >= 2^22 elements", name); return GIST_EINVAL;
     }
     {   // large, chip-filling shapes: split operands + f16 MFMA (mode 1); 0 = not taken
-        const int rc = h3_gemm(name, A_KC, B_KC, a, lda, b, ldb, bias, c, ldc, m, n, k, ws, ws_bytes, st);
+        int rc = h3_gemm(name, A_KC, B_KC, a, lda, b, ldb, bias, c, ldc, m, n, k, ws, ws_bytes, st);
+        if (rc != 0) return rc < 0 ? rc : GIST_OK;
+        rc = b3_gemm(name, A_KC, B_KC, a, lda, b, ldb, bias, c, ldc, m, n, k, ws, ws_bytes, st);   // mode 2
         if (rc != 0) return rc < 0 ? rc : GIST_OK;
     }
     GemmArgs g;
@@ -726,6 +733,8 @@ extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const int64_t h3 = gist::h3_workspace_bytes(m, n, k);
     if (h3 > 0) return h3;
+    const int64_t b3 = gist::b3_workspace_bytes(m, n, k);
+    if (b3 > 0) return b3;
     const int s = gist::choose_cfg(m, n, k).splits;
     return s > 1 ? (int64_t)s * m * n * 4 : 0;
 }

@@ -565,6 +565,7 @@ int h3_mode() {
         g_h3_mode = 0;      // default: fp32 products (v_mfma_f32_32x32x2_f32), like the reference's nn.Linear
         if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) g_h3_mode = 0;
         else if (e && (!strcmp(e, "f16x3") || !strcmp(e, "1"))) g_h3_mode = 1;
+        else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "2"))) g_h3_mode = 2;
     }
     return g_h3_mode;
 }
@@ -703,7 +704,8 @@ int h3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
 }  // namespace gist
 
 extern "C" int gist_gemm_set_mode(int mode) {
-    GIST_REQUIRE(mode == 0 || mode == 1, "gist_gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (f16x3 split)");
+    GIST_REQUIRE(mode >= 0 && mode <= 2,
+                 "gist_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (f16x3 split) or 2 (bf16x3 split)");
     gist::g_h3_mode = mode;
     return GIST_OK;
 }

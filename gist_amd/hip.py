@@ -179,11 +179,11 @@ def gemm_mode(mode=None):
     accuracy on the step's data; include/gist_hip.h gist_gemm_set_mode).  Process-wide."""
     L = _lib.load()
     if mode is not None:
-        code = {'f32': 0, 'f16x3': 1, 0: 0, 1: 1}.get(mode)
+        code = {'f32': 0, 'f16x3': 1, 'bf16x3': 2, 0: 0, 1: 1, 2: 2}.get(mode)
         if code is None:
-            raise ValueError("gist_amd: gemm mode must be 'f32' or 'f16x3'")
+            raise ValueError("gist_amd: gemm mode must be 'f32', 'f16x3' or 'bf16x3'")
         _lib.check(L.gist_gemm_set_mode(code), 'gist_gemm_set_mode')
-    return 'f16x3' if L.gist_gemm_get_mode() == 1 else 'f32'
+    return ('f32', 'f16x3', 'bf16x3')[L.gist_gemm_get_mode()]
 
 
 def tuning(knob, value=None):

@@ -37,10 +37,10 @@ for (lay, m, n, k) in shapes:
         a, w, y = torch.randn(k, m, device=dev), torch.randn(k, n, device=dev), torch.empty(m, n, device=dev)
         f = lambda: hip.gemm_tn(a, w, y)
     res = {}
-    for mode in ('f32', 'f16x3', 'f32', 'f16x3'):
+    for mode in ('f32', 'f16x3', 'bf16x3', 'f32', 'f16x3', 'bf16x3'):
         hip.gemm_mode(mode)
         res.setdefault(mode, []).append(timeit(f))
-    t1, t3 = min(res['f32']), min(res['f16x3'])
+    t1, t3, tb = min(res['f32']), min(res['f16x3']), min(res['bf16x3'])
     gf = 2.0 * m * n * k / 1e9
-    print('%s m=%d n=%d k=%d  f32 %.3f ms %.1f TF | f16x3 %.3f ms %.1f TF-equiv | x%.2f' % (
-        lay, m, n, k, t1, gf / t1, t3, gf / t3, t1 / t3), flush=True)
+    print('%s m=%d n=%d k=%d  f32 %.3f ms %.1f TF | f16x3 %.3f ms %.1f TF-equiv x%.2f | bf16x3 %.3f ms %.1f TF-equiv x%.2f' % (
+        lay, m, n, k, t1, gf / t1, t3, gf / t3, t1 / t3, tb, gf / tb, t1 / tb), flush=True)

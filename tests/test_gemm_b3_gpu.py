@@ -1,0 +1,197 @@
+"""GPU tests of the bf16x3 split projection path (gist_amd/csrc/gemm_b3.hip) through the C ABI:
+every fp32 operand is carried with ALL 24 significant bits (three bf16 pieces, the six cross terms
+down to 2^-16), so its error against a float64 product must be at or below the fp32-MFMA kernel's
+(mode 'f32') on the same operands -- on the shapes the training step runs, on operands of very
+different magnitudes, and on ADVERSARIAL operands: heavy cancellation, rows whose in-row dynamic
+range exceeds 2^17 (and 2^40), values at the edges of the fp32 exponent range."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from gist_amd import hip as h
+    assert h.device_count() >= 1
+    prev = h.gemm_mode()
+    h.tuning('h3_min_gflop', 1)      # also exercise shapes below the production threshold
+    h.tuning('h3_min_tiles', 16)
+    yield h
+    h.gemm_mode(prev)
+    h.tuning('h3_min_gflop', 0)
+    h.tuning('h3_min_tiles', 0)
+
+
+def _run(hip, form, a, w, bias, m, n):
+    out = torch.full((m, n), float('nan'), device=DEV)
+    if form == 'nt':
+        hip.gemm_nt(a, w, bias, out)
+    elif form == 'nn':
+        hip.gemm_nn(a, w, out)
+    else:
+        hip.gemm_tn(a, w, out)
+    return out
+
+
+def _shape(form, m, n, k):
+    if form == 'nt':
+        return (m, k), (n, k)
+    if form == 'nn':
+        return (m, k), (k, n)
+    return (k, m), (k, n)
+
+
+def _operands(form, m, n, k, gen, kind):
+    sa, sb = _shape(form, m, n, k)
+    a = torch.randn(*sa, device=DEV, generator=gen)
+    b = torch.randn(*sb, device=DEV, generator=gen)
+    kdim_a = 1 if form in ('nt', 'nn') else 0           # which axis of a is k
+    kdim_b = 1 if form == 'nt' else 0
+    if kind == 'train':           # post-LayerNorm/ReLU/dropout activations x U(-b, b) weights
+        a = torch.relu(a) * 1.25 * (torch.rand(*sa, device=DEV, generator=gen) > 0.2)
+        b = (torch.rand(*sb, device=DEV, generator=gen) - 0.5) * 0.022
+    elif kind == 'grad':          # tiny gradients, row scales spread over e^(+-4)
+        scale = torch.exp(2 * torch.randn(sa[0], 1, device=DEV, generator=gen)) if kdim_a == 1 else \
+            torch.exp(2 * torch.randn(1, sa[1], device=DEV, generator=gen))
+        a = a * 1e-6 * scale
+    elif kind == 'cancel':        # heavy cancellation: large terms that sum to (almost) nothing
+        half = k // 2
+        if kdim_a == 1:
+            a = torch.cat([a[:, :half], -a[:, :half] * (1 + 1e-6 * torch.randn(sa[0], half, device=DEV, generator=gen))], 1)
+            a = torch.cat([a, torch.zeros(sa[0], k - 2 * half, device=DEV)], 1) * 1e3
+        else:
+            a = torch.cat([a[:half], -a[:half] * (1 + 1e-6 * torch.randn(half, sa[1], device=DEV, generator=gen))], 0)
+            a = torch.cat([a, torch.zeros(k - 2 * half, sa[1], device=DEV)], 0) * 1e3
+        if kdim_b == 1:
+            b = torch.cat([b[:, :half], b[:, :half], b[:, 2 * half:]], 1)
+        else:
+            b = torch.cat([b[:half], b[:half], b[2 * half:]], 0)
+    elif kind == 'range':         # in-row dynamic range 2^40: every element keeps its 24 bits
+        e = torch.randint(-20, 21, sa, device=DEV, generator=gen).float()
+        a = a * torch.exp2(e)
+        e2 = torch.randint(-20, 21, sb, device=DEV, generator=gen).float()
+        b = b * torch.exp2(e2)
+    elif kind == 'edge':          # magnitudes near the ends of the fp32 exponent range
+        a = a * 2.0 ** 60
+        b = b * 2.0 ** -70
+    return a.contiguous(), b.contiguous()
+
+
+def _ref64(form, a, w, rows):
+    a64, w64 = a.double(), w.double()
+    if form == 'nt':
+        return a64[rows] @ w64.t(), a64[rows].abs() @ w64.abs().t()
+    if form == 'nn':
+        return a64[rows] @ w64, a64[rows].abs() @ w64.abs()
+    return a64[:, rows].t() @ w64, a64[:, rows].abs().t() @ w64.abs()
+
+
+SHAPES = [('nt', 2046, 4096, 1204), ('nt', 2046, 4096, 8192), ('nn', 2046, 8192, 4096),
+          ('tn', 4096, 8192, 2046), ('tn', 4096, 1204, 2046), ('nt', 1030, 1100, 1000),
+          ('nn', 1500, 1024, 777), ('tn', 1024, 1204, 2046)]
+
+
+@pytest.mark.parametrize('form,m,n,k', SHAPES)
+@pytest.mark.parametrize('kind', ['normal', 'train', 'grad', 'cancel', 'range', 'edge'])
+def test_bf16x3_error_at_or_below_fp32_mfma(hip, form, m, n, k, kind):
+    from gist_amd import _lib
+    L = _lib.load()
+    hip.gemm_mode('bf16x3')
+    assert L.gist_gemm_workspace_bytes(m, n, k) >= (m + n) * k * 6, 'shape not on the split path'
+    gen = torch.Generator(device=DEV).manual_seed(m + 3 * n + 7 * k)
+    a, w = _operands(form, m, n, k, gen, kind)
+    bias = torch.randn(n, device=DEV, generator=gen) * 1e-3 if form == 'nt' and kind == 'normal' else None
+    rows = torch.arange(0, m, max(1, m // 192), device=DEV)      # a sample of output rows
+    ref, den = _ref64(form, a, w, rows)
+    if bias is not None:
+        ref = ref + bias.double()
+    y3 = _run(hip, form, a, w, bias, m, n)[rows].double()
+    hip.gemm_mode('f32')
+    y1 = _run(hip, form, a, w, bias, m, n)[rows].double()
+    hip.gemm_mode('bf16x3')
+    assert torch.isfinite(y3).all()
+    den = den.clamp(min=1e-300)
+    e3 = ((y3 - ref).abs() / den).max().item()          # error relative to sum |a||b|
+    e1 = ((y1 - ref).abs() / den).max().item()
+    r3 = ((y3 - ref).pow(2).mean().sqrt() / den.pow(2).mean().sqrt()).item()
+    r1 = ((y1 - ref).pow(2).mean().sqrt() / den.pow(2).mean().sqrt()).item()
+    # 24-bit operands, 6 roundings per 32 products: the fp32 kernel's error level (it rounds once
+    # per product); where mode 'f32' picks split-K its chains are shorter and its rms error a
+    # little lower (k = 1204: 2.6e-8 vs 3.2e-8 of sum |a||b|), hence the absolute floors
+    assert e3 <= max(1.25 * e1, 2.5e-7), (kind, e3, e1)
+    assert r3 <= max(1.25 * r1, 4e-8), (kind, r3, r1)
+
+
+def test_bf16x3_is_exact_where_fp32_is(hip):
+    """(1) small integers: every partial sum is an integer below 2^24 -> the exact product, bit for
+    bit; (2) operands with full 24-bit mantissas against the identity: x = b1 + b2 + b3 must
+    reproduce EVERY bit of x (the 22-bit f16x3 split cannot); also catches a swapped fragment or
+    C/D map."""
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    m, n, k = 1030, 1100, 1000
+    a = torch.randint(-8, 9, (m, k), device=DEV, generator=gen).float()
+    w = torch.randint(-8, 9, (n, k), device=DEV, generator=gen).float()
+    y = _run(hip, 'nt', a, w, None, m, n)
+    assert torch.equal(y, (a.double() @ w.double().t()).float())
+    b = torch.randn(1024, 1152, device=DEV, generator=gen) * torch.exp2(
+        torch.randint(-30, 31, (1024, 1152), device=DEV, generator=gen).float())
+    eye = torch.eye(1024, device=DEV)
+    assert torch.equal(_run(hip, 'nn', eye, b, None, 1024, 1152), b)
+    assert torch.equal(_run(hip, 'tn', eye, b, None, 1024, 1152), b)
+    bt = b.t().contiguous()
+    assert torch.equal(_run(hip, 'nt', eye, bt, None, 1024, 1152), b)
+    assert torch.equal(_run(hip, 'nt', bt, eye, None, 1152, 1024), bt)
+
+
+def test_bf16x3_zero_operand_and_output_window(hip):
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    m, n, k = 1030, 1100, 520
+    a = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.zeros(n, k, device=DEV)
+    assert (_run(hip, 'nt', a, w, None, m, n) == 0).all()
+    w = torch.randn(n, k, device=DEV, generator=gen)
+    ybuf = torch.full((m + 3, n + 8), 7.0, device=DEV)
+    hip.gemm_nt(a, w, None, ybuf[:m, 4:4 + n])
+    ref = (a.double() @ w.double().t()).float()
+    assert (ybuf[:m, 4:4 + n] - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    assert (ybuf[m:] == 7.0).all() and (ybuf[:, :4] == 7.0).all() and (ybuf[:, 4 + n:] == 7.0).all()
+
+
+def test_bf16x3_non_finite_inputs_stay_in_their_row(hip):
+    """A NaN or an Inf in one row of an operand makes that output row (A) / column (B) non-finite
+    and leaves every other output exactly as without it (there are no shared scales at all)."""
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    m, n, k = 1030, 1100, 520
+    a = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.randn(n, k, device=DEV, generator=gen)
+    clean = _run(hip, 'nt', a, w, None, m, n)
+    a2, w2 = a.clone(), w.clone()
+    a2[7, 100] = float('nan')
+    a2[500, 3] = float('inf')
+    w2[33, 17] = float('nan')
+    y = _run(hip, 'nt', a2, w2, None, m, n)
+    touched = torch.zeros(m, n, dtype=torch.bool, device=DEV)
+    touched[[7, 500]] = True
+    touched[:, 33] = True
+    assert not torch.isfinite(y[7]).any() and not torch.isfinite(y[:, 33]).any()
+    assert not torch.isfinite(y[500]).any()
+    assert torch.equal(y[~touched], clean[~touched])
+
+
+def test_mode_switch(hip):
+    from gist_amd import _lib
+    L = _lib.load()
+    hip.gemm_mode('f32')
+    assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) == 0
+    hip.gemm_mode('bf16x3')
+    assert hip.gemm_mode() == 'bf16x3'
+    assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) >= (2046 + 4096) * 8192 * 6
+    small = L.gist_gemm_workspace_bytes(2046, 41, 8192)
+    hip.gemm_mode('f32')
+    assert L.gist_gemm_workspace_bytes(2046, 41, 8192) == small      # skinny: fp32 split-K either way
