@@ -582,7 +582,10 @@ static bool h3_shape_ok(int64_t m, int64_t n, int64_t k, double default_min_gflo
     const double t_gflop = tune(GIST_TUNE_H3_MIN_GFLOP), t_tiles = tune(GIST_TUNE_H3_MIN_TILES);
     const double min_gflop = t_gflop > 0.0 ? t_gflop : default_min_gflop;
     const int min_tiles = t_tiles > 0.0 ? (int)t_tiles : 64;
-    if (m < 64 || n < 64 || k < 64) return false;
+    // (an explicit tile threshold -- tests -- also lifts the minimum extents: the kernel itself
+    // handles any m, n, k >= 1)
+    if (t_tiles <= 0.0 && (m < 64 || n < 64 || k < 64)) return false;
+    if (m < 1 || n < 1 || k < 1) return false;
     if (ceil_div(m, H3_T) * ceil_div(n, H3_T) < min_tiles) return false;
     if (2.0 * (double)m * (double)n * (double)k < min_gflop * 1e9) return false;
     if (h3_kpad(k) >= (1LL << 22)) return false;

@@ -62,6 +62,45 @@ def test_e2e_single_gpu_cluster_gcn():
     assert tr.total_time > 0
 
 
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x3'])
+def test_e2e_golden_run_forced_onto_split_gemm(mode):
+    """The reference's recorded cluster_gcn.py run (G6) with EVERY projection of every step forced
+    onto the split GEMM kernels (thresholds lifted through the tuning hooks; the shapes are tiny:
+    k = 2 * 16): parameters after every epoch and the accuracies must match the golden run like
+    the fp32 kernel does -- 1e-4 for bf16x3 (all 24 operand bits) and for f16x3."""
+    from gist_amd import hip, _lib
+    from gist_amd.trainer import ClusterGCNTrainer
+    d = np.load(os.path.join(GOLD, 'G6_e2e_single.npz'))
+    g = _graph(d)
+    L = int(d['n_layers'])
+    prev = hip.gemm_mode()
+    hip.gemm_mode(mode)
+    hip.tuning('h3_min_gflop', 1e-9)
+    hip.tuning('h3_min_tiles', 1)
+    try:
+        assert _lib.load().gist_gemm_workspace_bytes(60, int(d['n_hidden']), 2 * int(d['n_hidden'])) > 0
+        random.seed(int(d['rnd_seed']))
+        tr = ClusterGCNTrainer('toy', g, _parts(d), int(d['psize']), int(d['batch_size']),
+                               int(d['n_hidden']), L, int(d['n_classes']), 0.0, True, float(d['lr']),
+                               0.0, DEV, init_params=_params(d, 'init_', L + 1))
+        tr.engine.enable_timer(4096)
+        val_accs = []
+        for e in range(int(d['n_epochs'])):
+            tr.timed_epoch()
+            for k, (W, b) in enumerate(tr.engine.arena.export()):
+                assert np.abs(W - d['ep%d_W%d' % (e, k)]).max() < TOL, (mode, e, k)
+                assert np.abs(b - d['ep%d_b%d' % (e, k)]).max() < TOL, (mode, e, k)
+            val_accs.append(tr.evaluate('val_mask'))
+        rec = tr.engine.read_timer()
+        assert sum(1 for r in rec if r[1] == 2) >= 3 * (L + 1)      # kind 2: split main kernels ran
+        tr.engine.disable_timer()
+        assert np.allclose(val_accs, d['val_accs'], atol=1e-6)
+    finally:
+        hip.tuning('h3_min_gflop', 0)
+        hip.tuning('h3_min_tiles', 0)
+        hip.gemm_mode(prev)
+
+
 @pytest.mark.parametrize('S', [2, 4])
 def test_e2e_gist_in_process(S):
     from gist_amd import ist
