@@ -18,9 +18,13 @@
 //     row r : [k0..7 b1 (16 B)] [k0..7 b2] [k0..7 b3] [k8..15 b1] ...       (6 bytes per element)
 // A lane's MFMA fragment (8 consecutive k of one row, one piece) is one 16-byte chunk.
 //
-// Main kernel: 128 x 64 x 32 block tile (A 24 KiB + B 12 KiB per stage, two stages = 72 KiB, two
-// workgroups per CU), 4 waves in 2 x 2, wave tile 64 x 32 = 4 x 2 MFMA tiles x 6 terms = 48 MFMAs
-// per k tile, LDS-DMA staging one k tile ahead.  LDS image = [16-row slab][chunk group of 4][chunk]
+// Main kernel: 256 x 128 x 32 block tile (A 48 KiB + B 24 KiB per stage, two stages = 144 KiB, one
+// 512-thread workgroup per CU), 8 waves in 4 x 2, wave tile 64 x 64 = 4 x 4 MFMA tiles x 6 terms =
+// 96 MFMAs per k tile, LDS-DMA staging one k tile ahead.  The tile is this large because at 6 bytes
+// per element the L2 -> LDS traffic bounds smaller ones: 128 x 64 tiles with two workgroups per CU
+// (9.4 GB staged for 2046 x 4096 x 8192) ran at 31 % matrix-pipe occupancy, this one (4.7 GB) at
+// 45 %; a one-stage 128 x 128 variant with two workgroups per CU (fragment reads of one under the
+// MFMAs of the other) was slower than either two-stage kernel (1.05 vs 0.95 ms per call).  LDS image = [16-row slab][chunk group of 4][chunk]
 // [row in slab] x 16 B: a DMA instruction's 1 KiB is 16 rows x 4 consecutive chunks (64 contiguous
 // bytes of global memory per row), and the 16-byte slot index mod 16 is the row in the slab whatever
 // the chunk, so a ds_read_b128 lane group -- rows {0-3, 12-15} of k group g with rows 4-11 of k
@@ -39,6 +43,7 @@ typedef float b3_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int B3_TM = 256, B3_TN = 128, B3_BK = 32;
 constexpr int B3_THREADS = 512;
+constexpr int B3_STAGES = 2;
 #ifndef B3_DMA_AFTER
 #define B3_DMA_AFTER 16        // MFMAs of a k step issued before the next tile's DMA
 #endif
@@ -175,7 +180,7 @@ __device__ __forceinline__ void b3_dma_image(const char *base, const uint32_t (&
 
 __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     extern __shared__ __attribute__((aligned(16))) char b3_smem[];
-    constexpr int NI = 4, NJ = 4;                 // 16-row slabs per wave: 64 x 64 wave tile, 8 waves 4 x 2
+    constexpr int NI = 4, NJ = 4;                 // 16-row slabs per wave: 64 x 64 wave tile
     const int nwg = g.tiles_m * g.tiles_n;
     const int orig = blockIdx.x;
     const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
@@ -203,16 +208,18 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    // A image: 48 DMA instructions (6 per wave); B image: 24 (3 per wave)
-    uint32_t offA[6], offB[3];
-    b3_dma_offsets<6>(g.lda, g.m, row0, 6 * wave, lane, offA);
-    b3_dma_offsets<3>(g.ldb, g.n, col0, 3 * wave, lane, offB);
+    // DMA instructions of 1 KiB: 3 per 16 rows of an image, dealt evenly to the waves
+    constexpr int NWAVES = B3_THREADS / 64;
+    constexpr int DA = B3_TM / 16 * 3 / NWAVES, DB = B3_TN / 16 * 3 / NWAVES;
+    uint32_t offA[DA], offB[DB];
+    b3_dma_offsets<DA>(g.lda, g.m, row0, DA * wave, lane, offA);
+    b3_dma_offsets<DB>(g.ldb, g.n, col0, DB * wave, lane, offB);
     const char *originA = reinterpret_cast<const char *>(g.a) + (int64_t)row0 * g.lda * 6;
     const char *originB = reinterpret_cast<const char *>(g.b) + (int64_t)col0 * g.ldb * 6;
     auto dma = [&](int buf, int kt) {
         char *sa = b3_smem + buf * B3_BUF_BYTES;
-        b3_dma_image<6>(originA + (int64_t)kt * B3_KT_BYTES, offA, sa, 6 * wave);
-        b3_dma_image<3>(originB + (int64_t)kt * B3_KT_BYTES, offB, sa + B3_A_BYTES, 3 * wave);
+        b3_dma_image<DA>(originA + (int64_t)kt * B3_KT_BYTES, offA, sa, DA * wave);
+        b3_dma_image<DB>(originB + (int64_t)kt * B3_KT_BYTES, offB, sa + B3_A_BYTES, DB * wave);
     };
 
     // fragment byte offsets inside an image: chunk c = 3 kg + piece of slab s at
@@ -365,7 +372,7 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
     int dev;
     if (once.needed(&dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_b3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B3_BUF_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, B3_STAGES * B3_BUF_BYTES);
         if (e != hipSuccess) {
             set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return GIST_ELAUNCH;
@@ -380,7 +387,7 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
     g.tiles_n = (int)ceil_div(n, B3_TN);
     const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel alone
     hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(B3_THREADS),
-                       2 * B3_BUF_BYTES, st, g);
+                       B3_STAGES * B3_BUF_BYTES, st, g);
     timer_end(tl_timer, slot, st);
     return launch_status(name);
 }
