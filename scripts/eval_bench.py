@@ -44,7 +44,14 @@ for d in (602, 1024, 4096):
     z = torch.randn(n, 2 * d, device=dev)
     ms = timeit(lambda: hip.spmm(g.rowptr, g.col, z[:, :d], z[:, d:], out_scale=norm))
     alg = 4.0 * (n + 1) + 4.0 * nnz + 8.0 * n * d
-    out['spmm'].append({'D': d, 'ms': round(ms, 3), 'algorithmic_GB': round(alg / 1e9, 3),
+    sizes = np.array([len(b) for b in np.array_split(np.arange(args.n), 2278)])
+    rb = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(dev)
+    ms_b = ms_u = None
+    if d % 4 == 0:
+        ms_b = timeit(lambda: hip.spmm(g.rowptr, g.col, z[:, :d], z[:, d:], out_scale=norm, row_blocks=rb), 3)
+        ms_u = timeit(lambda: hip.spmm(g.rowptr, g.col, z[:, :d], z[:, d:], out_scale=norm, blocked=True), 3)
+    out['spmm'].append({'D': d, 'ms': round(ms, 3), 'ms_lds_blocks': ms_b and round(ms_b, 3),
+                        'ms_lds_uniform128': ms_u and round(ms_u, 3), 'algorithmic_GB': round(alg / 1e9, 3),
                         'achieved_GBps': round(alg / ms / 1e6, 1),
                         'frac_of_8TBps': round(alg / ms / 1e6 / 8000.0, 4),
                         'gather_TBps': round(4.0 * nnz * d / ms / 1e9, 2)})

@@ -1,4 +1,4 @@
-"""Dev tool: row-split (plain) vs LDS-staged SpMM (first and second design) on a Reddit-like
+"""Dev tool: row-split (plain) vs LDS-staged SpMM on a Reddit-like
 cluster batch; forward form (out_scale) and backward form (reversed CSR, src_scale, accumulate);
 also with the batch rows randomly permuted (no block locality: every neighbour cross-block)."""
 import os, sys, random
@@ -62,23 +62,20 @@ def run(tag, rowptr, col, t_rowptr, t_col, norm, blocks):
                 return res().clone()
             ref = once()
             t0 = timeit(lambda: call())
-            hip.tuning('spmm_lds', 1)
-            e1 = (once(row_blocks=blocks) - ref).abs().max().item()
-            t1 = timeit(lambda: call(row_blocks=blocks))
-            hip.tuning('spmm_lds', 0)
             e2 = (once(row_blocks=blocks) - ref).abs().max().item()
             t2 = timeit(lambda: call(row_blocks=blocks))
             e3 = (once(blocked=True) - ref).abs().max().item()
             t3 = timeit(lambda: call(blocked=True))
-            print('%s D=%4d %s: row-split %.1f us (%.0f GB/s) | lds1 parts %.1f us | lds2 parts %.1f us '
-                  '(%.0f GB/s = %.3f of 8 TB/s) | lds2 uniform128 %.1f us | err %.1e %.1e %.1e'
-                  % (tag, d, form, t0 * 1e3, alg / t0 / 1e6, t1 * 1e3, t2 * 1e3, alg / t2 / 1e6,
-                     alg / t2 / 1e6 / 8000, t3 * 1e3, e1, e2, e3), flush=True)
+            print('%s D=%4d %s: row-split %.1f us (%.0f GB/s) | LDS-staged, blocks = parts %.1f us '
+                  '(%.0f GB/s = %.3f of 8 TB/s) | LDS-staged, uniform 128-row blocks %.1f us | max |diff| vs '
+                  'row-split %.1e %.1e   [HIP-event time of one call from Python: includes ~15 us of launch path]'
+                  % (tag, d, form, t0 * 1e3, alg / t0 / 1e6, t2 * 1e3, alg / t2 / 1e6,
+                     alg / t2 / 1e6 / 8000, t3 * 1e3, e2, e3), flush=True)
         if d == 4096:
             for R in (1, 2, 3, 4):
                 hip.tuning('spmm_split', R)
                 t = timeit(lambda: hip.spmm(rowptr, col, z[:, :d], z[:, d:], out_scale=norm, row_blocks=blocks))
-                print('   lds2 D=4096 fwd row_split=%d: %.1f us' % (R, t * 1e3), flush=True)
+                print('   LDS-staged D=4096 fwd row_split=%d: %.1f us' % (R, t * 1e3), flush=True)
             hip.tuning('spmm_split', 0)
 
 

@@ -28,19 +28,9 @@ def timeit(f, it_=30):
 out = []
 for d in [int(x) for x in (sys.argv[1:] or ['4096'])]:
     z = torch.randn(n, 2 * d, device=dev)
-    hip.tuning('spmm_lds', 3)
-    ref = torch.empty(n, d, device=dev)
-    hip.spmm(b.rowptr, b.col, z[:, :d], ref, out_scale=b.norm)
     for R in (0, 1, 2, 3, 4, 6):
+        T = 1
         hip.tuning('spmm_split', R)
-        t = timeit(lambda: hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm, row_blocks=rb), 10)
-        err = (z[:, d:] - ref).abs().max().item()
-        out.append('lds3 D=%d R=%d %.1f us err %.1e' % (d, R, t * 1e3, err))
-    hip.tuning('spmm_lds', 0)
-    combos = [(0, 0)] + [(T, R) for T in (1,) for R in (3,) if T * 256 <= d]
-    for T, R in combos:
-        hip.tuning('spmm_split', R)
-        hip.tuning('spmm_tiles', T)
         t = timeit(lambda: hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm, row_blocks=rb), 10)
         out.append('D=%d T=%d R=%d %.1f us' % (d, T, R, t * 1e3))
 print(os.environ.get('GIST_LIB_PATH', 'default'), ' | '.join(out), flush=True)
