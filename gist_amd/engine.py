@@ -228,6 +228,9 @@ class SageEngine(object):
         # split projection operands kept by the step (include/gist_hip.h, h3_workspace): sized by
         # the library for these shapes; 0 bytes = mode 'f32' or no layer large enough
         P.n_max = self.n_max
+        # upper bound of |feat| for the f16x3 mode's layer-0 split scale (ignored in the other
+        # modes).  `batcher.feat` must not grow in place after this: call attach_batcher again
+        # (it re-reads the bound) if the features are re-normalised or replaced.
         P.feat_absmax = float(batcher.feat.abs().max().item()) if batcher.feat.numel() else 0.0
         import ctypes
         need = _lib.load().gist_step_h3_workspace_bytes(ctypes.byref(P))

@@ -178,3 +178,46 @@ def test_mode_switch_and_small_shapes_stay_fp32(hip):
     assert L.gist_gemm_workspace_bytes(2046, 41, 8192) == small      # skinny: fp32 split-K either way
     with pytest.raises(ValueError):
         hip.gemm_mode('bf16')
+
+
+@pytest.mark.parametrize('form,m,n,k', [('nt', 2046, 4096, 1204), ('nn', 1500, 1024, 777),
+                                        ('tn', 1024, 1204, 2046)])
+@pytest.mark.parametrize('kind', ['cancel', 'range17', 'range', 'clamp'])
+def test_split_adversarial_operands_documented_limits(hip, form, m, n, k, kind):
+    """What the 22-bit f16x3 split does on operands built against it (it is opt-in, and not the
+    arithmetic behind the headline, because of exactly these):
+      cancel   large terms that cancel: the error stays relative to sum |a||b| like fp32's;
+      range17  in-row dynamic range 2^17: elements at the bottom of a row have a subnormal `lo`;
+      range    in-row dynamic range 2^40: elements 2^-22 below their row maximum lose ALL bits
+               (one scale per row) -- error relative to sum |a||b| is still bounded (they are
+               small against the row), but it is 2^-22-level, not 2^-24-level;
+      clamp    row maxima beyond the +-60 scale-exponent clamp (2^73 / 2^-75 magnitudes): the
+               2^-75 operand cannot be scaled into f16's normal range any more and the split degrades
+               to ~13 significant bits (1e-4 relative, measured) -- finite, but not fp32-level.
+    Bounds are the measured behaviour with headroom; the bf16x3 mode holds fp32's level on all of
+    these (tests/test_gemm_b3_gpu.py)."""
+    from tests.test_gemm_b3_gpu import _operands as adv_operands
+    hip.gemm_mode('f16x3')
+    gen = torch.Generator(device=DEV).manual_seed(m + 3 * n + 7 * k + 1)
+    if kind == 'range17':
+        a, w = adv_operands(form, m, n, k, gen, 'normal')
+        a = a * torch.exp2(torch.randint(-17, 1, a.shape, device=DEV, generator=gen).float())
+        w = w * torch.exp2(torch.randint(-17, 1, w.shape, device=DEV, generator=gen).float())
+    elif kind == 'clamp':
+        a, w = adv_operands(form, m, n, k, gen, 'normal')
+        a, w = a * 2.0 ** 73, w * 2.0 ** -75
+    else:
+        a, w = adv_operands(form, m, n, k, gen, kind)
+    rows = torch.arange(0, m, max(1, m // 192), device=DEV)
+    ref, den = _ref64(form, a, w, rows)
+    y3 = _run(hip, form, a, w, None, m, n)[rows].double()
+    hip.gemm_mode('f32')
+    y1 = _run(hip, form, a, w, None, m, n)[rows].double()
+    hip.gemm_mode('f16x3')
+    assert torch.isfinite(y3).all()
+    den = den.clamp(min=1e-300)
+    e3 = ((y3 - ref).abs() / den).max().item()
+    e1 = ((y1 - ref).abs() / den).max().item()
+    bound = {'cancel': 1e-6, 'range17': 2e-6, 'range': 2e-6, 'clamp': 1e-3}[kind]
+    assert e3 <= bound, (kind, e3, e1)
+    assert e1 <= 2e-6, (kind, e1)
