@@ -24,11 +24,18 @@
 // per element the L2 -> LDS traffic bounds smaller ones: 128 x 64 tiles with two workgroups per CU
 // (9.4 GB staged for 2046 x 4096 x 8192) ran at 31 % matrix-pipe occupancy, this one (4.7 GB) at
 // 45 %; a one-stage 128 x 128 variant with two workgroups per CU (fragment reads of one under the
-// MFMAs of the other) was slower than either two-stage kernel (1.05 vs 0.95 ms per call).  LDS image = [16-row slab][chunk group of 4][chunk]
-// [row in slab] x 16 B: a DMA instruction's 1 KiB is 16 rows x 4 consecutive chunks (64 contiguous
-// bytes of global memory per row), and the 16-byte slot index mod 16 is the row in the slab whatever
-// the chunk, so a ds_read_b128 lane group -- rows {0-3, 12-15} of k group g with rows 4-11 of k
-// group g + 1 -- always hits 16 different bank quads (no swizzle needed).
+// MFMAs of the other) was slower than either two-stage kernel (1.05 vs 0.95 ms per call).
+// LDS image = [16-row slab][row][chunk] x 16 B, row-major like the operand: slot L of a slab
+// (L = 12 row + position) holds chunk position ^ (2 if row >= 8), and a slab is three 1 KiB DMA
+// instructions of 64 consecutive slots.  The four lanes of a DMA quad therefore read ONE aligned
+// 64-byte piece of one row: the texture addresser handles a quad per cycle when it lies in one
+// cache line, and the earlier image ([chunk][row]: a quad = 16 bytes from each of four rows, four
+// lines) made the staging address-bound -- 1.08 -> 0.77 ms per 2046 x 4096 x 8192 call for the
+// change of image alone.  The pair swap of rows 8-15 keeps the fragment reads conflict free: a
+// ds_read_b128 lane group is rows {0-3, 12-15} of k group g with rows 4-11 of k group g + 1, i.e.
+// chunks c and c + 3, and 16 B slot index mod 16 = (12 row + (c ^ swap)) mod 16 takes 16 different
+// values over such a group (exhaustive check over the 3 pieces x 2 group kinds; no rotation by whole
+// 64-byte pieces can do it, the slot index mod 4 would repeat).
 #include <stdlib.h>
 #include <string.h>
 
@@ -152,15 +159,19 @@ struct B3Args {
     int tiles_m, tiles_n;
 };
 
-// DMA instruction `inst` of an image: 16-row slab inst / 3, chunks 4 (inst % 3) .. + 3; lane = 16 ci + rr
+// DMA instruction `inst` of an image: slot L = 64 (inst % 3) + lane of 16-row slab inst / 3; slot
+// L holds row L / 12, chunk (L % 12) ^ (2 if row >= 8): the four lanes of a quad read one aligned
+// 64-byte piece of one row
 template <int NI>
 __device__ __forceinline__ void b3_dma_offsets(int64_t ld, int rows, int row0, int first, int lane,
                                                 uint32_t (&off)[NI]) {
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
         const int inst = first + jj;
-        const int r = (inst / 3) * 16 + (lane & 15);
-        const int chunk = (inst % 3) * 4 + (lane >> 4);
+        const int slot = (inst % 3) * 64 + lane;
+        const int rs = slot / 12;
+        const int chunk = (slot % 12) ^ ((rs >> 3) << 1);
+        const int r = (inst / 3) * 16 + rs;
         const int dr = min(r, rows - 1 - row0);
         off[jj] = (uint32_t)((int64_t)dr * ld * 6 + chunk * 16);
     }
@@ -222,18 +233,18 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
         b3_dma_image<DB>(originB + (int64_t)kt * B3_KT_BYTES, offB, sa + B3_A_BYTES, DB * wave);
     };
 
-    // fragment byte offsets inside an image: chunk c = 3 kg + piece of slab s at
-    // ((3 s + c / 4) * 64 + (c % 4) * 16 + rr) * 16
+    // fragment byte offsets inside an image: chunk c = 3 kg + piece of row rr of slab s at slot
+    // 192 s + 12 rr + (c ^ (2 if rr >= 8))
     int fa[NI][3], fb[NJ][3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int c = 3 * kg + p;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            fa[i][p] = ((3 * (wm * NI + i) + (c >> 2)) * 64 + (c & 3) * 16 + rr) * 16;
+            fa[i][p] = ((wm * NI + i) * 192 + rr * 12 + (c ^ ((rr >> 3) << 1))) * 16;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            fb[j][p] = ((3 * (wn * NJ + j) + (c >> 2)) * 64 + (c & 3) * 16 + rr) * 16 + B3_A_BYTES;
+            fb[j][p] = ((wn * NJ + j) * 192 + rr * 12 + (c ^ ((rr >> 3) << 1))) * 16 + B3_A_BYTES;
     }
 
     if (n_kt > 0) dma(0, 0);
