@@ -179,10 +179,56 @@ H3Step h3_layout(const gist_step_plan *p, char *base) {
     h.bytes = off;
     return h;
 }
+
+// bf16x3 mode: the same idea without scales -- three bf16 pieces per element, 6 bytes each
+struct B3Layer {
+    bool on;
+    uint16_t *Zs, *ZsT, *Ws, *WsT; // [n][kpad(2in)], [2in][kpad(n)], [out][kpad(2in)], [2in][kpad(out)]
+};
+struct B3Step {
+    bool any;
+    B3Layer layer[GIST_MAX_LAYERS];
+    uint16_t *dYs, *dYsT;          // [n][kpad(out)], [out][kpad(n)] (shared by the layers)
+    int64_t bytes;
+};
+
+B3Step b3_layout(const gist_step_plan *p, char *base) {
+    B3Step h{};
+    const int L1 = p->n_layers;
+    const int64_t n = p->n_max;
+    if (gist_gemm_get_mode() != 2 || n <= 0) return h;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char *q = base ? base + off : nullptr;
+        off += ceil_div(bytes, 256) * 256;
+        return reinterpret_cast<uint16_t *>(q);
+    };
+    int64_t max_out = 0;
+    for (int k = 0; k < L1; ++k) {
+        const gist_layer_desc &l = p->layer[k];
+        const int64_t i2 = 2 * l.n_in, o = l.n_out;
+        B3Layer &hl = h.layer[k];
+        hl.on = b3_eligible_kept(n, o, i2) && b3_eligible_kept(o, i2, n) &&
+                (k == 0 || b3_eligible_kept(n, i2, o));
+        if (!hl.on) continue;
+        h.any = true;
+        hl.Zs = take(n * b3_kpad(i2) * 6);
+        hl.ZsT = take(i2 * b3_kpad(n) * 6);
+        hl.Ws = take(o * b3_kpad(i2) * 6);
+        hl.WsT = k > 0 ? take(i2 * b3_kpad(o) * 6) : nullptr;
+        max_out = o > max_out ? o : max_out;
+    }
+    if (!h.any) return h;
+    h.dYs = take(n * b3_kpad(max_out) * 6);
+    h.dYsT = take(max_out * b3_kpad(n) * 6);
+    h.bytes = off;
+    return h;
+}
 }  // namespace
 
 extern "C" int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan) {
     if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS) return 0;
+    if (gist_gemm_get_mode() == 2) return b3_layout(plan, nullptr).bytes;
     return h3_layout(plan, nullptr).bytes;
 }
 
@@ -215,6 +261,24 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     if (p->h3_workspace != nullptr && aligned16(p->h3_workspace) && n <= p->n_max) {
         h3 = h3_layout(p, static_cast<char *>(p->h3_workspace));
         if (h3.bytes > p->h3_workspace_bytes) h3 = H3Step{};
+    }
+    B3Step b3{};
+    if (p->h3_workspace != nullptr && aligned16(p->h3_workspace) && n <= p->n_max) {
+        b3 = b3_layout(p, static_cast<char *>(p->h3_workspace));
+        if (b3.bytes > p->h3_workspace_bytes) b3 = B3Step{};
+    }
+    if (b3.any) {      // this step's weights, one read each
+        Scope sc(p->timer, 3, 0, 0, 0, st);
+        for (int k = 0; k < L1; ++k) {
+            const B3Layer &hl = b3.layer[k];
+            if (!hl.on) continue;
+            const gist_layer_desc &l = p->layer[k];
+            B3Dual d{};
+            d.src = l.W; d.ld = 2 * l.n_in; d.rows = l.n_out; d.cols = 2 * l.n_in;
+            d.dst_r = hl.Ws;
+            d.dst_t = train ? hl.WsT : nullptr;
+            GIST_TRY(b3_dual_split(d, st));
+        }
     }
     if (h3.any) {      // this step's weights: rows split for Y = Z.W^T, transposed for dZ = dY.W
         Scope sc(p->timer, 3, 0, 0, 0, st);
@@ -278,6 +342,18 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             if (drop) off += round_up2((uint64_t)n * 2 * l.n_in);
             GIST_TRY(h3_gemm_presplit("gist_sage_step", hl.Zs, hl.inv_zr, hl.Ws, hl.inv_wr, l.b, l.Y,
                                       l.ldy, n, l.n_out, 2 * l.n_in, st));
+        } else if (b3.layer[k].on) {
+            const B3Layer &hl = b3.layer[k];
+            Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
+            B3Dual d{};
+            d.src = l.Z; d.ld = l.ldz; d.rows = n; d.cols = 2 * l.n_in;
+            d.p = drop ? p->p_drop : 0.f; d.seed = p->seed; d.offset = off;
+            d.dst_r = hl.Zs;
+            d.dst_t = train ? hl.ZsT : nullptr;
+            GIST_TRY(b3_dual_split(d, st));
+            if (drop) off += round_up2((uint64_t)n * 2 * l.n_in);
+            GIST_TRY(b3_gemm_presplit("gist_sage_step", hl.Zs, hl.Ws, l.b, l.Y, l.ldy, n, l.n_out,
+                                      2 * l.n_in, st));
         } else {
             if (drop) {
                 GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, off, s));
@@ -338,6 +414,38 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                 Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
                 GIST_TRY(h3_gemm_presplit("gist_sage_step", h3.dYsT, h3.inv_dyt, hl.ZsT, hl.inv_zt,
                                           nullptr, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in, n, st));
+            }
+            if (k > 0) {
+                if (drop)
+                    GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
+                                              offs[k], s));
+                Scope sc(p->timer, 0, n, n, l.n_in, st);
+                GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+            }
+            continue;
+        }
+        if (b3.layer[k].on) {
+            // bias gradient, then one read of dY_k -> both split layouts, dZ_k and dW_k on the splits
+            const B3Layer &hl = b3.layer[k];
+            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
+            {
+                Scope sc(p->timer, 3, 0, 0, 0, st);
+                B3Dual d{};
+                d.src = dy; d.ld = lddy; d.rows = n; d.cols = l.n_out;
+                d.dst_r = k > 0 ? b3.dYs : nullptr;
+                d.dst_t = b3.dYsT;
+                GIST_TRY(b3_dual_split(d, st));
+            }
+            if (k > 0) {
+                Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
+                GIST_TRY(b3_gemm_presplit("gist_sage_step", b3.dYs, hl.WsT, nullptr, p->dZ, 2 * l.n_in, n,
+                                          2 * l.n_in, l.n_out, st));
+            }
+            {
+                Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
+                GIST_TRY(b3_gemm_presplit("gist_sage_step", b3.dYsT, hl.ZsT, nullptr, l.dW, 2 * l.n_in,
+                                          l.n_out, 2 * l.n_in, n, st));
             }
             if (k > 0) {
                 if (drop)

@@ -373,8 +373,11 @@ typedef struct gist_step_plan {
      * and column maxima taken from the LayerNorm-backward and bias-gradient kernels -- instead
      * of once per GEMM call.  n_max = rows the batch buffers were sized for; feat_absmax = an
      * upper bound of |feat| (0 = unknown: layer 0 then takes the per-call path).  A layer qualifies
-     * when its three projections have >= 64 output tiles and >= 4 GFLOP each.  Size the
-     * workspace with gist_step_h3_workspace_bytes; NULL / too small = per-call path. */
+     * when its three projections have >= 64 output tiles and >= 4 GFLOP each.  In mode 2 (bf16x3) the
+     * same workspace holds the three-piece bf16 operands instead (6 bytes per element, no scales or
+     * maxima; a layer qualifies with >= 128 tiles of 256 x 128 and >= 4 GFLOP per projection).  Size
+     * the workspace with gist_step_h3_workspace_bytes IN THE MODE the steps will run in; NULL / too
+     * small / sized in another mode = per-call path. */
     int64_t n_max;
     float feat_absmax;
     void *h3_workspace; int64_t h3_workspace_bytes;
@@ -385,7 +388,8 @@ typedef struct gist_step_plan {
     const int32_t *row_blocks; int64_t n_row_blocks;
 } gist_step_plan;
 
-/* Bytes of h3_workspace the plan's shapes need (0: no layer qualifies, or mode 0). Host function. */
+/* Bytes of h3_workspace the plan's shapes need in the current GEMM mode (0: no layer qualifies, or
+ * mode 0). Host function. */
 int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream by the step

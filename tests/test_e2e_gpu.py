@@ -281,12 +281,14 @@ def _native_vs_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden):
     assert torch.equal(results[0][1], results[1][1])
 
 
+@pytest.mark.parametrize('split', ['f16x3', 'bf16x3'])
 @pytest.mark.parametrize('n_layers,n_feats,n_hidden', [(2, 64, 2048), (3, 302, 2048)])
-def test_native_step_kept_splits_small_batch(n_layers, n_feats, n_hidden):
+def test_native_step_kept_splits_small_batch(n_layers, n_feats, n_hidden, split):
     """A ~500-row batch at width 2048 (projections of 4-8 GFLOP: above the kept-split threshold,
     below the per-call one; batch rows not a multiple of 32, so the transposed splits are
-    zero-padded along k): the native step in GEMM mode f16x3 against the same step in mode f32,
-    same dropout stream -- losses of 4 steps within 1e-4 (of their magnitude: this toy run
+    zero-padded along k): the native step in GEMM mode f16x3 / bf16x3 (the latter with its tile
+    threshold lowered through the tuning hooks: 256 x 128 tiles, this batch has 32 of them) against
+    the same step in mode f32, same dropout stream -- losses of 4 steps within 1e-4 (of their magnitude: this toy run
     diverges to losses ~20), parameters close."""
     from gist_amd import datasets, hip
     from gist_amd.engine import SageEngine, dims_for
@@ -298,8 +300,11 @@ def test_native_step_kept_splits_small_batch(n_layers, n_feats, n_hidden):
     prev = hip.gemm_mode()
     out = {}
     try:
-        for mode in ('f32', 'f16x3'):
+        for mode in ('f32', split):
             hip.gemm_mode(mode)
+            if mode == 'bf16x3':
+                hip.tuning('h3_min_tiles', 1)
+                hip.tuning('h3_min_gflop', 0.5)
             random.seed(4)
             it = EngineClusterIter('toy', g, len(ds.par_li), 5, nid,
                                    par_li=[p.copy() for p in ds.par_li], device=DEV)
@@ -310,7 +315,7 @@ def test_native_step_kept_splits_small_batch(n_layers, n_feats, n_hidden):
                 eng.arena.W[k].copy_((torch.rand(o, 2 * i, generator=gen) - 0.5) * 2 * s_)
                 eng.arena.b[k].copy_((torch.rand(o, generator=gen) - 0.5) * 2 * s_)
             it.bind(eng)
-            assert (eng.plan.h3_workspace is not None) == (mode == 'f16x3')
+            assert (eng.plan.h3_workspace is not None) == (mode != 'f32')
             losses = []
             for j, b in enumerate(it):
                 assert b.n % 32 != 0 or j > 0
@@ -319,10 +324,12 @@ def test_native_step_kept_splits_small_batch(n_layers, n_feats, n_hidden):
                     break
             out[mode] = (losses, eng.arena.params.clone())
     finally:
+        hip.tuning('h3_min_tiles', 0)
+        hip.tuning('h3_min_gflop', 0)
         hip.gemm_mode(prev)
-    la, lb = out['f32'][0], out['f16x3'][0]
+    la, lb = out['f32'][0], out[split][0]
     assert all(abs(a - b) <= TOL * max(1.0, abs(a)) for a, b in zip(la, lb)), (la, lb)
-    d = (out['f32'][1] - out['f16x3'][1]).abs()
+    d = (out['f32'][1] - out[split][1]).abs()
     assert d.mean().item() < 2e-5 and (d > TOL).float().mean().item() < 3e-2, \
         (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
 
@@ -615,7 +622,7 @@ def _metric_config_engine(mode, hidden=4096):
     eng = SageEngine(dims, True, 0.0, it.n_max, DEV)
     if hidden == 4096:
         big = _lib.load().gist_gemm_workspace_bytes(it.n_max, 4096, 8192)
-        assert (big > (1 << 27)) == (mode == 'f16x3')      # the step really runs on the split path
+        assert (big > (1 << 27)) == (mode != 'f32')        # the step really runs on the split path
     rs = np.random.RandomState(3)
     params = []
     for (i, o) in dims:
@@ -626,8 +633,8 @@ def _metric_config_engine(mode, hidden=4096):
     return ds, it, eng, dims, params
 
 
-@pytest.mark.parametrize('mode,hidden', [('f32', 4096), ('f16x3', 4096), ('f16x3', 2048),
-                                         ('f16x3', 1024)])
+@pytest.mark.parametrize('mode,hidden', [('f32', 4096), ('bf16x3', 4096), ('bf16x3', 2048),
+                                         ('f16x3', 4096), ('f16x3', 2048), ('f16x3', 1024)])
 def test_metric_config_hidden4096_vs_oracle(mode, hidden):
     """Metric configuration (and the per-rank widths of the 2- and 4-GPU points), 2 full training
     steps against the oracle on the same batches, with the projections on the fp32 matrix-core
@@ -642,7 +649,7 @@ def test_metric_config_hidden4096_vs_oracle(mode, hidden):
     try:
         ds, it, eng, dims, params = _metric_config_engine(mode, hidden)
         it.bind(eng)
-        if mode == 'f16x3':       # widths 2048 / 1024: layer 1 (and 0) keep their split operands
+        if mode != 'f32':         # layer 1 (and 0) keep their split operands
             assert eng.plan.h3_workspace is not None
         g = ds.g
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
@@ -695,7 +702,7 @@ def _float64_step(rowptr, col, feat, labels, params, masks):
     return loss.item(), y.detach(), [(W.grad, b.grad) for W, b in ps], yhats
 
 
-@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16x3'])
 def test_metric_config_hidden4096_vs_float64(mode):
     """Metric configuration, one forward/backward against float64 autograd on the same batch.
     Both GEMM modes must reproduce the float64 activations, logits, loss and every gradient to
@@ -735,8 +742,9 @@ def test_metric_config_hidden4096_vs_float64(mode):
         hip.gemm_mode(prev)
 
 
-def test_step_kept_split_operands_equal_per_call_splits(monkeypatch):
-    """Metric configuration, dropout 0.2, GEMM mode f16x3: the native step that keeps its own
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x3'])
+def test_step_kept_split_operands_equal_per_call_splits(monkeypatch, mode):
+    """Metric configuration, dropout 0.2, GEMM mode f16x3 / bf16x3: the native step that keeps its own
     split operands (dropout applied inside the activation split, one split of W per step,
     gradient maxima from the LayerNorm-backward / bias-gradient kernels) against the native
     step that splits inside every gist_gemm_* call (GIST_STEP_H3=0).  Same dropout stream, same
@@ -747,7 +755,7 @@ def test_step_kept_split_operands_equal_per_call_splits(monkeypatch):
         runs = {}
         for tag, env in (('per_call', '0'), ('kept', '1')):
             monkeypatch.setenv('GIST_STEP_H3', env)
-            ds, it, eng, dims, params = _metric_config_engine('f16x3')
+            ds, it, eng, dims, params = _metric_config_engine(mode)
             eng.p_drop = 0.2
             it.bind(eng)
             assert (eng.plan.h3_workspace is not None) == (tag == 'kept')
@@ -781,7 +789,7 @@ def test_wide_class_layer_stays_off_the_kept_split_path():
         runs = {}
         ds = datasets.make_block_dataset('wide-c', 8400, 4, 64, 256, intra_deg=6, inter_deg=2, seed=11)
         g = ds.g
-        for mode in ('f32', 'f16x3'):
+        for mode in ('f32', 'f16x3', 'bf16x3'):
             hip.gemm_mode(mode)
             random.seed(5)
             it = EngineClusterIter(ds.name, g, len(ds.par_li), 4,
@@ -795,7 +803,7 @@ def test_wide_class_layer_stays_off_the_kept_split_path():
                             for (i, o) in dims])
             # stale "row maxima" of another tensor would sit in the split workspace: poison it
             it.bind(eng)
-            if mode == 'f16x3':
+            if mode != 'f32':
                 assert eng.plan.h3_workspace is not None      # layer 1 keeps its split operands
                 eng._h3_ws.view(torch.float32).fill_(float('nan'))
             losses = []
@@ -805,12 +813,13 @@ def test_wide_class_layer_stays_off_the_kept_split_path():
                 if j == 1:
                     break
             runs[mode] = (losses, eng.arena.params.clone())
-        la, lb = runs['f32'][0], runs['f16x3'][0]
-        assert all(np.isfinite(lb)) and torch.isfinite(runs['f16x3'][1]).all()
-        assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
-        d = (runs['f32'][1] - runs['f16x3'][1]).abs()
-        assert d.mean().item() < 1e-5 and (d > TOL).float().mean().item() < 2e-2, \
-            (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+        for split in ('f16x3', 'bf16x3'):
+            la, lb = runs['f32'][0], runs[split][0]
+            assert all(np.isfinite(lb)) and torch.isfinite(runs[split][1]).all()
+            assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (split, la, lb)
+            d = (runs['f32'][1] - runs[split][1]).abs()
+            assert d.mean().item() < 1e-5 and (d > TOL).float().mean().item() < 2e-2, \
+                (split, d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
     finally:
         hip.gemm_mode(prev)
 
