@@ -295,9 +295,7 @@ def main():
         ist_model.ini_sync_dispatch_model()
         engine = ist_model.engine
         dims = ist_model.sub_dims
-    if second_leg:
-        hip.gemm_mode('f16x3')       # the f16x3 leg's kept-split workspace is sized at bind time
-    it.bind(engine)
+    it.bind(engine)                  # (the kept-split workspace is sized for either split mode)
     hip.gemm_mode(args.gemm_mode)
     lr = 0.01
     native = engine.plan is not None
@@ -506,6 +504,11 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # every rank runs `steps` iterations of its own sub-GCN: S * steps / 75 epochs of work
         value = world * args.steps / STEPS_PER_EPOCH / elapsed
+        # a split mode whose thresholds no projection of this run reached (small per-rank widths) IS the
+        # fp32-MFMA run: say so
+        eff_mode = args.gemm_mode
+        if prof is not None and args.gemm_mode != 'f32' and not prof['h3']:
+            eff_mode = 'f32'
         out = {
             'metric': 'epochs/sec', 'value': round(value, 4), 'unit': 'epochs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -515,7 +518,7 @@ def main():
                       'bf16x3': 'f32 (projection products from 3 bf16 pieces per operand = all 24 bits, 6 cross '
                                 'terms, fp32 accumulation)',
                       'f16x3': 'f32 (projection products as 3 f16-split MFMA terms = 22 bits, fp32 '
-                               'accumulation)'}[args.gemm_mode],
+                               'accumulation)'}[eff_mode],
             'arithmetic_note': {
                 'f32': 'fp32 storage, products and accumulation everywhere: every projection on '
                        'v_mfma_f32_32x32x2_f32',
@@ -529,7 +532,7 @@ def main():
                           '`f32_mfma`',
                 'f16x3': 'storage, accumulation and every non-GEMM kernel are fp32; the large projections '
                          'split each fp32 operand into two f16 halves (22 bits) and accumulate ah.bh + '
-                         'ah.bl + al.bh in fp32 -- narrower than fp32'}[args.gemm_mode],
+                         'ah.bl + al.bh in fp32 -- narrower than fp32'}[eff_mode],
             'data': 'synthetic',
             'config': {
                 'workload': 'Reddit-like synthetic (N_train=153431, F=602, C=41, 1500 parts, '
@@ -541,7 +544,8 @@ def main():
                                 'all-gather (cluster_gcn_ist_distrib.py path)'
                                 % (S, H // S, args.iter_per_site)),
                 'n_hidden': H, 'n_layers': L, 'num_subnet': S, 'batch_parts': batch_size,
-                'gemm_mode': args.gemm_mode,
+                'gemm_mode': args.gemm_mode if eff_mode == args.gemm_mode else
+                             '%s requested; no projection of this width reaches its thresholds: every GEMM on the fp32 MFMA' % args.gemm_mode,
                 'psize': psize, 'steps_per_epoch': STEPS_PER_EPOCH,
                 'epochs_per_sec_per_rank': round(value / world, 4),
             },
@@ -559,7 +563,7 @@ def main():
         if sync_info is not None:
             out['weight_sync'] = sync_info
         if prof is not None:
-            out['roofline'] = gemm_roofline(prof, elapsed_local, args.steps, args.gemm_mode)
+            out['roofline'] = gemm_roofline(prof, elapsed_local, args.steps, eff_mode)
             # in-batch edge counts of the timed batches: re-extract them now, outside the timing
             nnz = np.zeros(args.steps, np.int64)
             for i, ids in enumerate(timed_ids):

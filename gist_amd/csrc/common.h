@@ -86,8 +86,13 @@ struct B3Dual {                       // one read of src[rows, cols] -> up to tw
     bool vec4;                        // set by b3_dual_split: 16-byte loads allowed
 };
 int b3_dual_split(const B3Dual &d, hipStream_t st);
+int64_t b3_slab_bytes(int64_t m, int64_t n, int64_t k);   // fp32 slabs of a split-K call (0: one k slice)
 int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
-                     int64_t ldc, int64_t m, int64_t n, int64_t k, hipStream_t st);
+                     int64_t ldc, int64_t m, int64_t n, int64_t k, float *slabs, int64_t slab_bytes,
+                     hipStream_t st);
+// gemm.hip: c[m, n] (ldc) = sum of `splits` dense slabs [m][n] + bias
+int splitk_reduce(const char *name, const float *slabs, int64_t slab, int splits, const float *bias, float *c,
+                  int64_t ldc, int64_t m, int64_t n, hipStream_t st);
 
 // rowops.hip: the C-ABI kernels with the extra outputs the split projection path consumes
 int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,

@@ -584,6 +584,15 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int64_t slab,
     c[(int64_t)rr * ldc + cc] = s;
 }
 
+int splitk_reduce(const char *name, const float *slabs, int64_t slab, int splits, const float *bias, float *c,
+                  int64_t ldc, int64_t m, int64_t n, hipStream_t st) {
+    const int64_t total = m * n;
+    if (total <= 0) return GIST_OK;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, slabs,
+                       slab, splits, bias, c, ldc, (int)m, (int)n);
+    return launch_status(name);
+}
+
 // ---- tile / split-K choice ---------------------------------------------------------------
 // Everything here is fp32 MFMA work, so time ~ MFMA work of the busiest SIMD.  A block is 4
 // waves (one per SIMD of a CU); blocks are dealt round-robin to 256 CUs, a CU keeps up to

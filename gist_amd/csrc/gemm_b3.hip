@@ -158,6 +158,8 @@ struct B3Args {
     float *c; int64_t ldc;
     int m, n, kpad;
     int tiles_m, tiles_n;
+    int kt_per_split;                    // k tiles per blockIdx.y (even); split s writes c + s * split_stride
+    int64_t split_stride;
 };
 
 // DMA instruction `inst` of an image: slot L = 64 (inst % 3) + lane of 16-row slab inst / 3; slot
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     const int bm = first_m + (L % width) % gsz;
     const int bn = (L % width) / gsz;
     const int row0 = bm * B3_TM, col0 = bn * B3_TN;
-    const int n_kt = g.kpad / B3_BK;
+    const int kt0 = (int)blockIdx.y * g.kt_per_split;                   // split-K: this workgroup's k tiles
+    const int n_kt = min(g.kpad / B3_BK - kt0, g.kt_per_split);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     uint32_t offA[DA], offB[DB];
     b3_dma_offsets<DA>(g.lda, g.m, row0, DA * wave, lane, offA);
     b3_dma_offsets<DB>(g.ldb, g.n, col0, DB * wave, lane, offB);
-    const char *originA = reinterpret_cast<const char *>(g.a) + (int64_t)row0 * g.lda * 6;
-    const char *originB = reinterpret_cast<const char *>(g.b) + (int64_t)col0 * g.ldb * 6;
+    const char *originA = reinterpret_cast<const char *>(g.a) + (int64_t)row0 * g.lda * 6 + (int64_t)kt0 * B3_KT_BYTES;
+    const char *originB = reinterpret_cast<const char *>(g.b) + (int64_t)col0 * g.ldb * 6 + (int64_t)kt0 * B3_KT_BYTES;
     auto dma = [&](int buf, int kt) {
         char *sa = b3_smem + buf * B3_BUF_BYTES;
         b3_dma_image<DA>(originA + (int64_t)kt * B3_KT_BYTES, offA, sa, DA * wave);
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     // before the accumulators are read (4 passes + write-back)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
-    float *cbase = g.c + (int64_t)row0 * g.ldc + col0;
+    float *cbase = g.c + (int64_t)blockIdx.y * g.split_stride + (int64_t)row0 * g.ldc + col0;
     const int rows_valid = min(g.m - row0, B3_TM);
     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
         cbase, 0, (int)((int64_t)rows_valid * g.ldc * 4), 0x00020000);
@@ -401,18 +404,40 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
 // ---- host side ------------------------------------------------------------------------------------
 int64_t b3_kpad(int64_t k) { return ceil_div(k, 2 * B3_BK) * (2 * B3_BK); }      // an even number of k tiles
 
-// Shapes the bf16x3 path takes: enough 128 x 64 tiles to occupy the chip, and enough flops to pay for
-// the pre-pass (~ the f16x3 path's thresholds).  Everything else stays on the fp32 kernel.
+// Split-K: an output with fewer than ~3/4 of 256 tiles leaves CUs idle (one 512-thread workgroup per
+// CU), so its k range is cut into `splits` slices, one workgroup each (blockIdx.y), which write fp32
+// slabs that one pass sums (+ bias).  A slice keeps >= 8 k tiles; slices are an even number of tiles.
+int b3_splits(int64_t m, int64_t n, int64_t k) {
+    const int64_t tiles = ceil_div(m, B3_TM) * ceil_div(n, B3_TN);
+    const int64_t n_kt = b3_kpad(k) / B3_BK;
+    const int forced = (int)tune(GIST_TUNE_GEMM_SPLITS);
+    int64_t s = forced > 0 ? forced : (tiles >= 192 ? 1 : 256 / tiles);
+    if (forced <= 0 && s > n_kt / 8) s = n_kt / 8;
+    if (s > n_kt / 2) s = n_kt / 2;
+    if (s < 1) s = 1;
+    const int64_t per = ceil_div(ceil_div(n_kt, s), 2) * 2;
+    return (int)ceil_div(n_kt, per);
+}
+int64_t b3_slab_bytes(int64_t m, int64_t n, int64_t k) {
+    const int s = b3_splits(m, n, k);
+    return s > 1 ? (int64_t)s * m * n * 4 : 0;
+}
+
+// Shapes the bf16x3 path takes: enough workgroups (256 x 128 tiles x k slices) to occupy the chip, and
+// enough flops to pay for the pre-pass (~ the f16x3 path's thresholds).  Everything else stays on the
+// fp32 kernel.
 static bool b3_shape_ok(int64_t m, int64_t n, int64_t k, double default_min_gflop) {
     if (h3_mode() != 2) return false;
     const double t_gflop = tune(GIST_TUNE_H3_MIN_GFLOP), t_tiles = tune(GIST_TUNE_H3_MIN_TILES);
     const double min_gflop = t_gflop > 0.0 ? t_gflop : default_min_gflop;
-    const int min_tiles = t_tiles > 0.0 ? (int)t_tiles : 128;      // of 256 x 128
+    const int min_wgs = t_tiles > 0.0 ? (int)t_tiles : 128;
     // (an explicit tile threshold -- tests -- also lifts the minimum extents: the kernel itself
     // handles any m, n, k >= 1)
     if (t_tiles <= 0.0 && (m < 64 || n < 64 || k < 64)) return false;
     if (m < 1 || n < 1 || k < 1) return false;
-    if (ceil_div(m, B3_TM) * ceil_div(n, B3_TN) < min_tiles) return false;
+    const int64_t tiles = ceil_div(m, B3_TM) * ceil_div(n, B3_TN);
+    if (tiles * b3_splits(m, n, k) < min_wgs) return false;
+    if (t_tiles <= 0.0 && (double)m * (double)n < 0.6 * (double)(tiles * B3_TM * B3_TN)) return false;   // mostly padding
     if (2.0 * (double)m * (double)n * (double)k < min_gflop * 1e9) return false;
     if (b3_kpad(k) * 6 >= (1LL << 23)) return false;          // 32-bit DMA byte offsets: 256 rows * pitch
     return true;
@@ -420,9 +445,12 @@ static bool b3_shape_ok(int64_t m, int64_t n, int64_t k, double default_min_gflo
 bool b3_eligible(int64_t m, int64_t n, int64_t k) { return b3_shape_ok(m, n, k, 16.0); }
 bool b3_eligible_kept(int64_t m, int64_t n, int64_t k) { return b3_shape_ok(m, n, k, 4.0); }
 
+static int64_t b3_operand_bytes(int64_t m, int64_t n, int64_t k) {
+    return ceil_div((m + n) * b3_kpad(k) * 6 + 512, 256) * 256;
+}
 int64_t b3_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (!b3_eligible(m, n, k)) return 0;
-    return (m + n) * b3_kpad(k) * 6 + 512;
+    return b3_operand_bytes(m, n, k) + b3_slab_bytes(m, n, k);
 }
 
 int b3_dual_split(const B3Dual &d, hipStream_t st) {
@@ -437,7 +465,8 @@ int b3_dual_split(const B3Dual &d, hipStream_t st) {
 }
 
 int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
-                     int64_t ldc, int64_t m, int64_t n, int64_t k, hipStream_t st) {
+                     int64_t ldc, int64_t m, int64_t n, int64_t k, float *slabs, int64_t slab_bytes,
+                     hipStream_t st) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
@@ -455,11 +484,20 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
     g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
     g.tiles_m = (int)ceil_div(m, B3_TM);
     g.tiles_n = (int)ceil_div(n, B3_TN);
-    const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel alone
-    hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(B3_THREADS),
-                       B3_STAGES * B3_BUF_BYTES, st, g);
+    const int64_t n_kt = kpad / B3_BK;
+    int splits = b3_splits(m, n, k);
+    if (splits > 1 && (slabs == nullptr || slab_bytes < (int64_t)splits * m * n * 4)) splits = 1;
+    g.kt_per_split = (int)(ceil_div(ceil_div(n_kt, splits), 2) * 2);
+    splits = (int)ceil_div(n_kt, g.kt_per_split);
+    g.split_stride = 0;
+    if (splits > 1) { g.c = slabs; g.ldc = n; g.split_stride = m * n; g.bias = nullptr; }
+    const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel (+ slab sum)
+    hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits),
+                       dim3(B3_THREADS), B3_STAGES * B3_BUF_BYTES, st, g);
+    int rc = launch_status(name);
+    if (rc == GIST_OK && splits > 1) rc = splitk_reduce(name, slabs, m * n, splits, bias, c, ldc, m, n, st);
     timer_end(tl_timer, slot, st);
-    return launch_status(name);
+    return rc;
 }
 
 // A: a_kc ? [m][k] : [k][m];  B: b_kc ? [n][k] : [k][n].  Returns 1 if the GEMM was issued,
@@ -472,6 +510,7 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
     const int64_t kpad = b3_kpad(k);
     uint16_t *sa = static_cast<uint16_t *>(ws);
     uint16_t *sb = sa + m * kpad * 3;
+    float *slabs = reinterpret_cast<float *>(static_cast<char *>(ws) + b3_operand_bytes(m, n, k));
     auto split = [&](bool kc, const float *src, int64_t ld, int64_t rows, uint16_t *dst) {
         B3Dual d{};
         d.src = src; d.ld = ld;
@@ -483,7 +522,7 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
     if (rc != GIST_OK) return rc;
     rc = split(b_kc, b, ldb, n, sb);
     if (rc != GIST_OK) return rc;
-    rc = b3_gemm_presplit(name, sa, sb, bias, c, ldc, m, n, k, st);
+    rc = b3_gemm_presplit(name, sa, sb, bias, c, ldc, m, n, k, slabs, b3_slab_bytes(m, n, k), st);
     return rc == GIST_OK ? 1 : rc;
 }
 

@@ -189,6 +189,7 @@ struct B3Step {
     bool any;
     B3Layer layer[GIST_MAX_LAYERS];
     uint16_t *dYs, *dYsT;          // [n][kpad(out)], [out][kpad(n)] (shared by the layers)
+    float *slabs; int64_t slab_bytes;     // split-K slabs of the layers' projections (shared)
     int64_t bytes;
 };
 
@@ -217,10 +218,17 @@ B3Step b3_layout(const gist_step_plan *p, char *base) {
         hl.Ws = take(o * b3_kpad(i2) * 6);
         hl.WsT = k > 0 ? take(i2 * b3_kpad(o) * 6) : nullptr;
         max_out = o > max_out ? o : max_out;
+        // (slice counts depend on the batch rows only through the tile count: sized at n_max, the
+        // launcher falls back to one slice if a smaller batch would need more slab than this)
+        int64_t sb = b3_slab_bytes(n, o, i2);
+        if (b3_slab_bytes(o, i2, n) > sb) sb = b3_slab_bytes(o, i2, n);
+        if (k > 0 && b3_slab_bytes(n, i2, o) > sb) sb = b3_slab_bytes(n, i2, o);
+        if (sb > h.slab_bytes) h.slab_bytes = sb;
     }
     if (!h.any) return h;
     h.dYs = take(n * b3_kpad(max_out) * 6);
     h.dYsT = take(max_out * b3_kpad(n) * 6);
+    h.slabs = h.slab_bytes > 0 ? reinterpret_cast<float *>(take(h.slab_bytes)) : nullptr;
     h.bytes = off;
     return h;
 }
@@ -353,7 +361,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             GIST_TRY(b3_dual_split(d, st));
             if (drop) off += round_up2((uint64_t)n * 2 * l.n_in);
             GIST_TRY(b3_gemm_presplit("gist_sage_step", hl.Zs, hl.Ws, l.b, l.Y, l.ldy, n, l.n_out,
-                                      2 * l.n_in, st));
+                                      2 * l.n_in, b3.slabs, b3.slab_bytes, st));
         } else {
             if (drop) {
                 GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, off, s));
@@ -440,12 +448,12 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             if (k > 0) {
                 Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
                 GIST_TRY(b3_gemm_presplit("gist_sage_step", b3.dYs, hl.WsT, nullptr, p->dZ, 2 * l.n_in, n,
-                                          2 * l.n_in, l.n_out, st));
+                                          2 * l.n_in, l.n_out, b3.slabs, b3.slab_bytes, st));
             }
             {
                 Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
                 GIST_TRY(b3_gemm_presplit("gist_sage_step", b3.dYsT, hl.ZsT, nullptr, l.dW, 2 * l.n_in,
-                                          l.n_out, 2 * l.n_in, n, st));
+                                          l.n_out, 2 * l.n_in, n, b3.slabs, b3.slab_bytes, st));
             }
             if (k > 0) {
                 if (drop)

@@ -233,7 +233,16 @@ class SageEngine(object):
         # (it re-reads the bound) if the features are re-normalised or replaced.
         P.feat_absmax = float(batcher.feat.abs().max().item()) if batcher.feat.numel() else 0.0
         import ctypes
-        need = _lib.load().gist_step_h3_workspace_bytes(ctypes.byref(P))
+        # (sized for the larger of the two split modes, so the GEMM mode may be switched after bind)
+        L_ = _lib.load()
+        cur = L_.gist_gemm_get_mode()
+        need = 0
+        try:
+            for m_ in ((1, 2) if cur != 0 else ()):
+                _lib.check(L_.gist_gemm_set_mode(m_), 'gist_gemm_set_mode')
+                need = max(need, L_.gist_step_h3_workspace_bytes(ctypes.byref(P)))
+        finally:
+            _lib.check(L_.gist_gemm_set_mode(cur), 'gist_gemm_set_mode')
         self._h3_ws = None
         if need > 0 and os.environ.get('GIST_STEP_H3', '1') != '0':
             self._h3_ws = torch.empty(need, dtype=torch.uint8, device=self.device)

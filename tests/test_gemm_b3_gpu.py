@@ -197,6 +197,42 @@ def test_mode_switch(hip):
     hip.gemm_mode('bf16x3')
     assert hip.gemm_mode() == 'bf16x3'
     assert L.gist_gemm_workspace_bytes(2046, 4096, 8192) >= (2046 + 4096) * 8192 * 6
-    small = L.gist_gemm_workspace_bytes(2046, 41, 8192)
-    hip.gemm_mode('f32')
-    assert L.gist_gemm_workspace_bytes(2046, 41, 8192) == small      # skinny: fp32 split-K either way
+    hip.tuning('h3_min_tiles', 0)         # production thresholds: a skinny output is mostly tile padding
+    try:
+        small = L.gist_gemm_workspace_bytes(2046, 41, 8192)
+        wide = L.gist_gemm_workspace_bytes(2046, 2048, 4096)
+        hip.gemm_mode('f32')
+        assert L.gist_gemm_workspace_bytes(2046, 41, 8192) == small      # fp32 split-K either way
+        assert wide >= (2046 + 2048) * 4096 * 6 + 2 * 2046 * 2048 * 4    # 128 tiles: two k slices + slabs
+    finally:
+        hip.tuning('h3_min_tiles', 16)
+
+
+@pytest.mark.parametrize('form,m,n,k', [('nt', 2046, 2048, 4096), ('nt', 2046, 2048, 1204),
+                                        ('tn', 2048, 1204, 2046), ('nn', 700, 640, 3000)])
+def test_bf16x3_split_k_equals_one_slice(hip, form, m, n, k):
+    """Outputs with few 256 x 128 tiles are computed as k slices (one workgroup each) summed from
+    fp32 slabs: same result as the single-slice kernel up to the order of the fp32 partial sums,
+    bias added exactly once, uneven slice lengths (1204 -> 38 k tiles = 20 + 18) included."""
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(5 * m + n + k)
+    a, w = _operands(form, m, n, k, gen, 'normal')
+    bias = torch.randn(n, device=DEV, generator=gen) if form == 'nt' else None
+    from gist_amd import _lib
+    L = _lib.load()
+    assert L.gist_gemm_workspace_bytes(m, n, k) >= (m + n) * k * 6 + 2 * m * n * 4, 'not a split-K shape'
+    y_auto = _run(hip, form, a, w, bias, m, n)
+    hip.tuning('gemm_splits', 1)
+    try:
+        y_one = _run(hip, form, a, w, bias, m, n)
+    finally:
+        hip.tuning('gemm_splits', 0)
+    rows = torch.arange(0, m, max(1, m // 128), device=DEV)
+    ref, den = _ref64(form, a, w, rows)
+    if bias is not None:
+        ref = ref + bias.double()
+    assert torch.isfinite(y_auto).all()
+    e_auto = ((y_auto[rows].double() - ref).abs() / den).max().item()
+    e_one = ((y_one[rows].double() - ref).abs() / den).max().item()
+    assert e_auto <= max(1.5 * e_one, 4e-7), (e_auto, e_one)
+    assert (y_auto - y_one).abs().max().item() <= 4e-6 * den.max().item()

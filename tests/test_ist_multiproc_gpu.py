@@ -69,7 +69,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['steps'] == 6
-    assert out['config']['num_subnet'] == 2 and out['dtype'] == 'f32'
+    assert out['config']['num_subnet'] == 2 and out['dtype'] == 'f32'      # width 128 per rank: fp32 MFMA
     assert len(out['per_rank_ms_per_step']) == 2 and all(t > 0 for t in out['per_rank_ms_per_step'])
     assert abs(out['value'] - 2 * 6 / 75.0 / (out['ms_per_step'] * 6e-3)) < 1e-3 * out['value']
     ws = out['weight_sync']
