@@ -52,6 +52,9 @@ typedef float b3_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int B3_TM = 256, B3_TN = 128, B3_BK = 32;
 constexpr int B3_THREADS = 512;
 constexpr int B3_STAGES = 2;
+#ifndef B3_SKEW
+#define B3_SKEW 16               // MFMAs by which waves 4-7 run behind waves 0-3 inside a k step
+#endif
 #ifndef B3_DMA_AFTER
 #define B3_DMA_AFTER 16        // MFMAs of a k step issued before the next tile's DMA
 #endif
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     const int last_kt = n_kt - 1;
     auto kstep = [&](auto cur_c, auto late_c, int kt) {
         constexpr int cur = decltype(cur_c)::value;
-        constexpr int skew = decltype(late_c)::value * NI * NJ;
+        constexpr int skew = decltype(late_c)::value * B3_SKEW;
         using I = std::integral_constant<int, 0>;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -357,8 +360,11 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
 #ifdef B3_CLOCK_PROBE
     const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifndef B3_NO_SKEW
     if (wave >= 4) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 0>{});
+    else
+#endif
+        run(std::integral_constant<int, 0>{});
 #ifdef B3_CLOCK_PROBE
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_b3_clock[2 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - ck0;

@@ -776,9 +776,18 @@ extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *c
         return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                                  accumulate, stream);
     hipStream_t st = as_stream(stream);
-    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
+    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y)) {
+        // wide rows: the block-dense matrix-core kernel (spmm_mfma.hip), whose per-workgroup set-up
+        // (the block's counts, ~11 us) pays from two 128-column tiles per workgroup on -- measured on
+        // the Reddit-like batch: D = 4096 38 vs 57 us, 2048 29 vs 33, 1024 21 vs 16, 512 20 vs 12.
+        // Tuning hook: 1 = always the LDS gather kernel, 2 = always the matrix-core kernel.
+        const int want = (int)tune(GIST_TUNE_SPMM_KERNEL);
+        if (want == 2 || (want != 1 && d >= 1536))
+            return launch_spmm_mfma(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                    accumulate, row_blocks, n_row_blocks, st);
         return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                                 accumulate, row_blocks, n_row_blocks, st);
+    }
     // other widths / alignments (the layer-0 aggregation of F = 602 features): the row-split kernel
     return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                              accumulate, stream);

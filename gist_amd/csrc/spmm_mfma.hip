@@ -1,0 +1,498 @@
+// Block-dense aggregation on the matrix cores: gist_spmm_csr_blocked_f32 for wide rows.
+//
+// A cluster batch is a union of METIS parts, and inside a part the adjacency is close to DENSE: on the
+// Reddit-like batch of the metric (2046 rows = 20 parts of ~102 rows, 63 in-batch neighbours per row)
+// 99.1 % of the edges stay inside the row's own part, i.e. the part's diagonal block of A holds
+// 63 / 102 = 62 % non-zeros.  Gathering those neighbours one by one (the LDS-staged kernel in
+// spmm.hip) moves nnz x D x 4 bytes through the LDS read port and is bound by its latency (51 us at
+// D = 4096, 0.14 of the HBM roofline).  Here the diagonal block is what it looks like, a small dense
+// matrix:
+//     Y_p[rows, D] = C_p[rows, rows] . X_p[rows, D]  +  (the few neighbours outside the part)
+// with C_p the block's edge COUNTS (a multigraph: an edge listed twice counts twice), on
+// v_mfma_f32_16x16x32_bf16.  It is exact fp32 aggregation, not a reduced-precision one: a count
+// <= 256 is exact in bf16, every fp32 x is carried as three bf16 pieces x = x1 + x2 + x3 (3 x 8 =
+// all 24 significant bits, fp32's exponent range), each count x piece product is exact, and the
+// accumulation is fp32 -- the same arithmetic as summing the neighbours one after the other, in
+// another (fixed) order.  Results do not depend on block boundaries or placement.
+//
+// One 1024-thread workgroup per (part, group of 128-column tiles):
+//   once:   the block's counts -> LDS, [k chunk][row][8 k] bf16: one flat pass over the block's edges
+//           (all loads of a thread in flight, row of an edge by binary search in the row pointers,
+//           LDS atomics on 16-bit counters), converted in place; per row the ids of its neighbours
+//           outside the block (up to 8, restored to CSR order; a row with more of them, with a count
+//           > 256, or beyond the 128 rows a block may stage is gathered from memory in full instead:
+//           hubs, oversized blocks)
+//   tile:   X_p tile [rows x 128] -> registers (4 x 16-byte loads per thread, issued one tile ahead,
+//           branch-free) -> x src_scale -> three bf16 pieces -> LDS as X^T, [k chunk][column & 3]
+//           [column >> 2][8 k]: both MFMA operands are then one conflict-free ds_read_b128 per lane
+//           8 x 8 MFMA tiles x 4 k steps x 3 pieces, 4 output tiles per wave
+//           accumulators -> LDS (fp32, over the X^T image) -> registers, two rows per wave pass ->
+//           barrier -> + outside neighbours (global loads, CSR order) -> x out_scale (+ y) -> 512-byte
+//           row stores, which run under the next tile's conversion
+// The barriers wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also
+// waits for vmcnt(0), i.e. for the prefetched tile.
+//
+// Measured (scripts/spmm_mf_probe.py under rocprofv3, scripts/spmm_mf_phases.py; Reddit-like batch,
+// 20 blocks x 12 column groups = 240 workgroups at D = 4096): 38 us against 57 us for the LDS gather
+// kernel (29 vs 33 at D = 2048; below that the set-up does not pay and the dispatcher keeps the gather
+// kernel).  Phases of a workgroup: set-up 11 us (row pointers 1, counts 7, conversion 3), then per tile
+// ~8 us = conversion 2.5 (VALU-bound: 16 waves x ~250 instructions) + MFMA 1 + barriers 2 + result
+// tile 0.5 + stores 2 (the chip's 256 workgroups store in step: 9 TB/s bursts).  One workgroup per CU
+// (136 KiB of LDS) cannot overlap those phases; the HBM floor of the call is 15 us.
+#include "common.h"
+
+namespace gist {
+
+typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MF_ROWS = 128;                       // rows of a block staged = k extent of the product
+constexpr int MF_CT = 128;                         // columns per tile
+constexpr int MF_THREADS = 1024;
+constexpr int MF_WAVES = MF_THREADS / 64;
+// one bf16 piece of X^T: [k chunk 16][column & 3][column >> 2 (32, padded to 36)][8 k] -- a thread
+// stages four ADJACENT columns (one 16-byte load per row), and with this order the 32 lanes of a
+// half wave write consecutive 16-byte slots while the 16 lanes of a fragment read (columns n .. n+15
+// -> slots 36 (n & 3) + (n >> 2)) still hit 16 different bank quads
+constexpr int MF_CHUNK_SLOTS = 4 * 36;
+constexpr int MF_PIECE = 16 * MF_CHUNK_SLOTS * 16;
+constexpr int MF_YT_PITCH = 132;                   // floats; the fp32 result tile aliases the X^T image
+constexpr int MF_REM = 8;                          // outside neighbours listed per row
+constexpr int MF_A_OFF = 3 * MF_PIECE;             // counts, [k chunk 16][row 128][8 k] bf16
+constexpr int MF_RP_OFF = MF_A_OFF + 16 * MF_ROWS * 16;          // int rowptr[132]
+constexpr int MF_REMC_OFF = MF_RP_OFF + 132 * 4;                 // int rem_cnt[128]  (-1: gather the whole row)
+constexpr int MF_REM_OFF = MF_REMC_OFF + MF_ROWS * 4;            // int rem_col[128][8]
+constexpr int MF_REME_OFF = MF_REM_OFF + MF_ROWS * MF_REM * 4;   // their edge indices (to restore CSR order)
+constexpr int MF_SC_OFF = MF_REME_OFF + MF_ROWS * MF_REM * 4;    // float out_scale[128]
+constexpr int MF_BIG_OFF = MF_SC_OFF + MF_ROWS * 4;              // int big_row[128]: a count > 256
+constexpr int MF_LDS_BYTES = MF_BIG_OFF + MF_ROWS * 4;
+static_assert(MF_ROWS * MF_YT_PITCH * 4 <= 3 * MF_PIECE, "result tile fits the X^T image");
+static_assert(MF_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+
+struct MfArgs {
+    const int32_t *rowptr, *col;
+    const float *x; int64_t ldx;
+    float *y; int64_t ldy;
+    int n_rows, d;
+    const float *out_scale, *src_scale;
+    int accumulate;
+    const int32_t *row_blocks;
+    int n_blocks, n_col_tiles, groups;
+};
+
+__device__ __forceinline__ uint32_t mf_pack(__bf16 lo, __bf16 hi) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, lo) |
+           ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only: the global loads of the next tile stay
+// in flight across it (__syncthreads() waits for vmcnt(0) as well, i.e. for every prefetch).
+__device__ __forceinline__ void mf_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// v += sum over the listed source rows (ids in lanes 0 .. cnt-1 of `ids`) of scale . x[id][gc .. gc+3],
+// in list order, for the lanes with `mine`; 4 row reads in flight
+__device__ __forceinline__ void mf_gather(const float *x, int64_t ldx, const float *src_scale, int gc,
+                                          bool mine, int ids, int cnt, float4 &v) {
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+        float4 rv[4];
+        float rs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool on = j0 + t < cnt;                          // wave-uniform
+            const int g = __builtin_amdgcn_readlane(ids, (j0 + t) & 63);
+            rs[t] = 0.f;
+            rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on) {
+                rs[t] = src_scale ? src_scale[g] : 1.f;
+                if (mine) rv[t] = *reinterpret_cast<const float4 *>(x + (int64_t)g * ldx + gc);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v.x = fmaf(rs[t], rv[t].x, v.x); v.y = fmaf(rs[t], rv[t].y, v.y);
+            v.z = fmaf(rs[t], rv[t].z, v.z); v.w = fmaf(rs[t], rv[t].w, v.w);
+        }
+    }
+}
+
+// every neighbour of one row, CSR order
+__device__ __forceinline__ void mf_gather_row(const MfArgs &a, int e0, int e1, int lane, int gc, bool mine,
+                                              float4 &v) {
+    for (int base = e0; base < e1; base += 64) {
+        const int ids = base + lane < e1 ? a.col[base + lane] : 0;
+        mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, min(64, e1 - base), v);
+    }
+}
+
+#ifdef MF_PROBE      // dev build (scripts/spmm_mf_phases.py): s_memrealtime (100 MHz) stamps of workgroup 0, wave 0
+__device__ unsigned long long g_mf_probe[64];
+#define MF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mf_probe[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MF_STAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    MF_STAMP(0);
+    // ---- workgroup -> (block, column group); the groups of one block stay on one XCD ----
+    const int total = a.n_blocks * a.groups;
+    const int per_xcd = (total + kXcds - 1) / kXcds;
+    const int unit = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    if (unit >= total) return;
+    const int grp = unit % a.groups;
+    const int rbk = unit / a.groups;
+    int r0, r1;
+    if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
+    else { r0 = rbk * MF_ROWS; r1 = r0 + MF_ROWS; }
+    r1 = min(r1, a.n_rows);
+    const int nrow = r1 - r0;
+    if (nrow <= 0) return;
+    const int nloc = min(nrow, MF_ROWS);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, cq = lane & 31;
+
+    unsigned char *xt = mf_smem;
+    float *yt = reinterpret_cast<float *>(mf_smem);
+    unsigned char *ab = mf_smem + MF_A_OFF;
+    uint32_t *a32 = reinterpret_cast<uint32_t *>(ab);
+    int32_t *rp = reinterpret_cast<int32_t *>(mf_smem + MF_RP_OFF);
+    int32_t *rem_cnt = reinterpret_cast<int32_t *>(mf_smem + MF_REMC_OFF);
+    int32_t *rem_col = reinterpret_cast<int32_t *>(mf_smem + MF_REM_OFF);
+    int32_t *rem_e = reinterpret_cast<int32_t *>(mf_smem + MF_REME_OFF);
+    float *sc = reinterpret_cast<float *>(mf_smem + MF_SC_OFF);
+    int32_t *big_row = reinterpret_cast<int32_t *>(mf_smem + MF_BIG_OFF);
+
+    // ---- once per workgroup: the block's edge counts and its outside neighbours ----
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(ab + tid * 32);
+        z[0] = make_uint4(0, 0, 0, 0);
+        z[1] = make_uint4(0, 0, 0, 0);
+        if (tid <= nloc) rp[tid] = a.rowptr[r0 + tid];
+        if (tid < MF_ROWS) {
+            sc[tid] = (tid < nloc && a.out_scale) ? a.out_scale[r0 + tid] : 1.f;
+            rem_cnt[tid] = 0;
+            big_row[tid] = 0;
+        }
+    }
+    mf_barrier();
+    MF_STAMP(1);
+
+    // staging role of this thread: rows 8 wave + 4 half + i, columns 4 cq .. 4 cq + 3 of the tile
+    const int srow = 8 * wave + 4 * half;
+    float ss[4];
+    float4 xv[4];
+    int ct = grp;
+    // (branch-free: a predicated load compiles to an exec-mask branch and a conservative s_waitcnt
+    // vmcnt(0) at its join, which serialises the loads -- clamp the address, select when the value is used)
+    auto load_tile = [&](int t) {
+        const bool cok = t * MF_CT + 4 * cq < a.d;
+        const float *px = a.x + (int64_t)r0 * a.ldx + (cok ? t * MF_CT + 4 * cq : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, nloc - 1) * a.ldx);
+    };
+    {   // every edge of the block, 1024 at a time, the loads of a thread in flight together (and BEFORE
+        // the first X tile's: loads return in order); the row of an edge by binary search in the block's
+        // row pointers (LDS)
+        const int E0 = rp[0], E1 = rp[nloc];
+        bool first = true;
+        for (int base = E0; base < E1 || first; base += 8 * MF_THREADS) {
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = -1;
+            if (E1 > E0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = a.col[min(base + u * MF_THREADS + tid, E1 - 1)];
+            }
+            if (first) {
+                first = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss[i] = a.src_scale ? a.src_scale[r0 + min(srow + i, nloc - 1)] : 1.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss[i] = srow + i < nloc ? ss[i] : 0.f;
+                if (ct < a.n_col_tiles) load_tile(ct);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = base + u * MF_THREADS + tid < E1 ? c[u] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * MF_THREADS + tid;
+                if (c[u] < 0) continue;
+                int lo = 0, hi = nloc;                     // rp[lo] <= e < rp[hi]
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool up = mid > lo && rp[mid] <= e;
+                    hi = (!up && mid > lo) ? mid : hi;
+                    lo = up ? mid : lo;
+                }
+                const int r = lo;
+                const int k = c[u] - r0;
+                if (k >= 0 && k < nloc) {
+                    atomicAdd(&a32[((k >> 3) * MF_ROWS + r) * 4 + ((k & 7) >> 1)], (k & 1) ? 0x10000u : 1u);
+                } else {
+                    const int slot = atomicAdd(&rem_cnt[r], 1);
+                    if (slot < MF_REM) { rem_e[r * MF_REM + slot] = e; rem_col[r * MF_REM + slot] = c[u]; }
+                }
+            }
+        }
+    }
+    mf_barrier();
+    MF_STAMP(2);
+    // outside neighbours of a row back into CSR order (the slots were taken in arrival order); a row
+    // with more than fit is gathered in full below
+    if (tid < nloc) {
+        const int cnt = rem_cnt[tid];
+        if (cnt > MF_REM) {
+            rem_cnt[tid] = -1;
+        } else {
+            for (int i = 1; i < cnt; ++i) {
+                const int e = rem_e[tid * MF_REM + i], c = rem_col[tid * MF_REM + i];
+                int j = i - 1;
+                while (j >= 0 && rem_e[tid * MF_REM + j] > e) {
+                    rem_e[tid * MF_REM + j + 1] = rem_e[tid * MF_REM + j];
+                    rem_col[tid * MF_REM + j + 1] = rem_col[tid * MF_REM + j];
+                    --j;
+                }
+                rem_e[tid * MF_REM + j + 1] = e;
+                rem_col[tid * MF_REM + j + 1] = c;
+            }
+        }
+    }
+    constexpr int RW = MF_ROWS / MF_WAVES;                 // rows a wave converts / finishes: wave + 16 i
+    // counts -> bf16 in place; a row with a count > 256 (not exact in bf16) leaves the dense product
+    // (zero row) and is gathered in full as well
+    {
+        uint32_t v[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) v[i] = a32[((lane >> 2) * MF_ROWS + wave + MF_WAVES * i) * 4 + (lane & 3)];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const uint32_t c0 = v[i] & 0xffffu, c1 = v[i] >> 16;
+            const bool big = __ballot(c0 > 256u || c1 > 256u) != 0ULL;
+            if (big && lane == 0) big_row[wave + MF_WAVES * i] = 1;
+            a32[((lane >> 2) * MF_ROWS + wave + MF_WAVES * i) * 4 + (lane & 3)] =
+                mf_pack((__bf16)(float)c0, (__bf16)(float)c1);
+        }
+    }
+    mf_barrier();
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int r = wave + MF_WAVES * i;
+        if (r < nloc && (rem_cnt[r] < 0 || big_row[r])) {             // wave-uniform
+            a32[((lane >> 2) * MF_ROWS + r) * 4 + (lane & 3)] = 0u;
+            if (lane == 0) rem_cnt[r] = -1;
+        }
+    }
+    mf_barrier();
+    MF_STAMP(3);
+
+    const int rr = lane & 15, kg = lane >> 4;
+    const int mt0 = (wave >> 2) * 2, nt0 = (wave & 3) * 2;
+    const int n_ks = (nloc + 31) >> 5;
+    const bool m_on = mt0 * 16 < nloc, m_two = (mt0 + 1) * 16 < nloc;
+    // B fragment slots of this lane's two output column tiles
+    int bslot[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = (nt0 + ni) * 16 + rr;
+        bslot[ni] = ((n & 3) * 36 + (n >> 2)) * 16;
+    }
+    // the rows this wave finishes: pairs (one per half wave), row = wave + 16 (2 p + half)
+    int rcnt[RW];
+    float rsc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int r = wave + MF_WAVES * i;
+        rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
+        rsc[i] = r < nloc ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc[r]))) : 0.f;
+    }
+    int mf_it = 0;
+    for (; ct < a.n_col_tiles; ct += a.groups, ++mf_it) {
+        MF_STAMP(8 + 8 * mf_it);
+        // ---- X tile -> x src_scale -> three bf16 pieces -> X^T image ----
+        {
+            __bf16 p[4][4][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = srow + i < nloc && ct * MF_CT + 4 * cq < a.d;      // (clamped loads: select here)
+                const float xs[4] = {ok ? xv[i].x * ss[i] : 0.f, ok ? xv[i].y * ss[i] : 0.f,
+                                     ok ? xv[i].z * ss[i] : 0.f, ok ? xv[i].w * ss[i] : 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    p[i][jj][0] = (__bf16)xs[jj];
+                    const float r1_ = xs[jj] - (float)p[i][jj][0];
+                    p[i][jj][1] = (__bf16)r1_;
+                    p[i][jj][2] = (__bf16)(r1_ - (float)p[i][jj][1]);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                unsigned char *dst = xt + (wave * MF_CHUNK_SLOTS + jj * 36 + cq) * 16 + half * 8;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    *reinterpret_cast<uint2 *>(dst + q * MF_PIECE) =
+                        make_uint2(mf_pack(p[0][jj][q], p[1][jj][q]), mf_pack(p[2][jj][q], p[3][jj][q]));
+            }
+        }
+        MF_STAMP(9 + 8 * mf_it);
+        if (ct + a.groups < a.n_col_tiles) load_tile(ct + a.groups);      // next tile, in flight under the MFMAs
+        const int gc = ct * MF_CT + 4 * cq;
+        const bool colok = gc < a.d;
+        mf_barrier();
+        MF_STAMP(10 + 8 * mf_it);
+
+        // ---- counts . X^T: 2 x 2 output tiles per wave ----
+        mf_f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
+        if (m_on) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < n_ks) {
+                    mf_bf16x8 av[2], bv[3][2];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        av[mi] = *reinterpret_cast<const mf_bf16x8 *>(
+                            ab + ((ks * 4 + kg) * MF_ROWS + (mt0 + mi) * 16 + rr) * 16);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            bv[q][ni] = *reinterpret_cast<const mf_bf16x8 *>(
+                                xt + q * MF_PIECE + (ks * 4 + kg) * (MF_CHUNK_SLOTS * 16) + bslot[ni]);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[q][ni], acc[0][ni], 0, 0, 0);
+                            if (m_two)
+                                acc[1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[q][ni], acc[1][ni], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        MF_STAMP(11 + 8 * mf_it);
+        mf_barrier();                                      // every wave is done reading the X^T image
+        MF_STAMP(12 + 8 * mf_it);
+        // ---- accumulators -> fp32 result tile (C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e) ----
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    yt[((mt0 + mi) * 16 + 4 * kg + e) * MF_YT_PITCH + (nt0 + ni) * 16 + rr] = acc[mi][ni][e];
+        mf_barrier();
+        MF_STAMP(13 + 8 * mf_it);
+
+        // ---- per row: + neighbours outside the block, x out_scale (+ y), store; two rows per pass ----
+        float4 v[RW / 2], yold[RW / 2];
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp) yold[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.accumulate) {                                // (uniform; addresses clamped, all four in flight)
+#pragma unroll
+            for (int pp = 0; pp < RW / 2; ++pp)
+                yold[pp] = *reinterpret_cast<const float4 *>(
+                    a.y + (int64_t)(r0 + min(wave + MF_WAVES * (2 * pp + half), nloc - 1)) * a.ldy + (colok ? gc : 0));
+        }
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp)
+            v[pp] = *reinterpret_cast<const float4 *>(
+                yt + min(wave + MF_WAVES * (2 * pp + half), MF_ROWS - 1) * MF_YT_PITCH + 4 * cq);
+        // the result tile (which aliases the next X^T image) is in registers: the stores below run
+        // under the next tile's conversion
+        mf_barrier();
+        MF_STAMP(14 + 8 * mf_it);
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * pp + h;
+                const int r = wave + MF_WAVES * i;
+                if (r >= nloc || rcnt[i] == 0) continue;                   // wave-uniform
+                const bool mine = colok && half == h;
+                if (rcnt[i] > 0) {
+                    const int ids = lane < MF_REM ? rem_col[r * MF_REM + lane] : 0;
+                    mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, rcnt[i], v[pp]);
+                } else {
+                    mf_gather_row(a, rp[r], rp[r + 1], lane, gc, mine, v[pp]);
+                }
+            }
+            const int r = wave + MF_WAVES * (2 * pp + half);
+            const float s = half ? rsc[2 * pp + 1] : rsc[2 * pp];
+            if (colok && r < nloc)
+                *reinterpret_cast<float4 *>(a.y + (int64_t)(r0 + r) * a.ldy + gc) =
+                    make_float4(fmaf(s, v[pp].x, yold[pp].x), fmaf(s, v[pp].y, yold[pp].y),
+                                fmaf(s, v[pp].z, yold[pp].z), fmaf(s, v[pp].w, yold[pp].w));
+        }
+        // rows of an oversized block beyond the 128 staged ones: gathered in full, two rows per pass
+        for (int rb = MF_ROWS + 2 * wave; rb < nrow; rb += 2 * MF_WAVES) {
+            float4 vo = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (rb + h >= nrow) continue;                              // wave-uniform
+                mf_gather_row(a, a.rowptr[r0 + rb + h], a.rowptr[r0 + rb + h + 1], lane, gc, colok && half == h, vo);
+            }
+            const int r = rb + half;
+            if (colok && r < nrow) {
+                float *yp = a.y + (int64_t)(r0 + r) * a.ldy + gc;
+                float4 yo = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.accumulate) yo = *reinterpret_cast<const float4 *>(yp);
+                const float s = a.out_scale ? a.out_scale[r0 + r] : 1.f;
+                *reinterpret_cast<float4 *>(yp) = make_float4(fmaf(s, vo.x, yo.x), fmaf(s, vo.y, yo.y),
+                                                              fmaf(s, vo.z, yo.z), fmaf(s, vo.w, yo.w));
+            }
+        }
+        MF_STAMP(15 + 8 * mf_it);
+    }
+}
+
+int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
+                     int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
+                     int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, hipStream_t st) {
+    MfArgs a;
+    a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
+    a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
+    a.accumulate = accumulate; a.row_blocks = row_blocks;
+    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, MF_ROWS);
+    a.n_blocks = (int)nb;
+    a.n_col_tiles = (int)ceil_div(d, MF_CT);
+    // one workgroup per CU at a time: as many column groups per block as fill the chip once
+    int64_t groups = nb > 0 ? 256 / nb : 1;
+    if (groups < 1) groups = 1;
+    if (groups > a.n_col_tiles) groups = a.n_col_tiles;
+    a.groups = (int)groups;
+    const int64_t total = nb * groups;
+    const int64_t grid = kXcds * ceil_div(total, kXcds);
+    if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return GIST_ELAUNCH;
+        }
+        once.done(dev);
+    }
+    hipLaunchKernelGGL(spmm_csr_mfma_kernel, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    return launch_status("gist_spmm_csr_blocked_f32");
+}
+
+}  // namespace gist
+
+#ifdef MF_PROBE
+extern "C" int gist_mf_probe_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gist::g_mf_probe), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

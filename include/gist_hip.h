@@ -157,6 +157,7 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_GEMM_SPLITS 4   /* fp32 GEMM split-K factor                                   */
 #define GIST_TUNE_SPMM_CHUNK 5    /* rows per XCD chunk of the row-split SpMM                   */
 #define GIST_TUNE_SPMM_SPLIT 6    /* row split of the LDS-staged SpMM (1..8)                    */
+#define GIST_TUNE_SPMM_KERNEL 7   /* blocked SpMM: 1 = LDS gather kernel, 2 = block-dense MFMA kernel  */
 #define GIST_TUNE_COUNT 8
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);

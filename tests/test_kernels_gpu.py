@@ -521,10 +521,53 @@ def test_gemm_forced_configs(hip, tile, splits):
 @pytest.mark.parametrize('n,d,deg,hub', [(300, 602, 8, 0), (513, 256, 16, 700), (1000, 1024, 20, 0),
                                          (2046, 4096, 64, 3000), (700, 130, 5, 0), (90, 12, 7, 0)])
 @pytest.mark.parametrize('blocks', ['uniform', 'parts', 'oversize'])
-def test_spmm_blocked_lds(hip, n, d, deg, hub, blocks):
-    """LDS-staged kernel == plain kernel semantics, for uniform 128-row blocks, ragged
-    'METIS part' blocks and blocks larger than the 128 rows that fit in LDS; graph with
-    strong in-block locality plus remote edges and a hub."""
+@pytest.mark.parametrize('kernel', ['lds_gather', 'mfma_block_dense'])
+def test_spmm_blocked_lds(hip, n, d, deg, hub, blocks, kernel):
+    """Both kernels behind gist_spmm_csr_blocked_f32 (the LDS gather kernel and the block-dense
+    matrix-core kernel, forced through the tuning hook) == plain kernel semantics, for uniform
+    128-row blocks, ragged 'METIS part' blocks and blocks larger than the 128 rows that fit in LDS;
+    multigraph with strong in-block locality plus remote edges and a hub (a row with thousands of
+    neighbours, which leaves the dense product and is gathered in full)."""
+    hip.tuning('spmm_kernel', 1 if kernel == 'lds_gather' else 2)
+    try:
+        _spmm_blocked_case(hip, n, d, deg, hub, blocks)
+    finally:
+        hip.tuning('spmm_kernel', 0)
+
+
+def test_spmm_block_dense_exact_counts_and_order():
+    """The matrix-core kernel is exact fp32 aggregation: on integer-valued features (every partial sum
+    exact in fp32, whatever the order) it must equal the oracle BIT FOR BIT -- including an edge
+    listed 300 times (a count above 256 is not exact in bf16: that row leaves the dense product) and
+    features with 21 significant bits (the three bf16 pieces must carry all of them)."""
+    from gist_amd import hip
+    rs = np.random.RandomState(5)
+    n, d = 400, 2048
+    src = rs.randint(0, n, 6000); dst = (src // 100) * 100 + rs.randint(0, 100, 6000)
+    dst = np.minimum(dst, n - 1)
+    src = np.concatenate([src, np.full(300, 7)]); dst = np.concatenate([dst, np.full(300, 9)])
+    rowptr, col = O.csr_from_edges(src, dst, n)
+    x = np.zeros((n, 2 * d), np.float32)
+    # multiples of 2^-12 below 512 (21 significant bits: all three bf16 pieces are needed), sparse enough
+    # that every sum stays below 2^12, i.e. exact in fp32 in any order; the 300-fold neighbour: small integers
+    x[:, :d] = rs.randint(-(1 << 21), 1 << 21, (n, d)).astype(np.float32) / 4096.0
+    x[:, :d] *= (rs.rand(n, d) < 0.05)
+    x[7, :d] = rs.randint(-8, 9, d).astype(np.float32)
+    rb = dev(np.array([0, 100, 200, 300, 400]), torch.int32)
+    xt = dev(x)
+    hip.tuning('spmm_kernel', 2)
+    try:
+        hip.spmm(dev(rowptr, torch.int32), dev(col, torch.int32), xt[:, :d], xt[:, d:], row_blocks=rb, blocked=True)
+    finally:
+        hip.tuning('spmm_kernel', 0)
+    want = O.spmm_sum(rowptr, col, np.ascontiguousarray(x[:, :d]))
+    ref64 = np.zeros((n, d))
+    np.add.at(ref64, np.repeat(np.arange(n), np.diff(rowptr)), x[col, :d].astype(np.float64))
+    assert np.array_equal(want.astype(np.float64), ref64), 'test data: the fp32 sums are not exact'
+    assert np.array_equal(xt[:, d:].cpu().numpy(), want)
+
+
+def _spmm_blocked_case(hip, n, d, deg, hub, blocks):
     rs = np.random.RandomState(n + d)
     # locality: most edges inside chunks of ~100 rows
     m = n * deg
