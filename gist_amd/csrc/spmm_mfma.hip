@@ -45,6 +45,8 @@ namespace gist {
 
 typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 mf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MF_ROWS = 128;                       // rows of a block staged = k extent of the product
 constexpr int MF_CT = 128;                         // columns per tile
@@ -216,12 +218,11 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
                 for (int i = 0; i < 4; ++i) ss[i] = srow + i < nloc ? ss[i] : 0.f;
                 if (ct < a.n_col_tiles) load_tile(ct);
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = base + u * MF_THREADS + tid < E1 ? c[u] : -1;
+            // the rows of the thread's eight edges: LDS only, done while the ids are in flight
+            int er[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = base + u * MF_THREADS + tid;
-                if (c[u] < 0) continue;
                 int lo = 0, hi = nloc;                     // rp[lo] <= e < rp[hi]
 #pragma unroll
                 for (int it = 0; it < 7; ++it) {
@@ -230,7 +231,13 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
                     hi = (!up && mid > lo) ? mid : hi;
                     lo = up ? mid : lo;
                 }
-                const int r = lo;
+                er[u] = lo;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * MF_THREADS + tid;
+                if (e >= E1) continue;
+                const int r = er[u];
                 const int k = c[u] - r0;
                 if (k >= 0 && k < nloc) {
                     atomicAdd(&a32[((k >> 3) * MF_ROWS + r) * 4 + ((k & 7) >> 1)], (k & 1) ? 0x10000u : 1u);
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     // with more than fit is gathered in full below
     if (tid < nloc) {
         const int cnt = rem_cnt[tid];
-        if (cnt > MF_REM) {
+        if (cnt > MF_REM || rp[tid + 1] - rp[tid] > 65535) {       // (65536 copies of an edge would wrap a counter)
             rem_cnt[tid] = -1;
         } else {
             for (int i = 1; i < cnt; ++i) {
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     }
     constexpr int RW = MF_ROWS / MF_WAVES;                 // rows a wave converts / finishes: wave + 16 i
     // counts -> bf16 in place; a row with a count > 256 (not exact in bf16) leaves the dense product
-    // (zero row) and is gathered in full as well
+    // as well (its part of the result tile is ignored) and is gathered in full
     {
         uint32_t v[RW];
 #pragma unroll
@@ -277,15 +284,6 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
             if (big && lane == 0) big_row[wave + MF_WAVES * i] = 1;
             a32[((lane >> 2) * MF_ROWS + wave + MF_WAVES * i) * 4 + (lane & 3)] =
                 mf_pack((__bf16)(float)c0, (__bf16)(float)c1);
-        }
-    }
-    mf_barrier();
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int r = wave + MF_WAVES * i;
-        if (r < nloc && (rem_cnt[r] < 0 || big_row[r])) {             // wave-uniform
-            a32[((lane >> 2) * MF_ROWS + r) * 4 + (lane & 3)] = 0u;
-            if (lane == 0) rem_cnt[r] = -1;
         }
     }
     mf_barrier();
@@ -308,35 +306,43 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int r = wave + MF_WAVES * i;
-        rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
+        rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(big_row[r] ? -1 : rem_cnt[r]) : 0;
         rsc[i] = r < nloc ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc[r]))) : 0.f;
     }
     int mf_it = 0;
     for (; ct < a.n_col_tiles; ct += a.groups, ++mf_it) {
         MF_STAMP(8 + 8 * mf_it);
         // ---- X tile -> x src_scale -> three bf16 pieces -> X^T image ----
-        {
-            __bf16 p[4][4][3];
+        {   // rows (0, 1) and (2, 3) of a column are converted in pairs: one v_cvt_pk_bf16_f32 per
+            // piece gives the packed word the image wants, its two halves shifted / masked back to fp32
+            // give the residuals
+            const bool cok = ct * MF_CT + 4 * cq < a.d;
+            float xs[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool ok = srow + i < nloc && ct * MF_CT + 4 * cq < a.d;      // (clamped loads: select here)
-                const float xs[4] = {ok ? xv[i].x * ss[i] : 0.f, ok ? xv[i].y * ss[i] : 0.f,
-                                     ok ? xv[i].z * ss[i] : 0.f, ok ? xv[i].w * ss[i] : 0.f};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    p[i][jj][0] = (__bf16)xs[jj];
-                    const float r1_ = xs[jj] - (float)p[i][jj][0];
-                    p[i][jj][1] = (__bf16)r1_;
-                    p[i][jj][2] = (__bf16)(r1_ - (float)p[i][jj][1]);
-                }
+                const bool ok = cok && srow + i < nloc;                    // (clamped loads: select here)
+                xs[i][0] = ok ? xv[i].x * ss[i] : 0.f; xs[i][1] = ok ? xv[i].y * ss[i] : 0.f;
+                xs[i][2] = ok ? xv[i].z * ss[i] : 0.f; xs[i][3] = ok ? xv[i].w * ss[i] : 0.f;
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
+                uint32_t w[3][2];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float x0 = xs[2 * pr][jj], x1 = xs[2 * pr + 1][jj];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const mf_bf16x2 pk = __builtin_convertvector(mf_f32x2{x0, x1}, mf_bf16x2);
+                        const uint32_t u = __builtin_bit_cast(uint32_t, pk);
+                        w[q][pr] = u;
+                        x0 -= __builtin_bit_cast(float, u << 16);
+                        x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+                    }
+                }
                 unsigned char *dst = xt + (wave * MF_CHUNK_SLOTS + jj * 36 + cq) * 16 + half * 8;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    *reinterpret_cast<uint2 *>(dst + q * MF_PIECE) =
-                        make_uint2(mf_pack(p[0][jj][q], p[1][jj][q]), mf_pack(p[2][jj][q], p[3][jj][q]));
+                    *reinterpret_cast<uint2 *>(dst + q * MF_PIECE) = make_uint2(w[q][0], w[q][1]);
             }
         }
         MF_STAMP(9 + 8 * mf_it);
@@ -424,6 +430,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
                     const int ids = lane < MF_REM ? rem_col[r * MF_REM + lane] : 0;
                     mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, rcnt[i], v[pp]);
                 } else {
+                    if (mine) v[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
                     mf_gather_row(a, rp[r], rp[r + 1], lane, gc, mine, v[pp]);
                 }
             }
