@@ -581,7 +581,7 @@ def main():
             copy_gbs = measured_copy_gbs(dev)
             n_instr = len(range(0, args.steps, every))
             out['roofline_spmm'] = {
-                'kernel': 'gist::spmm_csr_lds2_kernel (wide layers; gist::spmm_csr_rowsplit_kernel for the F=602 layer)', 'bound': 'hbm', 'achieved': round(s_ach, 2),
+                'kernel': ('gist::spmm_csr_mfma_kernel (block-dense, wide layers)' if H // S >= 1536 else 'gist::spmm_csr_lds2_kernel (LDS gather, wide layers)') + '; gist::spmm_csr_rowsplit_kernel for the F=602 layer', 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
                 # achievable HBM bandwidth on this box: a 1 GiB device-to-device copy (read+write)
                 'peak_measured_copy': round(copy_gbs, 1),

@@ -562,7 +562,9 @@ static int g_h3_mode = -1;      // -1: read GIST_GEMM_MODE on first use
 int h3_mode() {
     if (g_h3_mode < 0) {
         const char *e = getenv("GIST_GEMM_MODE");
-        g_h3_mode = 0;      // default: fp32 products (v_mfma_f32_32x32x2_f32), like the reference's nn.Linear
+        // default: large projections as three bf16 pieces per operand (all 24 bits, six cross terms:
+        // error at the fp32-MFMA kernel's level, gemm_b3.hip), everything else fp32 MFMA
+        g_h3_mode = 2;
         if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) g_h3_mode = 0;
         else if (e && (!strcmp(e, "f16x3") || !strcmp(e, "1"))) g_h3_mode = 1;
         else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "2"))) g_h3_mode = 2;

@@ -173,10 +173,11 @@ def _ws_for(m, n, k, device):
 
 
 def gemm_mode(mode=None):
-    """Get (and with an argument, set) how large projections form their products:
-    'f32' (default) = v_mfma_f32_32x32x2_f32 everywhere, fp32 arithmetic like the reference;
-    'f16x3' (opt-in) = split operands on the f16 matrix cores (22-bit operands, fp32-level
-    accuracy on the step's data; include/gist_hip.h gist_gemm_set_mode).  Process-wide."""
+    """Get (and with an argument, set) how large projections form their products
+    (include/gist_hip.h gist_gemm_set_mode): 'bf16x3' (default) = three bf16 pieces per fp32 operand
+    (all 24 bits), six cross terms on the bf16 matrix cores, fp32-MFMA-level error; 'f32' =
+    v_mfma_f32_32x32x2_f32 everywhere, fp32 products like the reference; 'f16x3' (opt-in) = two f16
+    halves per operand (22 bits).  Small shapes are fp32 MFMA in every mode.  Process-wide."""
     L = _lib.load()
     if mode is not None:
         code = {'f32': 0, 'f16x3': 1, 'bf16x3': 2, 0: 0, 1: 1, 2: 2}.get(mode)

@@ -128,20 +128,27 @@ int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
                      float *d, int64_t ldd, int64_t m, int64_t n, int64_t k,
                      void *workspace, int64_t workspace_bytes, gist_stream_t stream);
 
-/* How the three entry points above form their products.  Mode 0 (the default; GIST_GEMM_MODE=f32
- * read once at first use) keeps every shape on v_mfma_f32_32x32x2_f32: fp32 products and fp32
- * accumulation, the arithmetic of the reference's nn.Linear.  Mode 1 (opt-in; GIST_GEMM_MODE=f16x3)
- * changes shapes large enough to fill the chip (>= 64 output tiles of 128x128, >= 16 GFLOP,
- * 16-byte aligned operands, workspace of gist_gemm_workspace_bytes): each fp32 operand is split
- * once into two f16 halves under one power-of-two scale per operand row (22 of fp32's 24
- * significant bits) and ah.bh + ah.bl + al.bh is accumulated in fp32 on v_mfma_f32_16x16x32_f16 --
- * error against fp64 at mode 0's level on the step's operands (tests/test_gemm_h3_gpu.py) at
- * about half the time, but narrower operand arithmetic than fp32 by construction.  Inputs and
- * outputs are fp32 in both modes; small and skinny shapes always take mode 0's kernel.  In mode 1
- * a NaN or Inf in an operand row makes the corresponding output row / column non-finite (NaN
- * where fp32 would give Inf) and leaves all other outputs unchanged.  Process-wide; set it
- * before sizing workspaces.  Both replace the same call, self.linear(h),
- * cluster_gcn/modules.py:233, and its autograd. */
+/* How the three entry points above form their products (GIST_GEMM_MODE = bf16x3 | f32 | f16x3 is
+ * read once at first use; gist_gemm_set_mode overrides it; process-wide: set it before sizing
+ * workspaces).  Inputs, outputs and accumulation are fp32 in every mode, and small or skinny shapes
+ * always run on v_mfma_f32_32x32x2_f32.
+ *   Mode 2, bf16x3 (the default): shapes large enough to fill the chip (>= 128 workgroups of
+ *     256 x 128 tiles x k slices, >= 16 GFLOP per call or >= 4 GFLOP inside gist_sage_step, workspace
+ *     of gist_gemm_workspace_bytes) carry each fp32 operand as three bf16 pieces, x = b1 + b2 + b3
+ *     EXACTLY (3 x 8 = all 24 significant bits, fp32's exponent range, no scales), and accumulate
+ *     the six leading cross terms in fp32 on v_mfma_f32_16x16x32_bf16; what is dropped is below one
+ *     fp32 rounding of a product.  Error against fp64 at mode 0's level on every operand class tested,
+ *     adversarial ones included (tests/test_gemm_b3_gpu.py), at ~0.6x the time.
+ *   Mode 0, f32: every shape on v_mfma_f32_32x32x2_f32 -- fp32 products, the arithmetic of the
+ *     reference's nn.Linear.
+ *   Mode 1, f16x3 (opt-in): each fp32 operand as two f16 halves under one power-of-two scale per
+ *     operand row (22 of fp32's 24 significant bits), ah.bh + ah.bl + al.bh in fp32 on
+ *     v_mfma_f32_16x16x32_f16 -- error at mode 0's level on the step's operands
+ *     (tests/test_gemm_h3_gpu.py) at about half the time, but narrower operand arithmetic than fp32
+ *     by construction.
+ * In the split modes a NaN or Inf in an operand row makes the corresponding output row / column
+ * non-finite (NaN where fp32 would give Inf) and leaves all other outputs unchanged.  All three
+ * replace the same call, self.linear(h), cluster_gcn/modules.py:233, and its autograd. */
 int gist_gemm_set_mode(int mode);
 int gist_gemm_get_mode(void);
 
