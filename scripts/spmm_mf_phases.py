@@ -18,7 +18,7 @@ it.bind(eng, native=False)
 b = next(iter(it))
 L = _lib.load()
 L.gist_mf_probe_read.argtypes = [ctypes.c_void_p]
-names = {0: 'start', 1: 'rowptr in LDS (barrier)', 2: 'counts built (barrier)', 3: 'counts -> bf16 (2 barriers)', 4: '-'}
+names = {0: 'start', 1: 'rowptr in LDS (barrier)', 2: 'counts built (barrier)', 3: 'counts -> bf16 (2 barriers)'}
 tile = ['tile start', 'X^T written', 'barrier', 'MFMAs issued', 'barrier', 'result tile written (barrier)', 'result rows read (barrier)', 'stores issued']
 for d in [int(x) for x in (sys.argv[1:] or ['4096'])]:
     z = torch.randn(b.n, 2 * d, device=dev)
@@ -32,7 +32,7 @@ for d in [int(x) for x in (sys.argv[1:] or ['4096'])]:
         buf = np.zeros(64, np.uint64)
         assert L.gist_mf_probe_read(buf.ctypes.data) == 0
         t = (buf.astype(np.int64) - int(buf[0])) / 100.0
-        out = ['D=%d %s:' % (d, form)] + ['%s %.2f' % (names[i], t[i]) for i in range(1, 5)]
+        out = ['D=%d %s:' % (d, form)] + ['%s %.2f' % (names[i], t[i]) for i in range(1, 4)]
         i = 0
         while 8 + 8 * i + 7 < 64 and buf[8 + 8 * i] > buf[0] and (i == 0 or buf[8 + 8 * i] > buf[8 * i]):
             out.append(' | tile %d: ' % i + ', '.join('%s %.2f' % (tile[j], t[8 + 8 * i + j]) for j in range(8)))
