@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GistLibraryError(RuntimeError):
@@ -37,6 +37,9 @@ SIGNATURES = {
     'gist_spmm_csr_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p]),
     'gist_partition_graph': (_int, [_p, _p, _p, _p, _i64, _i32, _u64, _i32, _f, _p]),
     'gist_spmm_csr_blocked_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _p]),
+    'gist_spmm_blocks_bytes': (_i64, [_i64]),
+    'gist_spmm_blocks_prepare': (_int, [_p, _p, _i64, _p, _i64, _p, _i64, _p]),
+    'gist_spmm_csr_prepared_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _p, _p]),
     'gist_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'gist_gemm_set_mode': (_int, [_int]),
     'gist_gemm_get_mode': (_int, []),
@@ -103,7 +106,8 @@ class StepPlan(ctypes.Structure):
                 ('rowptr', _p), ('col', _p), ('t_rowptr', _p), ('t_col', _p),
                 ('col_capacity', _i64), ('norm', _p), ('labels', _p), ('timer', _p),
                 ('n_max', _i64), ('feat_absmax', _f), ('h3_workspace', _p),
-                ('h3_workspace_bytes', _i64), ('row_blocks', _p), ('n_row_blocks', _i64)]
+                ('h3_workspace_bytes', _i64), ('row_blocks', _p), ('n_row_blocks', _i64),
+                ('spmm_prepared', _p), ('spmm_prepared_bytes', _i64)]
 
 
 _lib = None

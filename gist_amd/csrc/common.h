@@ -94,10 +94,17 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
 int splitk_reduce(const char *name, const float *slabs, int64_t slab, int splits, const float *bias, float *c,
                   int64_t ldc, int64_t m, int64_t n, hipStream_t st);
 
-// spmm_mfma.hip: the block-dense aggregation kernel behind gist_spmm_csr_blocked_f32
+// spmm_mfma.hip: the block-dense aggregation kernel behind gist_spmm_csr_blocked_f32 / _prepared_f32
+// (prepared = NULL: every workgroup builds its block's counts itself)
 int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
                      int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
-                     int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, hipStream_t st);
+                     int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
+                     hipStream_t st);
+int64_t spmm_blocks_bytes(int64_t n_blocks);
+bool spmm_prepared_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);   // spmm.hip
+int launch_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, const int32_t *rowptr2,
+                               const int32_t *col2, int64_t n_rows, const int32_t *row_blocks,
+                               int64_t n_row_blocks, void *prepared, void *prepared2, hipStream_t st);
 
 // rowops.hip: the C-ABI kernels with the extra outputs the split projection path consumes
 int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,

@@ -718,6 +718,15 @@ static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const flo
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 
+// Calls the prepared matrix-core kernel takes (everything else: gist_spmm_csr_blocked_f32's choice).
+// Measured with the block structure prepared (rocprofv3, Reddit-like batch): D = 4096 30.5 us (38 when
+// every workgroup builds its own, 57 on the LDS gather kernel), 2048 21 (29, 33), 1024 13.5 (21.5, 16),
+// 512 13.4 (20, 12); the preparation is one 13 us launch per batch, so it pays from D = 2048 on.
+bool spmm_prepared_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y) {
+    return d >= 1536 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) &&
+           (int)tune(GIST_TUNE_SPMM_KERNEL) != 1;
+}
+
 }  // namespace gist
 
 extern "C" int gist_in_degree_norm_f32(const int32_t *rowptr, int64_t n_rows, float *norm,
@@ -784,11 +793,51 @@ extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *c
         const int want = (int)tune(GIST_TUNE_SPMM_KERNEL);
         if (want == 2 || (want != 1 && d >= 1536))
             return launch_spmm_mfma(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
-                                    accumulate, row_blocks, n_row_blocks, st);
+                                    accumulate, row_blocks, n_row_blocks, nullptr, st);
         return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                                 accumulate, row_blocks, n_row_blocks, st);
     }
     // other widths / alignments (the layer-0 aggregation of F = 602 features): the row-split kernel
     return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                              accumulate, stream);
+}
+
+extern "C" int64_t gist_spmm_blocks_bytes(int64_t n_row_blocks) { return gist::spmm_blocks_bytes(n_row_blocks); }
+
+extern "C" int gist_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, int64_t n_rows,
+                                        const int32_t *row_blocks, int64_t n_row_blocks, void *prepared,
+                                        int64_t prepared_bytes, gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(n_rows >= 0, "gist_spmm_blocks_prepare: negative size");
+    if (n_rows == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && prepared, "gist_spmm_blocks_prepare: null pointer");
+    GIST_REQUIRE(n_rows < (1LL << 31), "gist_spmm_blocks_prepare: size >= 2^31");
+    GIST_REQUIRE(row_blocks == nullptr || n_row_blocks > 0,
+                 "gist_spmm_blocks_prepare: row_blocks given but n_row_blocks <= 0");
+    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, 128);
+    GIST_REQUIRE(aligned16(prepared) && prepared_bytes >= spmm_blocks_bytes(nb),
+                 "gist_spmm_blocks_prepare: buffer too small or not 16-byte aligned");
+    return launch_spmm_blocks_prepare(rowptr, col, nullptr, nullptr, n_rows, row_blocks, n_row_blocks, prepared,
+                                      nullptr, as_stream(stream));
+}
+
+extern "C" int gist_spmm_csr_prepared_f32(const int32_t *rowptr, const int32_t *col, const float *x,
+                                          int64_t ldx, float *y, int64_t ldy, int64_t n_rows, int64_t d,
+                                          const float *out_scale, const float *src_scale, int accumulate,
+                                          const int32_t *row_blocks, int64_t n_row_blocks,
+                                          const void *prepared, gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_spmm_csr_prepared_f32: negative size");
+    if (n_rows == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && x && y && prepared, "gist_spmm_csr_prepared_f32: null pointer");
+    GIST_REQUIRE(ldx >= d && ldy >= d, "gist_spmm_csr_prepared_f32: leading dimension < d");
+    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_spmm_csr_prepared_f32: size >= 2^31");
+    GIST_REQUIRE(row_blocks == nullptr || n_row_blocks > 0,
+                 "gist_spmm_csr_prepared_f32: row_blocks given but n_row_blocks <= 0");
+    // widths / alignments the matrix-core kernel does not take: the unprepared entry point decides
+    if (!spmm_prepared_takes(d, ldx, ldy, x, y) || !aligned16(prepared))
+        return gist_spmm_csr_blocked_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                         accumulate, row_blocks, n_row_blocks, stream);
+    return launch_spmm_mfma(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
+                            row_blocks, n_row_blocks, prepared, as_stream(stream));
 }

@@ -70,6 +70,9 @@ constexpr int MF_BIG_OFF = MF_SC_OFF + MF_ROWS * 4;              // int big_row[
 constexpr int MF_LDS_BYTES = MF_BIG_OFF + MF_ROWS * 4;
 static_assert(MF_ROWS * MF_YT_PITCH * 4 <= 3 * MF_PIECE, "result tile fits the X^T image");
 static_assert(MF_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+// a prepared block in memory: the counts image, then rem_cnt[128], then rem_col[128][8] (as in LDS)
+constexpr int MF_PREP_STRIDE = 16 * MF_ROWS * 16 + MF_ROWS * 4 + MF_ROWS * MF_REM * 4;
+static_assert(MF_REM_OFF == MF_REMC_OFF + MF_ROWS * 4 && MF_PREP_STRIDE % 16 == 0, "rem_cnt and rem_col are contiguous");
 
 struct MfArgs {
     const int32_t *rowptr, *col;
@@ -80,6 +83,7 @@ struct MfArgs {
     int accumulate;
     const int32_t *row_blocks;
     int n_blocks, n_col_tiles, groups;
+    const unsigned char *prep;       // prepared blocks (spmm_blocks_prepare_kernel) or NULL
 };
 
 __device__ __forceinline__ uint32_t mf_pack(__bf16 lo, __bf16 hi) {
@@ -135,30 +139,16 @@ __device__ unsigned long long g_mf_probe[64];
 #define MF_STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
-    MF_STAMP(0);
-    // ---- workgroup -> (block, column group); the groups of one block stay on one XCD ----
-    const int total = a.n_blocks * a.groups;
-    const int per_xcd = (total + kXcds - 1) / kXcds;
-    const int unit = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
-    if (unit >= total) return;
-    const int grp = unit % a.groups;
-    const int rbk = unit / a.groups;
-    int r0, r1;
-    if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
-    else { r0 = rbk * MF_ROWS; r1 = r0 + MF_ROWS; }
-    r1 = min(r1, a.n_rows);
-    const int nrow = r1 - r0;
-    if (nrow <= 0) return;
-    const int nloc = min(nrow, MF_ROWS);
+// Edge counts of block [r0, r0 + nloc) as bf16 in `ab`, [k chunk][row][8 k], and per row its neighbours
+// outside the block (rem_cnt: how many, -1 = the row leaves the dense product and is gathered in full;
+// rem_col: their ids in CSR order).  All 1024 threads; `after_ids` is called once, right after the first
+// batch of id loads has been issued.
+template <typename F>
+__device__ __forceinline__ void mf_build_block(const MfArgs &a, int r0, int nloc, unsigned char *mf_smem,
+                                               F after_ids) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, cq = lane & 31;
-
-    unsigned char *xt = mf_smem;
-    float *yt = reinterpret_cast<float *>(mf_smem);
     unsigned char *ab = mf_smem + MF_A_OFF;
     uint32_t *a32 = reinterpret_cast<uint32_t *>(ab);
     int32_t *rp = reinterpret_cast<int32_t *>(mf_smem + MF_RP_OFF);
@@ -167,7 +157,6 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     int32_t *rem_e = reinterpret_cast<int32_t *>(mf_smem + MF_REME_OFF);
     float *sc = reinterpret_cast<float *>(mf_smem + MF_SC_OFF);
     int32_t *big_row = reinterpret_cast<int32_t *>(mf_smem + MF_BIG_OFF);
-
     // ---- once per workgroup: the block's edge counts and its outside neighbours ----
     {
         uint4 *z = reinterpret_cast<uint4 *>(ab + tid * 32);
@@ -183,20 +172,6 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     mf_barrier();
     MF_STAMP(1);
 
-    // staging role of this thread: rows 8 wave + 4 half + i, columns 4 cq .. 4 cq + 3 of the tile
-    const int srow = 8 * wave + 4 * half;
-    float ss[4];
-    float4 xv[4];
-    int ct = grp;
-    // (branch-free: a predicated load compiles to an exec-mask branch and a conservative s_waitcnt
-    // vmcnt(0) at its join, which serialises the loads -- clamp the address, select when the value is used)
-    auto load_tile = [&](int t) {
-        const bool cok = t * MF_CT + 4 * cq < a.d;
-        const float *px = a.x + (int64_t)r0 * a.ldx + (cok ? t * MF_CT + 4 * cq : 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, nloc - 1) * a.ldx);
-    };
     {   // every edge of the block, 1024 at a time, the loads of a thread in flight together (and BEFORE
         // the first X tile's: loads return in order); the row of an edge by binary search in the block's
         // row pointers (LDS)
@@ -212,11 +187,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
             }
             if (first) {
                 first = false;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ss[i] = a.src_scale ? a.src_scale[r0 + min(srow + i, nloc - 1)] : 1.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ss[i] = srow + i < nloc ? ss[i] : 0.f;
-                if (ct < a.n_col_tiles) load_tile(ct);
+                after_ids();        // the caller's own loads go out behind the ids (loads return in order)
             }
             // the rows of the thread's eight edges: LDS only, done while the ids are in flight
             int er[8];
@@ -270,7 +241,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
             }
         }
     }
-    constexpr int RW = MF_ROWS / MF_WAVES;                 // rows a wave converts / finishes: wave + 16 i
+    constexpr int RW = MF_ROWS / MF_WAVES;                 // rows a wave converts: wave + 16 i
     // counts -> bf16 in place; a row with a count > 256 (not exact in bf16) leaves the dense product
     // as well (its part of the result tile is ignored) and is gathered in full
     {
@@ -287,6 +258,81 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
         }
     }
     mf_barrier();
+    // final state of a row in one place: -1 = gathered in full
+    if (tid < nloc && big_row[tid]) rem_cnt[tid] = -1;
+    mf_barrier();
+}
+
+template <bool PREP>
+__global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    MF_STAMP(0);
+    // ---- workgroup -> (block, column group); the groups of one block stay on one XCD ----
+    const int total = a.n_blocks * a.groups;
+    const int per_xcd = (total + kXcds - 1) / kXcds;
+    const int unit = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    if (unit >= total) return;
+    const int grp = unit % a.groups;
+    const int rbk = unit / a.groups;
+    int r0, r1;
+    if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
+    else { r0 = rbk * MF_ROWS; r1 = r0 + MF_ROWS; }
+    r1 = min(r1, a.n_rows);
+    const int nrow = r1 - r0;
+    if (nrow <= 0) return;
+    const int nloc = min(nrow, MF_ROWS);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, cq = lane & 31;
+
+    unsigned char *xt = mf_smem;
+    float *yt = reinterpret_cast<float *>(mf_smem);
+    unsigned char *ab = mf_smem + MF_A_OFF;
+    int32_t *rp = reinterpret_cast<int32_t *>(mf_smem + MF_RP_OFF);
+    int32_t *rem_cnt = reinterpret_cast<int32_t *>(mf_smem + MF_REMC_OFF);
+    int32_t *rem_col = reinterpret_cast<int32_t *>(mf_smem + MF_REM_OFF);
+    float *sc = reinterpret_cast<float *>(mf_smem + MF_SC_OFF);
+
+    // staging role of this thread: rows 8 wave + 4 half + i, columns 4 cq .. 4 cq + 3 of the tile
+    const int srow = 8 * wave + 4 * half;
+    float ss[4];
+    float4 xv[4];
+    int ct = grp;
+    // (branch-free: a predicated load compiles to an exec-mask branch and a conservative s_waitcnt
+    // vmcnt(0) at its join, which serialises the loads -- clamp the address, select when the value is used)
+    auto load_tile = [&](int t) {
+        const bool cok = t * MF_CT + 4 * cq < a.d;
+        const float *px = a.x + (int64_t)r0 * a.ldx + (cok ? t * MF_CT + 4 * cq : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, nloc - 1) * a.ldx);
+    };
+    auto first_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss[i] = a.src_scale ? a.src_scale[r0 + min(srow + i, nloc - 1)] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss[i] = srow + i < nloc ? ss[i] : 0.f;
+        if (ct < a.n_col_tiles) load_tile(ct);
+    };
+    if constexpr (PREP) {
+        // ---- the block's counts and outside neighbours were built once for the batch: copy them ----
+        const unsigned char *src = a.prep + (int64_t)rbk * MF_PREP_STRIDE;
+        const uint4 c0 = reinterpret_cast<const uint4 *>(src)[2 * tid], c1 = reinterpret_cast<const uint4 *>(src)[2 * tid + 1];
+        const int4 rm = tid < (MF_ROWS * (1 + MF_REM)) / 4 ? reinterpret_cast<const int4 *>(src + 16 * MF_ROWS * 16)[tid]
+                                                           : make_int4(0, 0, 0, 0);
+        const int rpv = tid <= nloc ? a.rowptr[r0 + tid] : 0;
+        const float scv = (tid < nloc && a.out_scale) ? a.out_scale[r0 + tid] : 1.f;
+        first_loads();
+        reinterpret_cast<uint4 *>(ab)[2 * tid] = c0;
+        reinterpret_cast<uint4 *>(ab)[2 * tid + 1] = c1;
+        if (tid < (MF_ROWS * (1 + MF_REM)) / 4) reinterpret_cast<int4 *>(mf_smem + MF_REMC_OFF)[tid] = rm;
+        if (tid <= nloc) rp[tid] = rpv;
+        if (tid < MF_ROWS) sc[tid] = scv;
+        mf_barrier();
+    } else {
+        mf_build_block(a, r0, nloc, mf_smem, first_loads);
+    }
     MF_STAMP(3);
 
     const int rr = lane & 15, kg = lane >> 4;
@@ -301,12 +347,13 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
         bslot[ni] = ((n & 3) * 36 + (n >> 2)) * 16;
     }
     // the rows this wave finishes: pairs (one per half wave), row = wave + 16 (2 p + half)
+    constexpr int RW = MF_ROWS / MF_WAVES;
     int rcnt[RW];
     float rsc[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int r = wave + MF_WAVES * i;
-        rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(big_row[r] ? -1 : rem_cnt[r]) : 0;
+        rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
         rsc[i] = r < nloc ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc[r]))) : 0.f;
     }
     int mf_it = 0;
@@ -463,13 +510,74 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     }
 }
 
+// One workgroup per block: its counts image and outside-neighbour lists -> memory, for every aggregation
+// over the same graph and blocks (gist_spmm_blocks_prepare).
+__global__ __launch_bounds__(MF_THREADS) void spmm_blocks_prepare_kernel(MfArgs a, const int32_t *rowptr2,
+                                                                         const int32_t *col2, unsigned char *out,
+                                                                         unsigned char *out2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    const int rbk = blockIdx.x;
+    if (blockIdx.y == 1) { a.rowptr = rowptr2; a.col = col2; out = out2; }      // second graph, same blocks
+    int r0, r1;
+    if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
+    else { r0 = rbk * MF_ROWS; r1 = r0 + MF_ROWS; }
+    r1 = min(r1, a.n_rows);
+    const int nloc = min(max(r1 - r0, 0), MF_ROWS);
+    const int tid = threadIdx.x;
+    unsigned char *dst = out + (int64_t)rbk * MF_PREP_STRIDE;
+    if (nloc > 0) {
+        mf_build_block(a, r0, nloc, mf_smem, [] {});
+        reinterpret_cast<uint4 *>(dst)[2 * tid] = reinterpret_cast<const uint4 *>(mf_smem + MF_A_OFF)[2 * tid];
+        reinterpret_cast<uint4 *>(dst)[2 * tid + 1] = reinterpret_cast<const uint4 *>(mf_smem + MF_A_OFF)[2 * tid + 1];
+        if (tid < (MF_ROWS * (1 + MF_REM)) / 4)
+            reinterpret_cast<int4 *>(dst + 16 * MF_ROWS * 16)[tid] = reinterpret_cast<const int4 *>(mf_smem + MF_REMC_OFF)[tid];
+    }
+}
+
+static int mf_set_lds(const void *kernel, const char *name) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+        return GIST_ELAUNCH;
+    }
+    return GIST_OK;
+}
+
+int64_t spmm_blocks_bytes(int64_t n_blocks) { return n_blocks > 0 ? n_blocks * (int64_t)MF_PREP_STRIDE : 0; }
+
+// rowptr2 / col2 / prepared2: optionally a second graph over the same rows and blocks (the reversed
+// CSR of the backward aggregation), prepared by the same launch
+int launch_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, const int32_t *rowptr2,
+                               const int32_t *col2, int64_t n_rows, const int32_t *row_blocks,
+                               int64_t n_row_blocks, void *prepared, void *prepared2, hipStream_t st) {
+    MfArgs a{};
+    a.rowptr = rowptr; a.col = col; a.n_rows = (int)n_rows; a.row_blocks = row_blocks;
+    const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, MF_ROWS);
+    a.n_blocks = (int)nb;
+    if (nb <= 0) return GIST_OK;
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        const int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_blocks_prepare_kernel), "gist_spmm_blocks_prepare");
+        if (rc != GIST_OK) return rc;
+        once.done(dev);
+    }
+    const bool two = rowptr2 != nullptr && col2 != nullptr && prepared2 != nullptr;
+    hipLaunchKernelGGL(spmm_blocks_prepare_kernel, dim3((unsigned)nb, two ? 2u : 1u), dim3(MF_THREADS), MF_LDS_BYTES,
+                       st, a, rowptr2, col2, static_cast<unsigned char *>(prepared),
+                       static_cast<unsigned char *>(prepared2));
+    return launch_status("gist_spmm_blocks_prepare");
+}
+
 int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
                      int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
-                     int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, hipStream_t st) {
+                     int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
+                     hipStream_t st) {
     MfArgs a;
     a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
     a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
     a.accumulate = accumulate; a.row_blocks = row_blocks;
+    a.prep = static_cast<const unsigned char *>(prepared);
     const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, MF_ROWS);
     a.n_blocks = (int)nb;
     a.n_col_tiles = (int)ceil_div(d, MF_CT);
@@ -484,15 +592,16 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return GIST_ELAUNCH;
-        }
+        int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<false>), "gist_spmm_csr_blocked_f32");
+        if (rc == GIST_OK)
+            rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true>), "gist_spmm_csr_blocked_f32");
+        if (rc != GIST_OK) return rc;
         once.done(dev);
     }
-    hipLaunchKernelGGL(spmm_csr_mfma_kernel, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    if (prepared)
+        hipLaunchKernelGGL(spmm_csr_mfma_kernel<true>, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(spmm_csr_mfma_kernel<false>, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 

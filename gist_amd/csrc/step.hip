@@ -240,13 +240,18 @@ extern "C" int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan) {
     return h3_layout(plan, nullptr).bytes;
 }
 
-// The step's aggregations: the LDS-staged kernel when the batch comes with its locality blocks.
+// The step's aggregations: the blocked kernels when the batch comes with its locality blocks; with the
+// batch's prepared block structure (`prepared`: this orientation's) the matrix-core kernel skips its set-up.
 static int step_spmm(const gist_step_plan *p, const int32_t *rowptr, const int32_t *col, const float *x,
                      int64_t ldx, float *y, int64_t ldy, int64_t n, int64_t d, const float *out_scale,
-                     const float *src_scale, int accumulate, gist_stream_t s) {
-    if (p->row_blocks != nullptr && p->n_row_blocks > 0)
+                     const float *src_scale, int accumulate, const void *prepared, gist_stream_t s) {
+    if (p->row_blocks != nullptr && p->n_row_blocks > 0) {
+        if (prepared != nullptr)
+            return gist_spmm_csr_prepared_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale,
+                                              accumulate, p->row_blocks, p->n_row_blocks, prepared, s);
         return gist_spmm_csr_blocked_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale,
                                          accumulate, p->row_blocks, p->n_row_blocks, s);
+    }
     return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale, accumulate, s);
 }
 
@@ -324,6 +329,25 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                     p->labels_all, p->labels, s));
     }
 
+    // ---- block structure of the batch, once for all its aggregations ----------------
+    const void *prep_fwd = nullptr, *prep_bwd = nullptr;
+    if (p->row_blocks != nullptr && p->n_row_blocks > 0 && p->spmm_prepared != nullptr &&
+        aligned16(p->spmm_prepared)) {
+        const int64_t one = gist_spmm_blocks_bytes(p->n_row_blocks);
+        bool wide = false;      // is there an aggregation the prepared kernel takes?
+        for (int k = 0; k < L1; ++k)
+            wide = wide || spmm_prepared_takes(p->layer[k].n_in, p->layer[k].ldz, p->layer[k].ldz,
+                                               p->layer[k].Z, p->layer[k].Z + p->layer[k].n_in);
+        if (wide && p->spmm_prepared_bytes >= (train ? 2 : 1) * one) {
+            char *base = static_cast<char *>(p->spmm_prepared);
+            GIST_TRY(launch_spmm_blocks_prepare(p->rowptr, p->col, train ? p->t_rowptr : nullptr,
+                                                train ? p->t_col : nullptr, n, p->row_blocks, p->n_row_blocks,
+                                                base, train ? base + one : nullptr, st));
+            prep_fwd = base;
+            prep_bwd = train ? base + one : nullptr;
+        }
+    }
+
     // ---- forward (modules.py:310-314 / :218-237) ---------------------------------
     uint64_t offs[GIST_MAX_LAYERS];
     uint64_t off = drop_offset;
@@ -332,7 +356,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
             GIST_TRY(step_spmm(p, p->rowptr, p->col, l.Z, l.ldz, l.Z + l.n_in, l.ldz, n, l.n_in,
-                               p->norm, nullptr, 0, s));
+                               p->norm, nullptr, 0, prep_fwd, s));
         }
         offs[k] = off;
         if (h3.layer[k].on) {
@@ -429,7 +453,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                               offs[k], s));
                 Scope sc(p->timer, 0, n, n, l.n_in, st);
                 GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
             }
             continue;
         }
@@ -461,7 +485,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                               offs[k], s));
                 Scope sc(p->timer, 0, n, n, l.n_in, st);
                 GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
             }
             continue;
         }
@@ -480,7 +504,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         if (k > 0) {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
             GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                               2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, s));
+                               2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
         }
     }
     GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,

@@ -180,6 +180,7 @@ class SageEngine(object):
         self._ws2 = torch.empty(max(int(need), 1 << 20), dtype=torch.uint8, device=device)
         self._drop_offsets = []
         self.plan = None
+        self._spmm_prep = None      # prepared block structure of the current batch (native step)
         self._plan_keep = None
         # inference-only reassociation of the last layer (see forward); GIST_PROJECT_FIRST=0
         # keeps the reference's aggregate-then-project order
@@ -247,6 +248,8 @@ class SageEngine(object):
         if need > 0 and os.environ.get('GIST_STEP_H3', '1') != '0':
             self._h3_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             P.h3_workspace, P.h3_workspace_bytes = self._h3_ws.data_ptr(), need
+        if self._spmm_prep is not None:
+            P.spmm_prepared, P.spmm_prepared_bytes = self._spmm_prep.data_ptr(), self._spmm_prep.numel()
         self.plan = P
         self._plan_keep = (batcher, g, self._ws, self._ws2, self._h3_ws)     # keep every buffer alive
         return P
@@ -302,6 +305,13 @@ class SageEngine(object):
         rb = b.row_blocks
         if rb is not None and rb.numel() > 1:
             self.plan.row_blocks, self.plan.n_row_blocks = rb.data_ptr(), rb.numel() - 1
+            # room for the batch's prepared block structure (include/gist_hip.h, spmm_prepared):
+            # both orientations, grown to the largest block count seen
+            need = 2 * L.gist_spmm_blocks_bytes(rb.numel() - 1)
+            if self._spmm_prep is None or self._spmm_prep.numel() < need:
+                self._spmm_prep = torch.empty(need + need // 4, dtype=torch.uint8, device=self.device)
+                self.plan.spmm_prepared = self._spmm_prep.data_ptr()
+                self.plan.spmm_prepared_bytes = self._spmm_prep.numel()
         else:
             self.plan.row_blocks, self.plan.n_row_blocks = None, 0
         rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],

@@ -101,11 +101,26 @@ def in_degree_norm(rowptr, out=None):
     return out
 
 
+def spmm_prepare(rowptr, col, row_blocks=None):
+    """The block structure of a row set for spmm(..., prepared=...): built once for every
+    aggregation over the same graph and blocks (gist_spmm_blocks_prepare).  Returns a uint8 tensor."""
+    L = _lib.load()
+    n = rowptr.numel() - 1
+    nb = (n + 127) // 128 if row_blocks is None else row_blocks.numel() - 1
+    buf = torch.empty(max(int(L.gist_spmm_blocks_bytes(nb)), 16), dtype=torch.uint8, device=rowptr.device)
+    _lib.check(L.gist_spmm_blocks_prepare(_vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32),
+                                          n, _opt(row_blocks, 'row_blocks', torch.int32),
+                                          0 if row_blocks is None else nb, buf.data_ptr(), buf.numel(),
+                                          _stream()), 'gist_spmm_blocks_prepare')
+    return buf
+
+
 def spmm(rowptr, col, x, y, out_scale=None, src_scale=None, accumulate=False, row_blocks=None,
-         blocked=False):
+         blocked=False, prepared=None):
     """y[v] (+)= out_scale[v] * sum_e src_scale[col[e]] * x[col[e]]; see gist_spmm_csr_f32.
     row_blocks (int32 [n_blocks+1]: locality blocks of the rows, <= 128 rows each) or blocked=True
-    (uniform 128-row blocks) selects the LDS-staged kernel (gist_spmm_csr_blocked_f32)."""
+    (uniform 128-row blocks) selects the blocked kernels (gist_spmm_csr_blocked_f32); prepared =
+    spmm_prepare(rowptr, col, row_blocks) reuses the block structure (gist_spmm_csr_prepared_f32)."""
     L = _lib.load()
     n = rowptr.numel() - 1
     xp, ldx = _mat(x, 'x')
@@ -121,9 +136,14 @@ def spmm(rowptr, col, x, y, out_scale=None, src_scale=None, accumulate=False, ro
             if x.shape[0] != n:
                 raise ValueError('gist_amd: the blocked spmm needs a square row/source set')
             nb = 0 if row_blocks is None else row_blocks.numel() - 1
-            rc = L.gist_spmm_csr_blocked_f32(*common, _opt(row_blocks, 'row_blocks', torch.int32),
-                                             nb, _stream())
-            name = 'gist_spmm_csr_blocked_f32'
+            if prepared is not None:
+                rc = L.gist_spmm_csr_prepared_f32(*common, _opt(row_blocks, 'row_blocks', torch.int32),
+                                                  nb, prepared.data_ptr(), _stream())
+                name = 'gist_spmm_csr_prepared_f32'
+            else:
+                rc = L.gist_spmm_csr_blocked_f32(*common, _opt(row_blocks, 'row_blocks', torch.int32),
+                                                 nb, _stream())
+                name = 'gist_spmm_csr_blocked_f32'
         else:
             rc = L.gist_spmm_csr_f32(*common, _stream())
             name = 'gist_spmm_csr_f32'

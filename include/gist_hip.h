@@ -82,6 +82,24 @@ int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col,
                               const int32_t *row_blocks, int64_t n_row_blocks,
                               gist_stream_t stream);
 
+/* The block structure of a row set, built ONCE for every aggregation over the same graph and blocks
+ * (a training step aggregates over its batch two or three times forward and again backward): per
+ * block the edge counts of its diagonal block (bf16, the matrix-core kernel's A operand) and the
+ * ids of each row's neighbours outside the block.  gist_spmm_blocks_bytes(n_row_blocks) bytes
+ * (row_blocks = NULL: ceil(n_rows / 128) uniform blocks), 16-byte aligned; valid until rowptr / col /
+ * row_blocks change.  gist_spmm_csr_prepared_f32 == gist_spmm_csr_blocked_f32 on the same arguments
+ * (same results; shapes the matrix-core kernel does not take fall through to it). */
+int64_t gist_spmm_blocks_bytes(int64_t n_row_blocks);                      /* host function */
+int gist_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, int64_t n_rows,
+                             const int32_t *row_blocks, int64_t n_row_blocks,
+                             void *prepared, int64_t prepared_bytes, gist_stream_t stream);
+int gist_spmm_csr_prepared_f32(const int32_t *rowptr, const int32_t *col,
+                               const float *x, int64_t ldx, float *y, int64_t ldy,
+                               int64_t n_rows, int64_t d,
+                               const float *out_scale, const float *src_scale, int accumulate,
+                               const int32_t *row_blocks, int64_t n_row_blocks,
+                               const void *prepared, gist_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Data preparation (HOST function, host pointers)
  * ------------------------------------------------------------------------- */
@@ -394,6 +412,11 @@ typedef struct gist_step_plan {
      * (longer parts cut).  With it the wide aggregations run gist_spmm_csr_blocked_f32 (X tile of
      * a part staged in LDS once); NULL = gist_spmm_csr_f32. */
     const int32_t *row_blocks; int64_t n_row_blocks;
+    /* With row_blocks: room for the batch's prepared block structure, both orientations
+     * (2 * gist_spmm_blocks_bytes(n_row_blocks) bytes, 16-byte aligned).  The step then prepares the
+     * blocks once after the extraction and its wide aggregations run gist_spmm_csr_prepared_f32;
+     * NULL / too small = every aggregation builds what it needs itself. */
+    void *spmm_prepared; int64_t spmm_prepared_bytes;
 } gist_step_plan;
 
 /* Bytes of h3_workspace the plan's shapes need in the current GEMM mode (0: no layer qualifies, or

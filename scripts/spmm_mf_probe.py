@@ -20,11 +20,13 @@ n = b.n
 rb = b.row_blocks
 for d in [int(x) for x in (sys.argv[1:] or ['4096'])]:
     z = torch.randn(n, 2 * d, device=dev)
-    for kern in (1, 2):
-        hip.tuning('spmm_kernel', kern)
+    prep, prep_t = hip.spmm_prepare(b.rowptr, b.col, rb), hip.spmm_prepare(b.t_rowptr, b.t_col, rb)
+    for kern in (1, 2, 3):
+        hip.tuning("spmm_kernel", min(kern, 2))
         for _ in range(12):
-            hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm, row_blocks=rb)
-            hip.spmm(b.t_rowptr, b.t_col, z[:, d:], z[:, :d], src_scale=b.norm, accumulate=True, row_blocks=rb)
+            hip.spmm(b.rowptr, b.col, z[:, :d], z[:, d:], out_scale=b.norm, row_blocks=rb, prepared=prep if kern == 3 else None)
+            hip.spmm(b.t_rowptr, b.t_col, z[:, d:], z[:, :d], src_scale=b.norm, accumulate=True, row_blocks=rb,
+                     prepared=prep_t if kern == 3 else None)
         torch.cuda.synchronize()
 hip.tuning('spmm_kernel', 0)
 print('blocks', int(rb.numel()) - 1, 'rows', n)

@@ -567,7 +567,16 @@ def test_spmm_block_dense_exact_counts_and_order():
     assert np.array_equal(xt[:, d:].cpu().numpy(), want)
 
 
-def _spmm_blocked_case(hip, n, d, deg, hub, blocks):
+@pytest.mark.parametrize('n,d,deg,hub,blocks', [(2046, 4096, 64, 3000, 'parts'), (1000, 1024, 20, 0, 'uniform'),
+                                                (513, 256, 16, 700, 'oversize'), (300, 602, 8, 0, 'parts')])
+def test_spmm_prepared_blocks(hip, n, d, deg, hub, blocks):
+    """gist_spmm_blocks_prepare + gist_spmm_csr_prepared_f32 == the oracle (forward and backward form),
+    and bit-identical to the unprepared matrix-core kernel: the block structure built once per
+    graph is the one every workgroup would build for itself."""
+    _spmm_blocked_case(hip, n, d, deg, hub, blocks, prepared=True)
+
+
+def _spmm_blocked_case(hip, n, d, deg, hub, blocks, prepared=False):
     rs = np.random.RandomState(n + d)
     # locality: most edges inside chunks of ~100 rows
     m = n * deg
@@ -589,16 +598,27 @@ def _spmm_blocked_case(hip, n, d, deg, hub, blocks):
         rb = dev(np.array(cuts), torch.int32)
     rp, cl = dev(rowptr, torch.int32), dev(col, torch.int32)
     xt = dev(x)
-    hip.spmm(rp, cl, xt[:, :d], xt[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True)
+    prep = hip.spmm_prepare(rp, cl, rb) if prepared else None
+    hip.spmm(rp, cl, xt[:, :d], xt[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True, prepared=prep)
     ref = x.copy()
     ref[:, d:] = O.spmm_sum(rowptr, col, np.ascontiguousarray(x[:, :d]), out_scale=norm)
     close(xt, ref)
+    if prepared and d % 4 == 0 and d >= 1536:      # (the widths the prepared entry point takes) same arithmetic
+        x2 = dev(x)
+        hip.tuning('spmm_kernel', 2)
+        try:
+            hip.spmm(rp, cl, x2[:, :d], x2[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True)
+        finally:
+            hip.tuning('spmm_kernel', 0)
+        assert torch.equal(x2, xt)
     # backward form: src_scale + accumulate, reversed graph
     t_rp, t_cl = O.transpose_csr(rowptr, col)
     g = rs.randn(n, 2 * d).astype(np.float32)
     gt = dev(g)
-    hip.spmm(dev(t_rp, torch.int32), dev(t_cl, torch.int32), gt[:, d:], gt[:, :d],
-             src_scale=dev(norm), accumulate=True, row_blocks=rb, blocked=True)
+    trp, tcl = dev(t_rp, torch.int32), dev(t_cl, torch.int32)
+    prep_t = hip.spmm_prepare(trp, tcl, rb) if prepared else None
+    hip.spmm(trp, tcl, gt[:, d:], gt[:, :d], src_scale=dev(norm), accumulate=True, row_blocks=rb, blocked=True,
+             prepared=prep_t)
     dh = np.ascontiguousarray(g[:, :d])
     O.spmm_sum(t_rp, t_cl, g[:, d:], src_scale=norm, out=dh, accumulate=True)
     close(gt[:, :d], dh)
