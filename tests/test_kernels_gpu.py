@@ -519,7 +519,8 @@ def test_gemm_forced_configs(hip, tile, splits):
 
 
 @pytest.mark.parametrize('n,d,deg,hub', [(300, 602, 8, 0), (513, 256, 16, 700), (1000, 1024, 20, 0),
-                                         (2046, 4096, 64, 3000), (700, 130, 5, 0), (90, 12, 7, 0)])
+                                         (2046, 4096, 64, 3000), (700, 130, 5, 0), (90, 12, 7, 0),
+                                         (777, 300, 12, 0), (260, 2052, 9, 400)])       # ragged last column tile
 @pytest.mark.parametrize('blocks', ['uniform', 'parts', 'oversize'])
 @pytest.mark.parametrize('kernel', ['lds_gather', 'mfma_block_dense'])
 def test_spmm_blocked_lds(hip, n, d, deg, hub, blocks, kernel):
@@ -568,6 +569,7 @@ def test_spmm_block_dense_exact_counts_and_order():
 
 
 @pytest.mark.parametrize('n,d,deg,hub,blocks', [(2046, 4096, 64, 3000, 'parts'), (1000, 1024, 20, 0, 'uniform'),
+                                                (260, 2052, 9, 400, 'parts'), (1500, 1536, 30, 0, 'uniform'),
                                                 (513, 256, 16, 700, 'oversize'), (300, 602, 8, 0, 'parts')])
 def test_spmm_prepared_blocks(hip, n, d, deg, hub, blocks):
     """gist_spmm_blocks_prepare + gist_spmm_csr_prepared_f32 == the oracle (forward and backward form),
