@@ -1,4 +1,5 @@
-"""Dev tool: row-split (plain) vs LDS-staged SpMM on a Reddit-like
+"""Dev tool: row-split (plain) vs the blocked SpMM entry point (block-dense matrix-core kernel for
+D >= 1536, LDS gather kernel below; scripts/spmm_mf_probe.py separates the two) on a Reddit-like
 cluster batch; forward form (out_scale) and backward form (reversed CSR, src_scale, accumulate);
 also with the batch rows randomly permuted (no block locality: every neighbour cross-block)."""
 import os, sys, random
@@ -66,17 +67,19 @@ def run(tag, rowptr, col, t_rowptr, t_col, norm, blocks):
             t2 = timeit(lambda: call(row_blocks=blocks))
             e3 = (once(blocked=True) - ref).abs().max().item()
             t3 = timeit(lambda: call(blocked=True))
-            print('%s D=%4d %s: row-split %.1f us (%.0f GB/s) | LDS-staged, blocks = parts %.1f us '
-                  '(%.0f GB/s = %.3f of 8 TB/s) | LDS-staged, uniform 128-row blocks %.1f us | max |diff| vs '
+            print('%s D=%4d %s: row-split %.1f us (%.0f GB/s) | blocked, blocks = parts %.1f us '
+                  '(%.0f GB/s = %.3f of 8 TB/s) | blocked, uniform 128-row blocks %.1f us | max |diff| vs '
                   'row-split %.1e %.1e   [HIP-event time of one call from Python: includes ~15 us of launch path]'
                   % (tag, d, form, t0 * 1e3, alg / t0 / 1e6, t2 * 1e3, alg / t2 / 1e6,
                      alg / t2 / 1e6 / 8000, t3 * 1e3, e2, e3), flush=True)
         if d == 4096:
+            hip.tuning('spmm_kernel', 1)
             for R in (1, 2, 3, 4):
                 hip.tuning('spmm_split', R)
                 t = timeit(lambda: hip.spmm(rowptr, col, z[:, :d], z[:, d:], out_scale=norm, row_blocks=blocks))
-                print('   LDS-staged D=4096 fwd row_split=%d: %.1f us' % (R, t * 1e3), flush=True)
+                print('   LDS gather kernel D=4096 fwd row_split=%d: %.1f us' % (R, t * 1e3), flush=True)
             hip.tuning('spmm_split', 0)
+            hip.tuning('spmm_kernel', 0)
 
 
 run('clustered', b.rowptr, b.col, b.t_rowptr, b.t_col, b.norm, rb)
