@@ -791,7 +791,9 @@ extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *c
         // the Reddit-like batch: D = 4096 38 vs 57 us, 2048 29 vs 33, 1024 21 vs 16, 512 20 vs 12.
         // Tuning hook: 1 = always the LDS gather kernel, 2 = always the matrix-core kernel.
         const int want = (int)tune(GIST_TUNE_SPMM_KERNEL);
-        if (want == 2 || (want != 1 && d >= 1536))
+        // (uniform 128-row blocks -- row_blocks = NULL -- cut across the parts: too many neighbours fall
+        // outside a block for the dense product, the gather kernel degrades more gracefully there)
+        if (want == 2 || (want != 1 && d >= 1536 && row_blocks != nullptr))
             return launch_spmm_mfma(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
                                     accumulate, row_blocks, n_row_blocks, nullptr, st);
         return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
