@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 5 */
+int gist_abi_version(void);   /* currently 8 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
