@@ -449,7 +449,10 @@ static bool b3_shape_ok(int64_t m, int64_t n, int64_t k, double default_min_gflo
     return true;
 }
 bool b3_eligible(int64_t m, int64_t n, int64_t k) { return b3_shape_ok(m, n, k, 16.0); }
-bool b3_eligible_kept(int64_t m, int64_t n, int64_t k) { return b3_shape_ok(m, n, k, 4.0); }
+// (inside the step, operands split once per tensor: measured break-even between 8.6 GFLOP -- the h = 1024
+// projections, 0.595 vs 0.587 ms/step on the fp32 kernel -- and 10.1 GFLOP -- the layer-0 projections at
+// h = 2048, 1.071 vs 1.095)
+bool b3_eligible_kept(int64_t m, int64_t n, int64_t k) { return b3_shape_ok(m, n, k, 9.0); }
 
 static int64_t b3_operand_bytes(int64_t m, int64_t n, int64_t k) {
     return ceil_div((m + n) * b3_kpad(k) * 6 + 512, 256) * 256;

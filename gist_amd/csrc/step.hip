@@ -218,11 +218,15 @@ B3Step b3_layout(const gist_step_plan *p, char *base) {
         hl.Ws = take(o * b3_kpad(i2) * 6);
         hl.WsT = k > 0 ? take(i2 * b3_kpad(o) * 6) : nullptr;
         max_out = o > max_out ? o : max_out;
-        // (slice counts depend on the batch rows only through the tile count: sized at n_max, the
-        // launcher falls back to one slice if a smaller batch would need more slab than this)
-        int64_t sb = b3_slab_bytes(n, o, i2);
-        if (b3_slab_bytes(o, i2, n) > sb) sb = b3_slab_bytes(o, i2, n);
-        if (k > 0 && b3_slab_bytes(n, i2, o) > sb) sb = b3_slab_bytes(n, i2, o);
+        // split-K slabs: the slice count depends on the batch rows through the tile count, and a batch
+        // may have fewer rows than n_max (one 256-row tile less can double the slices): the largest
+        // need over every row count up to n_max (the launcher uses one slice if the slab is too small)
+        int64_t sb = 0;
+        for (int64_t rows = n; rows > 0; rows = (rows - 1) / 256 * 256) {
+            const int64_t need[3] = {b3_slab_bytes(rows, o, i2), b3_slab_bytes(o, i2, rows),
+                                     k > 0 ? b3_slab_bytes(rows, i2, o) : 0};
+            for (int q = 0; q < 3; ++q) sb = need[q] > sb ? need[q] : sb;
+        }
         if (sb > h.slab_bytes) h.slab_bytes = sb;
     }
     if (!h.any) return h;

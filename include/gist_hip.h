@@ -151,7 +151,7 @@ int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
  * workspaces).  Inputs, outputs and accumulation are fp32 in every mode, and small or skinny shapes
  * always run on v_mfma_f32_32x32x2_f32.
  *   Mode 2, bf16x3 (the default): shapes large enough to fill the chip (>= 128 workgroups of
- *     256 x 128 tiles x k slices, >= 16 GFLOP per call or >= 4 GFLOP inside gist_sage_step, workspace
+ *     256 x 128 tiles x k slices, >= 16 GFLOP per call or >= 9 GFLOP inside gist_sage_step, workspace
  *     of gist_gemm_workspace_bytes) carry each fp32 operand as three bf16 pieces, x = b1 + b2 + b3
  *     EXACTLY (3 x 8 = all 24 significant bits, fp32's exponent range, no scales), and accumulate
  *     the six leading cross terms in fp32 on v_mfma_f32_16x16x32_bf16; what is dropped is below one
@@ -401,7 +401,8 @@ typedef struct gist_step_plan {
      * upper bound of |feat| (0 = unknown: layer 0 then takes the per-call path).  A layer qualifies
      * when its three projections have >= 64 output tiles and >= 4 GFLOP each.  In mode 2 (bf16x3) the
      * same workspace holds the three-piece bf16 operands instead (6 bytes per element, no scales or
-     * maxima; a layer qualifies with >= 128 tiles of 256 x 128 and >= 4 GFLOP per projection).  Size
+     * maxima; a layer qualifies with >= 128 workgroups of 256 x 128 tiles x k slices and >= 9 GFLOP per
+     * projection).  Size
      * the workspace with gist_step_h3_workspace_bytes IN THE MODE the steps will run in; NULL / too
      * small / sized in another mode = per-call path. */
     int64_t n_max;
