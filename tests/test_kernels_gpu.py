@@ -578,6 +578,28 @@ def test_spmm_prepared_blocks(hip, n, d, deg, hub, blocks):
     _spmm_blocked_case(hip, n, d, deg, hub, blocks, prepared=True)
 
 
+def test_spmm_blocks_prepare_rejects_bad_buffers(hip):
+    """The prepared-block entry points fail loudly: a buffer smaller than gist_spmm_blocks_bytes, a
+    misaligned one, a missing one."""
+    from gist_amd import _lib
+    L = _lib.load()
+    rp = torch.arange(0, 301, dtype=torch.int32, device=DEV)
+    cl = torch.zeros(300, dtype=torch.int32, device=DEV)
+    need = L.gist_spmm_blocks_bytes(3)
+    assert need == 3 * (16 * 128 * 16 + 128 * 4 + 128 * 8 * 4)
+    buf = torch.empty(need + 16, dtype=torch.uint8, device=DEV)
+    assert L.gist_spmm_blocks_prepare(rp.data_ptr(), cl.data_ptr(), 300, None, 0, buf.data_ptr(), need - 1, None) < 0
+    assert b'buffer too small' in L.gist_last_error()
+    assert L.gist_spmm_blocks_prepare(rp.data_ptr(), cl.data_ptr(), 300, None, 0, buf.data_ptr() + 4, need, None) < 0
+    assert L.gist_spmm_blocks_prepare(rp.data_ptr(), cl.data_ptr(), 300, None, 0, None, need, None) < 0
+    assert L.gist_spmm_blocks_prepare(rp.data_ptr(), cl.data_ptr(), 300, None, 0, buf.data_ptr(), need, None) == 0
+    x = torch.zeros(300, 2048, device=DEV)
+    y = torch.zeros(300, 2048, device=DEV)
+    assert L.gist_spmm_csr_prepared_f32(rp.data_ptr(), cl.data_ptr(), x.data_ptr(), 2048, y.data_ptr(), 2048, 300,
+                                        2048, None, None, 0, None, 0, None, None) < 0
+    torch.cuda.synchronize()
+
+
 def _spmm_blocked_case(hip, n, d, deg, hub, blocks, prepared=False):
     rs = np.random.RandomState(n + d)
     # locality: most edges inside chunks of ~100 rows
