@@ -83,6 +83,8 @@ struct B3Dual {                       // one read of src[rows, cols] -> up to tw
     float p; uint64_t seed, offset;   // dropout applied on the fly (p = 0: none), gist_dropout_f32's stream
     uint16_t *dst_r;                  // [rows][kpad(cols)]: k = columns of src   (NULL: skip)
     uint16_t *dst_t;                  // [cols][kpad(rows)]: k = rows of src      (NULL: skip)
+    float *col_partials;              // [ceil(rows / 64)][cols] column sums per 64-row chunk of src (NULL: none):
+                                      // the first stage of gist_colsum_f32, taken from the tile the split reads anyway
     bool vec4;                        // set by b3_dual_split: 16-byte loads allowed
 };
 int b3_dual_split(const B3Dual &d, hipStream_t st);
@@ -112,6 +114,8 @@ int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t l
                    float *rowmax, hipStream_t st);
 int colsum_ex(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, float *out,
               float *pmax, float *outmax, hipStream_t st);
+// second stage alone: out[d] = sum over `chunks` rows of partials[chunks][d], fixed order
+int colsum_finish(const float *partials, int64_t chunks, int64_t d, float *out, hipStream_t st);
 
 // Tuning hooks (gist_tuning_set, include/gist_hip.h): explicit process-wide overrides of the
 // launchers' own choices, for sweeps and for tests that must reach both variants of a kernel.

@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256) void b3_dual_split_kernel(B3Dual d, int64_t ld
         tile[rr][c4 + 2] = v[2]; tile[rr][c4 + 3] = v[3];
     }
     __syncthreads();
+    // column sums of this 64-row chunk (rows past the end are zeros in the tile), fixed order
+    if (d.col_partials != nullptr && t < 64 && c0 + t < d.cols && r0 < d.rows) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; r += 4) {
+            s0 += tile[r][t]; s1 += tile[r + 1][t]; s2 += tile[r + 2][t]; s3 += tile[r + 3][t];
+        }
+        d.col_partials[(int64_t)blockIdx.y * d.cols + c0 + t] = (s0 + s1) + (s2 + s3);
+    }
     const int kb = t & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

@@ -695,6 +695,15 @@ int colsum_ex(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *par
 }
 }  // namespace gist
 
+namespace gist {
+int colsum_finish(const float *partials, int64_t chunks, int64_t d, float *out, hipStream_t st) {
+    if (d <= 0) return GIST_OK;
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(d, 64)), dim3(64), 0, st, partials,
+                       (int)chunks, (int)d, out, nullptr, nullptr);
+    return launch_status("gist_colsum_f32");
+}
+}  // namespace gist
+
 extern "C" int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int64_t d,
                                float *partials, float *out, gist_stream_t stream) {
     return gist::colsum_ex(g, ldg, n_rows, d, partials, out, nullptr, nullptr,

@@ -464,15 +464,16 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         if (b3.layer[k].on) {
             // bias gradient, then one read of dY_k -> both split layouts, dZ_k and dW_k on the splits
             const B3Layer &hl = b3.layer[k];
-            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
-            {
+            {   // (the split's 64 x 64 tiles also give the bias gradient's per-chunk column sums)
                 Scope sc(p->timer, 3, 0, 0, 0, st);
                 B3Dual d{};
                 d.src = dy; d.ld = lddy; d.rows = n; d.cols = l.n_out;
                 d.dst_r = k > 0 ? b3.dYs : nullptr;
                 d.dst_t = b3.dYsT;
+                d.col_partials = p->partials;
                 GIST_TRY(b3_dual_split(d, st));
             }
+            GIST_TRY(colsum_finish(p->partials, gist_colsum_partials(n), l.n_out, l.db, st));
             if (k > 0) {
                 Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
                 GIST_TRY(b3_gemm_presplit("gist_sage_step", b3.dYs, hl.WsT, nullptr, p->dZ, 2 * l.n_in, n,
