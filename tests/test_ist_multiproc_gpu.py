@@ -8,6 +8,7 @@ processes (no torchrun) and prints one JSON line.
 
 At most 5 processes use the GPU at once (this runner + 4 ranks)."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -80,3 +81,24 @@ def test_bench_starts_its_own_ranks(tmp_path):
     bad = subprocess.run(cmd + ['--n-hidden', '255'], env=env, capture_output=True, text=True,
                          timeout=600)
     assert bad.returncode != 0
+
+
+def test_bench_two_ranks_on_the_split_projection_path():
+    """Two rank processes at the metric's width (per-rank 2048: the bf16x3 projections with split-K, the
+    step's kept split operands, the prepared block-dense aggregation) with a weight exchange every 4
+    iterations: the sub-GCN weights are re-dispatched between steps, so the splits the step keeps must be
+    rebuilt from them every step.  Shared-GPU validation mode; finite losses, the split path really taken."""
+    env = dict(os.environ, GIST_BENCH_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '2',
+           '--n-hidden', '4096', '--iter-per-site', '4', '--timing-every', '2']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['config']['num_subnet'] == 2
+    assert out['dtype'].startswith('f32 (projection products from 3 bf16 pieces')
+    assert out['roofline']['kernel'].startswith('gist::gemm_b3_kernel') and out['roofline']['frac'] > 0.1
+    assert out['roofline_spmm']['kernel'].startswith('gist::spmm_csr_mfma_kernel')
+    assert math.isfinite(out['loss_first']) and math.isfinite(out['loss_last'])
+    assert out['weight_sync']['syncs_inside_timed_region'] >= 2
