@@ -53,7 +53,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STEPS_PER_EPOCH = 75
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
 MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA, dense
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak BW (spec)
@@ -64,10 +63,21 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=150)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--n-hidden', type=int, default=4096)
-    ap.add_argument('--n-layers', type=int, default=2)
+    ap.add_argument('--config', type=int, choices=[2, 3, 4, 5], default=None,
+                    help='BASELINE.json config preset (SURVEY.md section 8d).  2: Reddit-like hidden=256 L=4 on '
+                         '1 GPU (script/reddit/run_baseline_reddit.sh:6-8).  3: the default workload (Reddit-like '
+                         'H=4096 L=2, S = --gpus).  4: Amazon-like F=100 C=47, 15000 parts, batch 10, L=4, sync '
+                         'every 500 (script/amazon/run_ist_distrib_amazon.sh:16-18); H=4096 over 8 GPUs, or with '
+                         '--gpus 1 the per-rank sub-GCN (width 512) of that run.  5: Reddit-like ultra-wide '
+                         'H=32768 over 8 GPUs, or with --gpus 1 the per-rank sub-GCN (width 4096) plus the '
+                         'H=32768 S=8 weight exchange measured with 8 base replicas on this GPU.  Explicit '
+                         '--n-hidden / --n-layers / --dataset / --batch-parts / --iter-per-site override a preset')
+    ap.add_argument('--dataset', choices=['reddit-synth', 'amazon-synth'], default=None)
+    ap.add_argument('--batch-parts', type=int, default=None, help='METIS parts per cluster batch')
+    ap.add_argument('--n-hidden', type=int, default=None)
+    ap.add_argument('--n-layers', type=int, default=None)
     ap.add_argument('--dropout', type=float, default=0.2)
-    ap.add_argument('--iter-per-site', type=int, default=100)
+    ap.add_argument('--iter-per-site', type=int, default=None)
     ap.add_argument('--gemm-mode', choices=['f32', 'f16x3', 'bf16x3'], default='bf16x3',
                     help='products of the large projections behind `value`: three bf16 pieces per fp32 '
                          'operand = all 24 bits, six cross terms (default), v_mfma_f32_32x32x2_f32, or the '
@@ -83,7 +93,27 @@ def parse():
                     help='bracket the SpMM/GEMM launches of every N-th timed step with HIP events '
                          '(an event pair per launch serialises kernel boundaries: ~80 us/step '
                          'when every step is instrumented, i.e. it would depress `value`)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    # presets: the default invocation (no --config) is the metric's workload, unchanged
+    n = args.gpus
+    preset = {
+        None: dict(dataset='reddit-synth', batch_parts=20, n_hidden=4096, n_layers=2, iter_per_site=100),
+        3: dict(dataset='reddit-synth', batch_parts=20, n_hidden=4096, n_layers=2, iter_per_site=100),
+        2: dict(dataset='reddit-synth', batch_parts=20, n_hidden=256, n_layers=4, iter_per_site=100),
+        4: dict(dataset='amazon-synth', batch_parts=10, n_hidden=4096 if n > 1 else 4096 // 8, n_layers=4,
+                iter_per_site=500),
+        5: dict(dataset='reddit-synth', batch_parts=20, n_hidden=32768 if n > 1 else 32768 // 8, n_layers=2,
+                iter_per_site=100),
+    }[args.config]
+    args.emulated_rank_of = None          # N=1 run of one rank's sub-GCN of an 8-GPU config
+    if args.config in (4, 5) and n == 1 and args.n_hidden is None:
+        args.emulated_rank_of = 8
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.config == 2 and n != 1:
+        ap.error('--config 2 is the single-GPU baseline (cluster_gcn.py): use --gpus 1')
+    return args
 
 
 # --------------------------------------------------------------------------------------------
@@ -97,40 +127,118 @@ def _free_port():
     return port
 
 
-def launch_ranks(n):
+def launch_ranks(n, deadline_s=None):
     """Parent of a self-launched N-rank run: never imports torch, never touches the GPU.  One
     child per rank with the torchrun environment contract; children share stdout/stderr (rank
-    0 prints the JSON line).  Any child failing -> the others are terminated, exit code != 0."""
+    0 prints the JSON line).  Any child failing -> the others are terminated (SIGTERM, then SIGKILL
+    after a grace period), exit code != 0.  SIGTERM / SIGINT / SIGHUP to the parent, an exception in
+    it, or the overall deadline (GIST_BENCH_DEADLINE_S, default 3 h) take the children down the
+    same way: no rank process outlives the launcher."""
+    import signal
     port = os.environ.get('MASTER_PORT') or str(_free_port())
+    if deadline_s is None:
+        deadline_s = float(os.environ.get('GIST_BENCH_DEADLINE_S', '10800'))
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=env))
+
+    def stop_all(grace=5.0):
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                pass
+        for p in live:
+            if p.poll() is None:
+                try:
+                    p.kill()
+                except OSError:
+                    pass
+        for p in live:
+            try:
+                p.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pass
+
+    class _Signalled(Exception):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Signalled(signum)
+
+    previous = {}
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            previous[sig] = signal.signal(sig, on_signal)
+        except (ValueError, OSError):        # not the main thread
+            pass
+
+    def die_with_parent():
+        # the kernel delivers SIGTERM to the child if the launcher dies without running its handlers
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
     rc = 0
-    alive = list(procs)
-    while alive:
-        time.sleep(0.2)
-        for p in list(alive):
-            code = p.poll()
-            if code is None:
-                continue
-            alive.remove(p)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print('bench: rank process %d exited with %d; stopping the others'
-                      % (procs.index(p), code), file=sys.stderr, flush=True)
-                for q in alive:
-                    q.terminate()
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                       LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+            # GIST_BENCH_RANK_CMD (tests only): the rank program, so that the launcher's handling of
+            # hung / signal-ignoring ranks can be exercised without a GPU
+            cmd = ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+                   if not os.environ.get('GIST_BENCH_RANK_CMD')
+                   else [sys.executable, '-c', os.environ['GIST_BENCH_RANK_CMD']])
+            procs.append(subprocess.Popen(cmd, env=env, preexec_fn=die_with_parent))
+        t_dead = time.time() + deadline_s
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print('bench: rank process %d exited with %d; stopping the others'
+                          % (procs.index(p), code), file=sys.stderr, flush=True)
+                    stop_all()
+                    alive = []
+            if alive and time.time() > t_dead:
+                print('bench: deadline of %.0f s passed with %d rank processes still running; stopping them'
+                      % (deadline_s, len(alive)), file=sys.stderr, flush=True)
+                rc = rc or 124
+                stop_all()
+                alive = []
+    except _Signalled as e:
+        print('bench: signal %d; stopping the rank processes' % e.args[0], file=sys.stderr, flush=True)
+        rc = 128 + int(e.args[0])
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        stop_all()
+        for sig, h in previous.items():
+            try:
+                signal.signal(sig, h)
+            except (ValueError, OSError):
+                pass
     return rc
 
 
 # --------------------------------------------------------------------------------------------
 # CPU baseline (the oracle) -- the only place this file touches oracle/
 # --------------------------------------------------------------------------------------------
-def cpu_baseline(ds, par_order, dims, use_layernorm, p_drop, n_steps, seed, threads):
+def cpu_baseline(ds, par_order, dims, use_layernorm, p_drop, n_steps, seed, threads, batch_parts=20):
     """The oracle (oracle/gist_oracle.py, numpy + OpenBLAS + OpenMP C SpMM) on `threads` host
     threads, same workload: the first batches of the epoch, full step each (extraction, forward
     with dropout masks, CE, backward, Adam).  Returns the median step time of n_steps steps
@@ -156,7 +264,7 @@ def cpu_baseline(ds, par_order, dims, use_layernorm, p_drop, n_steps, seed, thre
         pools = sorted('%s:%d' % (p_.get('internal_api', '?'), p_.get('num_threads', 0))
                        for p_ in threadpool_info())
         for j in range(n_steps + warm):
-            ids = np.concatenate(par_order[j * 20:(j + 1) * 20]).astype(np.int64)
+            ids = np.concatenate(par_order[j * batch_parts:(j + 1) * batch_parts]).astype(np.int64)
             t0 = time.time()
             rpb, clb, trp, tcl, x, y = tg.batch(ids)
             masks = None
@@ -167,6 +275,73 @@ def cpu_baseline(ds, par_order, dims, use_layernorm, p_drop, n_steps, seed, thre
                          drop_masks=masks, drop_p=p_drop)
             times.append(time.time() - t0)
     return float(np.median(times[warm:])), pools
+
+
+def ultra_wide_exchange(dev, in_feats, n_classes, H, S, L, iter_per_site, reps=3):
+    """BASELINE config 5's weight exchange at FULL size on one GPU: S base replicas of the H-wide
+    model (8.8 GB each at H=32768) and S sub-GCNs in this process (ist.LocalCommGroup), HIP-event
+    times of ONE rank's device work per exchange: scatter of the S gathered sub arenas into its base
+    replica (sync_model minus the collective, cluster_gcn_ist_ultra_wide.py:143-248 keeps the base on
+    the host and stages every slice over PCIe) and the local gather of its next sub-model
+    (dispatch_model).  The all-gather itself needs S GPUs: its bytes are reported, its time is not."""
+    import argparse as _ap
+    import torch
+    from gist_amd import ist
+    from gist_amd.engine import dims_for
+    group = ist.LocalCommGroup(S)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    base_init = [((torch.rand(o, 2 * i, device=dev, generator=gen) * 2 - 1) / np.sqrt(2 * i),
+                  (torch.rand(o, device=dev, generator=gen) * 2 - 1) / np.sqrt(2 * i))
+                 for (i, o) in dims_for(in_feats, H, n_classes, L)]
+    models = []
+    for r in range(S):
+        ns = _ap.Namespace(num_subnet=S, n_hidden=H, n_layers=L, rank=r, dropout=0.0, use_layernorm=True)
+        models.append(ist.DistributedGNNWrapper(ns, None, in_feats, n_classes, dev,
+                                                base_init=base_init if r == 0 else None,
+                                                comm=group.handle(r)))
+    del base_init
+    rstate = random.getstate()
+    part = models[0].sample_partitions()
+    for m in models:
+        m.ini_sync_dispatch_model(part)
+    m0 = models[0]
+    t_gather, t_apply, t_disp = [], [], []
+    for _ in range(reps + 1):
+        part = models[0].sample_partitions()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for m in models[1:]:
+            m.sync_gather()
+        ev[0].record()
+        m0.sync_gather()                 # S device copies of the sub arenas (stand-in for the all-gather)
+        ev[1].record()
+        m0.sync_apply()
+        ev[2].record()
+        m0.dispatch_model(part)
+        ev[3].record()
+        for m in models[1:]:
+            m.sync_apply()
+            m.dispatch_model(part)
+        torch.cuda.synchronize(dev)
+        t_gather.append(ev[0].elapsed_time(ev[1]))
+        t_apply.append(ev[1].elapsed_time(ev[2]))
+        t_disp.append(ev[2].elapsed_time(ev[3]))
+    random.setstate(rstate)
+    P = m0.sub.numel
+    med = lambda v: float(np.median(v[1:]))
+    out = {
+        'n_hidden': H, 'num_subnet': S, 'n_layers': L,
+        'base_replica_bytes': int(4 * m0.base.numel), 'sub_arena_bytes': int(4 * P),
+        'sync_scatter_ms': round(med(t_apply), 4), 'dispatch_gather_ms': round(med(t_disp), 4),
+        'local_copy_of_gathered_arenas_ms': round(med(t_gather), 4),
+        'all_gather_bytes_per_rank': int(4 * P), 'all_gather_bytes_total': int(4 * P * S),
+        'amortized_device_ms_per_step': round((med(t_apply) + med(t_disp)) / iter_per_site, 5),
+        'measured': 'median of %d exchanges, HIP events, one rank\'s device work with %d base replicas + %d sub-GCNs '
+                    'resident on this GPU; the RCCL all-gather over xGMI is NOT measured here (needs %d GPUs)'
+                    % (reps, S, S, S),
+    }
+    del models, group
+    torch.cuda.empty_cache()
+    return out
 
 
 def host_cores():
@@ -253,16 +428,17 @@ def main():
     torch.manual_seed(seed)
     np.random.seed(seed)
     random.seed(seed)
-    ds = datasets.reddit_synth(seed=0)
+    ds = datasets.reddit_synth(seed=0) if args.dataset == 'reddit-synth' else datasets.amazon_synth(seed=1)
     g = ds.g
     in_feats, n_classes = g.ndata['feat'].shape[1], ds.num_classes
     train_nid = np.arange(g.number_of_nodes(), dtype=np.int64)
-    psize, batch_size = len(ds.par_li), 20
+    psize, batch_size = len(ds.par_li), args.batch_parts
+    STEPS_PER_EPOCH = psize // batch_size                      # sampler.py:54
     S = world
     H, L = args.n_hidden, args.n_layers
     assert H % S == 0
 
-    it = EngineClusterIter('reddit-synth', g, psize, batch_size, train_nid,
+    it = EngineClusterIter(ds.name, g, psize, batch_size, train_nid,
                            par_li=[p.copy() for p in ds.par_li], device=dev)
     first_epoch_order = [p.copy() for p in it.par_li]
     use_ln = True
@@ -431,9 +607,11 @@ def main():
 
     # ---- headline: W untimed warm-up steps, then exactly K timed steps ------------------------
     run_steps(args.warmup)
+    del sync_ms[:]                 # syncs of the warm-up are not part of the timed region
     timing = not args.no_kernel_timing
     elapsed_local, prof, timed_ids, n_log, loss_log = timed_region(args.steps, timing)
     n_sync_timed = len(sync_ms)
+    sync_timed = list(sync_ms)
 
     stats = torch.tensor([elapsed_local], dtype=torch.float64, device='cpu' if shared_gpu else dev)
     per_rank = [stats.clone() for _ in range(world)]
@@ -474,9 +652,15 @@ def main():
                         'max over ranks (HIP events)' % reps,
             'all_gather_bytes_per_rank': int(4 * P), 'all_gather_bytes_total': int(4 * P * world),
             'syncs_inside_timed_region': n_sync_timed,
-            'sync_ms_inside_timed_region': [round(a.elapsed_time(b_), 4) for a, b_ in sync_ms],
+            'sync_ms_inside_timed_region': [round(a.elapsed_time(b_), 4) for a, b_ in sync_timed],
             'amortized_ms_per_step': round((s_ms + d_ms) / args.iter_per_site, 5),
         }
+
+    # ---- --config 5 on one GPU: the H=32768, S=8 weight exchange, measured on this GPU ----------
+    uw_info = None
+    if args.config == 5 and world == 1 and args.emulated_rank_of:
+        uw_info = ultra_wide_exchange(dev, in_feats, n_classes, args.emulated_rank_of * H, args.emulated_rank_of,
+                                      L, args.iter_per_site)
 
     # ---- N=1: the same workload in the other GEMM modes, same process --------------------------
     legs = {}
@@ -512,6 +696,14 @@ def main():
             eff_mode = 'f32'
         out = {
             'metric': 'epochs/sec', 'value': round(value, 4), 'unit': 'epochs/s',
+            'epochs_per_sec_per_rank': round(value / world, 4),
+            'scaling_note': ('value = SUM over the %d ranks of each rank\'s epochs/s: under GIST every rank trains its '
+                             'OWN sub-GCN of width n_hidden/%d on the full batch stream for n_epochs/%d epochs '
+                             '(cluster_gcn_ist_distrib.py:385), so per-rank work SHRINKS as N grows and `value` at '
+                             'N>1 is not a speed-up of the N=1 model; compare epochs_per_sec_per_rank and '
+                             'per_rank_ms_per_step across N, and wall time per GIST epoch = 1 / epochs_per_sec_per_rank'
+                             % (world, world, world)) if world > 1 else
+                            'N=1: the full-width model on one GPU; value == epochs_per_sec_per_rank',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
@@ -536,14 +728,22 @@ def main():
                          'ah.bl + al.bh in fp32 -- narrower than fp32'}[eff_mode],
             'data': 'synthetic',
             'config': {
-                'workload': 'Reddit-like synthetic (N_train=153431, F=602, C=41, 1500 parts, '
-                            'batch=20 parts, 75 steps/epoch); GraphSAGE n_hidden=%d n_layers=%d '
+                'workload': '%s synthetic (N_train=%d, F=%d, C=%d, %d parts, '
+                            'batch=%d parts, %d steps/epoch); GraphSAGE n_hidden=%d n_layers=%d '
                             'LayerNorm dropout=%.2f Adam lr=0.01; %s' % (
+                                'Reddit-like' if args.dataset == 'reddit-synth' else 'Amazon-like',
+                                g.number_of_nodes(), in_feats, n_classes, psize, batch_size, STEPS_PER_EPOCH,
                                 H, L, args.dropout,
+                                ('ONE RANK of the %d-GPU GIST run of BASELINE config %d emulated on 1 GPU: its '
+                                 'sub-GCN of width %d (n_hidden %d / %d), no weight exchange in the timed region'
+                                 % (args.emulated_rank_of, args.config, H, H * args.emulated_rank_of,
+                                    args.emulated_rank_of)) if args.emulated_rank_of else
                                 'full-width model on 1 GPU (cluster_gcn.py path)' if S == 1 else
                                 'GIST %d sub-GCNs of width %d, sync every %d iters via one RCCL '
                                 'all-gather (cluster_gcn_ist_distrib.py path)'
                                 % (S, H // S, args.iter_per_site)),
+                'baseline_config': args.config if args.config is not None else 3,
+                'dataset': args.dataset,
                 'n_hidden': H, 'n_layers': L, 'num_subnet': S, 'batch_parts': batch_size,
                 'gemm_mode': args.gemm_mode if eff_mode == args.gemm_mode else
                              '%s requested; no projection of this width reaches its thresholds: every GEMM on the fp32 MFMA' % args.gemm_mode,
@@ -563,6 +763,8 @@ def main():
         }
         if sync_info is not None:
             out['weight_sync'] = sync_info
+        if uw_info is not None:
+            out['ultra_wide_exchange'] = uw_info
         if prof is not None:
             out['roofline'] = gemm_roofline(prof, elapsed_local, args.steps, eff_mode)
             # in-batch edge counts of the timed batches: re-extract them now, outside the timing
@@ -582,7 +784,7 @@ def main():
             copy_gbs = measured_copy_gbs(dev)
             n_instr = len(range(0, args.steps, every))
             out['roofline_spmm'] = {
-                'kernel': ('gist::spmm_csr_mfma_kernel (block-dense, wide layers)' if H // S >= 1536 else 'gist::spmm_csr_lds2_kernel (LDS gather, wide layers)') + '; gist::spmm_csr_rowsplit_kernel for the F=602 layer', 'bound': 'hbm', 'achieved': round(s_ach, 2),
+                'kernel': ('gist::spmm_csr_mfma_kernel (block-dense, wide layers)' if H // S >= 1536 else 'gist::spmm_csr_lds2_kernel (LDS gather, wide layers)') + '; gist::spmm_csr_rowsplit_kernel / spmm_csr_kernel for the F=%d input layer' % in_feats, 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
                 # achievable HBM bandwidth on this box: a 1 GiB device-to-device copy (read+write)
                 'peak_measured_copy': round(copy_gbs, 1),
@@ -599,16 +801,18 @@ def main():
             try:
                 ncpu = host_cores()
                 t_all, pools_all = cpu_baseline(ds, first_epoch_order, dims, use_ln, args.dropout,
-                                                args.cpu_steps, seed, ncpu)
+                                                args.cpu_steps, seed, ncpu, batch_size)
                 t_one, pools_one = cpu_baseline(ds, first_epoch_order, dims, use_ln, args.dropout,
-                                                3, seed, 1)
+                                                3, seed, 1, batch_size)
                 out['cpu_baseline'] = {
                     'value': round(1.0 / (STEPS_PER_EPOCH * t_all), 6), 'unit': 'epochs/s',
                     'cores': ncpu, 'kind': 'port', 'thread_pools': pools_all,
                     'sample': 'oracle (numpy/OpenBLAS + OpenMP C SpMM) full training step with '
                               'dropout masks on the first %d batches of the same workload after 1 '
-                              'warm-up step, %d threads, median %.3f s/step'
-                              % (args.cpu_steps, ncpu, t_all),
+                              'warm-up step, %d threads, median %.3f s/step (a bounded sample, not SURVEY 8d\'s '
+                              '>= 1 warm-up epoch + median of >= 3 epochs: an epoch of this step takes ~%d s on '
+                              'these cores)'
+                              % (args.cpu_steps, ncpu, t_all, int(t_all * STEPS_PER_EPOCH)),
                     'one_thread': {'value': round(1.0 / (STEPS_PER_EPOCH * t_one), 6),
                                    'unit': 'epochs/s', 'cores': 1, 'thread_pools': pools_one,
                                    'sample': 'same step, first 3 batches, 1 thread, no warm-up, median %.2f s/step' % t_one},

@@ -31,3 +31,76 @@ def test_launcher_is_not_used_under_torchrun_env():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def _ps_alive(pids):
+    out = []
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            # a zombie still answers kill(0): look at its state
+            with open('/proc/%d/stat' % pid) as f:
+                if f.read().split(')')[-1].split()[0] != 'Z':
+                    out.append(pid)
+        except (OSError, IOError):
+            pass
+    return out
+
+
+HANG = ("import os, signal, sys, time\n"
+        "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"       # a rank stuck in a collective ignores SIGTERM
+        "open(os.environ['PIDDIR'] + '/' + os.environ['RANK'], 'w').write(str(os.getpid()))\n"
+        "time.sleep(600)\n")
+
+
+def _launcher_env(tmp_path, **kw):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(GIST_BENCH_RANK_CMD=HANG, PIDDIR=str(tmp_path), **kw)
+    return env
+
+
+def _wait_pids(tmp_path, n, timeout=60):
+    import time
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        names = [f for f in os.listdir(str(tmp_path)) if f.isdigit()]
+        if len(names) == n:
+            pids = []
+            for f in names:
+                txt = open(os.path.join(str(tmp_path), f)).read()
+                if txt:
+                    pids.append(int(txt))
+            if len(pids) == n:
+                return pids
+        time.sleep(0.1)
+    raise AssertionError('rank processes did not start')
+
+
+def test_launcher_sigterm_kills_hung_ranks(tmp_path):
+    """SIGTERM to the launcher (a harness timeout) must not leave rank processes behind,
+    even ranks that ignore SIGTERM: terminate, grace period, kill; exit code 128+15."""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3'],
+                         env=_launcher_env(tmp_path), stderr=subprocess.PIPE, text=True)
+    pids = _wait_pids(tmp_path, 3)
+    assert len(_ps_alive(pids)) == 3
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err)
+    t0 = time.time()
+    while _ps_alive(pids) and time.time() - t0 < 10:
+        time.sleep(0.1)
+    assert _ps_alive(pids) == [], err
+
+
+def test_launcher_deadline_stops_hung_ranks(tmp_path):
+    """No rank ever exits (a deadlock): the launcher's own deadline ends the run with a non-zero code."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'],
+                       env=_launcher_env(tmp_path, GIST_BENCH_DEADLINE_S='3'), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr)
+    assert 'deadline' in r.stderr
+    pids = [int(open(os.path.join(str(tmp_path), f)).read()) for f in os.listdir(str(tmp_path)) if f.isdigit()]
+    assert len(pids) == 2 and _ps_alive(pids) == []
