@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GistLibraryError(RuntimeError):
@@ -76,6 +76,26 @@ SIGNATURES = {
     'gist_timer_count': (_i64, [_p]),
     'gist_timer_read': (_int, [_p, _i64, _p, _p, _p, _p, _p]),
     'gist_step_h3_workspace_bytes': (_i64, [_p]),
+    'gist_step_fused_workspace_bytes': (_i64, [_p]),
+    'gist_step_col_partials_floats': (_i64, [_p]),
+    'gist_step_fused_slab_bytes': (_i64, [_p, _i32]),
+    'gist_spmm_csr_drop_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _int, _f,
+                                      _u64, _u64, _u64, _i64, _p]),
+    'gist_spmm_drop_takes': (_int, [_int, _i64, _i64, _i64, _p, _p, _int]),
+    'gist_gemm_slabs_f32': (_int, [_int, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _p]),
+    'gist_ln_relu_fwd_drop_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _f, _f, _u64,
+                                         _u64, _i64, _p]),
+    'gist_row_chunks16': (_i64, [_i64]),
+    'gist_ln_relu_bwd_colsum_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p, _p]),
+    'gist_colsum_chunks_f32': (_int, [_p, _i64, _i64, _p, _p]),
+    'gist_gemm_nn_dropout_colsum_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _u64, _u64,
+                                               _p, _i64, _p, _p]),
+    'gist_softmax_xent_slabs_f32': (_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64,
+                                           _i64, _p]),
+    'gist_adam_segments_f32': (_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _i64, _p, _i64, _i64,
+                                      _p, _p]),
+    'gist_extract_batch_drop': (_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p,
+                                       _i64, _p, _p, _p, _i64, _f, _u64, _u64, _i64, _p]),
     'gist_sage_step': (_int, [_p, _p, _i64, _u64, _f, _f, _f, _f, _f, _i64, _int, _p]),
 }
 
@@ -107,7 +127,14 @@ class StepPlan(ctypes.Structure):
                 ('col_capacity', _i64), ('norm', _p), ('labels', _p), ('timer', _p),
                 ('n_max', _i64), ('feat_absmax', _f), ('h3_workspace', _p),
                 ('h3_workspace_bytes', _i64), ('row_blocks', _p), ('n_row_blocks', _i64),
-                ('spmm_prepared', _p), ('spmm_prepared_bytes', _i64)]
+                ('spmm_prepared', _p), ('spmm_prepared_bytes', _i64),
+                ('fuse', _i32), ('hsrc', _p * GIST_MAX_LAYERS), ('ld_hsrc', _i64 * GIST_MAX_LAYERS),
+                ('col_partials', _p), ('fused_workspace', _p), ('fused_workspace_bytes', _i64)]
+
+
+class GradSegment(ctypes.Structure):
+    """struct gist_grad_segment (include/gist_hip.h)."""
+    _fields_ = [('begin', _i64), ('end', _i64), ('src', _p), ('stride', _i64), ('n_src', _i32)]
 
 
 _lib = None

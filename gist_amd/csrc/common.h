@@ -92,10 +92,29 @@ int64_t b3_slab_bytes(int64_t m, int64_t n, int64_t k);   // fp32 slabs of a spl
 int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
                      int64_t ldc, int64_t m, int64_t n, int64_t k, float *slabs, int64_t slab_bytes,
                      hipStream_t st);
+// gemm.hip: gist_gemm_{nt,nn,tn}_f32 (layout 0, 1, 2) whose split-K partial sums stay as dense slabs
+// [*n_slabs][m][n] at `slabs` for the consumer to sum in slab order (+ bias); *n_slabs = 1: c is final
+int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, float *c,
+               int64_t ldc, int64_t m, int64_t n, int64_t k, void *slabs, int64_t slab_bytes, int *n_slabs,
+               hipStream_t st);
+int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k);
 // gemm.hip: c[m, n] (ldc) = sum of `splits` dense slabs [m][n] + bias
 int splitk_reduce(const char *name, const float *slabs, int64_t slab, int splits, const float *bias, float *c,
                   int64_t ldc, int64_t m, int64_t n, hipStream_t st);
 
+// spmm.hip: dropout folded into an aggregation (gist_spmm_csr_drop_f32); element (row, c) of y has mask
+// index y_base + row * ld + c, of x src_base + row * ld + c (sm = seed * golden ratio)
+struct SpmmDrop {
+    int mode;                 // 0 none, 1 forward (mask what is stored), 2 backward (mask x and the old y)
+    float p, scale;
+    uint64_t sm, y_base, src_base;
+    int64_t ld;
+};
+int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y, int64_t ldy,
+              int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale, int accumulate,
+              const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st);
+bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
+                     const int32_t *row_blocks);
 // spmm_mfma.hip: the block-dense aggregation kernel behind gist_spmm_csr_blocked_f32 / _prepared_f32
 // (prepared = NULL: every workgroup builds its block's counts itself)
 int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
@@ -116,6 +135,19 @@ int colsum_ex(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *par
               float *pmax, float *outmax, hipStream_t st);
 // second stage alone: out[d] = sum over `chunks` rows of partials[chunks][d], fixed order
 int colsum_finish(const float *partials, int64_t chunks, int64_t d, float *out, hipStream_t st);
+// rowops.hip: the fused producers of "column sums per 16-row chunk" and their consumers
+int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                       float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                       float *col_partials, hipStream_t st);
+int gemm_nn_dropout_ex(const char *name, const float *g, int64_t ldg, const float *w, int64_t ldw, float *z,
+                       int64_t ldz, int64_t m, int64_t n, int64_t k, float p, uint64_t seed, uint64_t offset,
+                       void *workspace, int64_t workspace_bytes, float *dy_col_partials, hipStream_t st);
+int softmax_xent_ex(const char *name, float *logits, int64_t ldl, const float *slabs, int64_t slab_stride,
+                    int n_slabs, const float *bias, const int32_t *labels, const uint8_t *mask, int64_t count,
+                    float *row_loss, float *loss, float *d_logits, int64_t ldg, int64_t n_rows,
+                    int64_t n_classes, hipStream_t st);
+int colsum_rows16(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, bool interleaved,
+                  hipStream_t st);
 
 // Tuning hooks (gist_tuning_set, include/gist_hip.h): explicit process-wide overrides of the
 // launchers' own choices, for sweeps and for tests that must reach both variants of a kernel.

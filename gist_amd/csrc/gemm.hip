@@ -679,10 +679,14 @@ static int launch_tile(const char *name, GemmArgs &g, bool aligned, int splits, 
     return launch_status(name);
 }
 
+// deferred != NULL: a split-K call leaves its partial sums as dense slabs [splits][m][n] at ws and does
+// NOT reduce them (the consumer sums them in slab order, + bias): *deferred = the slab count, or 1 when
+// c holds the finished result (bias included).
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const char *name, const float *a, int64_t lda, const float *b, int64_t ldb,
                        const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
-                       void *ws, int64_t ws_bytes, hipStream_t st) {
+                       void *ws, int64_t ws_bytes, hipStream_t st, int *deferred = nullptr) {
+    if (deferred) *deferred = 1;
     if (m < 0 || n < 0 || k < 0) { set_error("%s: negative size", name); return GIST_EINVAL; }
     if (m == 0 || n == 0) return GIST_OK;
     if (!a || !b || !c) { set_error("%s: null pointer", name); return GIST_EINVAL; }
@@ -723,6 +727,7 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     int rc = cfg.tile == 128 ? launch_tile<A_KC, B_KC, 128>(name, g, aligned, splits, st)
                              : launch_tile<A_KC, B_KC, 64>(name, g, aligned, splits, st);
     if (rc || splits == 1) return rc;
+    if (deferred) { *deferred = splits; return rc; }
     const int64_t total = m * n;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
                        st, static_cast<const float *>(ws), m * n, splits, bias, c, ldc, (int)m,
@@ -730,7 +735,46 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     return launch_status(name);
 }
 
+// slab bytes of the fp32 kernel's own split-K choice for this shape (0: one k slice)
+int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int sp = choose_cfg(m, n, k).splits;
+    return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
+}
+
+int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, float *c,
+               int64_t ldc, int64_t m, int64_t n, int64_t k, void *slabs, int64_t slab_bytes, int *n_slabs,
+               hipStream_t st) {
+    switch (layout) {
+        case 0:
+            GIST_REQUIRE(lda >= k && ldb >= k && ldc >= n, "gist_gemm_slabs_f32: leading dimension too small");
+            return launch_gemm<true, true>("gist_gemm_slabs_f32", a, lda, b, ldb, bias, c, ldc, m, n, k, slabs,
+                                           slab_bytes, st, n_slabs);
+        case 1:
+            GIST_REQUIRE(lda >= k && ldb >= n && ldc >= n, "gist_gemm_slabs_f32: leading dimension too small");
+            return launch_gemm<true, false>("gist_gemm_slabs_f32", a, lda, b, ldb, bias, c, ldc, m, n, k, slabs,
+                                            slab_bytes, st, n_slabs);
+        case 2:
+            GIST_REQUIRE(lda >= m && ldb >= n && ldc >= n, "gist_gemm_slabs_f32: leading dimension too small");
+            return launch_gemm<false, false>("gist_gemm_slabs_f32", a, lda, b, ldb, bias, c, ldc, m, n, k, slabs,
+                                             slab_bytes, st, n_slabs);
+    }
+    set_error("gist_gemm_slabs_f32: layout must be 0 (NT), 1 (NN) or 2 (TN)");
+    return GIST_EINVAL;
+}
+
 }  // namespace gist
+
+extern "C" int gist_gemm_slabs_f32(int layout, const float *a, int64_t lda, const float *b, int64_t ldb,
+                                   const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                                   void *slabs, int64_t slab_bytes, int32_t *n_slabs, gist_stream_t stream) {
+    GIST_REQUIRE(n_slabs != nullptr, "gist_gemm_slabs_f32: null n_slabs");
+    int ns = 1;
+    const int rc = gist::gemm_slabs(layout, a, lda, b, ldb, bias, c, ldc, m, n, k, slabs, slab_bytes, &ns,
+                                    gist::as_stream(stream));
+    *n_slabs = ns;
+    return rc;
+}
 
 #ifdef GIST_GEMM_TRACE
 extern "C" int gist_gemm_trace_read(unsigned long long *out, int64_t n_blocks) {

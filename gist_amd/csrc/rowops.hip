@@ -33,14 +33,55 @@ __device__ __forceinline__ float row_sum(float v, float *red) {
 }
 
 // ---------------------------------------------------------------------------
+// dropout's generator: counter based (splitmix64 finaliser of the seed-mixed element index); one hash
+// serves two consecutive elements (even index -> low word, odd -> high word)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float scale) {
+    const uint64_t h = splitmix64((idx >> 1) + seed * 0x9E3779B97F4A7C15ULL);
+    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+    const float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? scale : 0.f;
+}
+
+// the mask of gist_dropout_f32 for the 4 consecutive element indices idx0 .. idx0 + 3 (sm = seed *
+// golden ratio): two hashes when idx0 is even, three otherwise
+__device__ __forceinline__ void drop_quad(float4 &v, uint64_t idx0, uint64_t sm, float p, float scale) {
+    const float inv = 1.0f / 16777216.0f;
+    const uint64_t pair = idx0 >> 1;
+    const uint64_t h0 = splitmix64(pair + sm), h1 = splitmix64(pair + 1 + sm);
+    if ((idx0 & 1) == 0) {
+        v.x *= ((float)((uint32_t)h0 >> 8) * inv >= p) ? scale : 0.f;
+        v.y *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv >= p) ? scale : 0.f;
+        v.z *= ((float)((uint32_t)h1 >> 8) * inv >= p) ? scale : 0.f;
+        v.w *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv >= p) ? scale : 0.f;
+    } else {
+        const uint64_t h2 = splitmix64(pair + 2 + sm);
+        v.x *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv >= p) ? scale : 0.f;
+        v.y *= ((float)((uint32_t)h1 >> 8) * inv >= p) ? scale : 0.f;
+        v.z *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv >= p) ? scale : 0.f;
+        v.w *= ((float)((uint32_t)h2 >> 8) * inv >= p) ? scale : 0.f;
+    }
+}
+
+// Dropout folded into a producer (gist_ln_relu_fwd_drop_f32): what the producer stores at row r,
+// column c of `out` is multiplied by the mask gist_dropout_f32 would apply to element index
+// offset + r * mask_ld + c; the value before the mask goes to out2 (the aggregation's source).
+struct DropOut {
+    float *out2; int64_t ldo2;      // undropped copy (NULL: none)
+    float p, scale;                 // p = 0: no mask (out = the plain value)
+    uint64_t sm, offset;            // seed * golden ratio; counter base
+    int64_t mask_ld;
+};
+
+// ---------------------------------------------------------------------------
 // LayerNorm (no affine, biased variance) + ReLU, forward.  y <- yhat in place.
 // ---------------------------------------------------------------------------
-template <int TPR, int VEC>
+template <int TPR, int VEC, bool DROP = false>
 __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y, int64_t ldy,
                                                           float *__restrict__ out, int64_t ldo,
                                                           float *__restrict__ rstd_out,
                                                           int n_rows, int d, int use_lynorm,
-                                                          int relu, float eps) {
+                                                          int relu, float eps, DropOut dr) {
     __shared__ float red[4];
     constexpr int RPB = 256 / TPR;
     const int row = blockIdx.x * RPB + threadIdx.x / TPR;
@@ -48,6 +89,32 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y,
     const bool live = row < n_rows;
     float *yr = y + (int64_t)(live ? row : 0) * ldy;
     float *orow = out + (int64_t)(live ? row : 0) * ldo;
+    float *o2row = nullptr;
+    uint64_t ibase = 0;
+    if constexpr (DROP) {
+        if (dr.out2 != nullptr) o2row = dr.out2 + (int64_t)(live ? row : 0) * dr.ldo2;
+        ibase = dr.offset + (uint64_t)(live ? row : 0) * (uint64_t)dr.mask_ld;
+    }
+    // the store of one quad / element of the output row: plain, or undropped copy + masked value
+    auto put4 = [&](int c, float4 w) {
+        if constexpr (DROP) {
+            if (o2row != nullptr) *reinterpret_cast<float4 *>(o2row + c) = w;
+            if (dr.p > 0.f) drop_quad(w, ibase + (uint64_t)c, dr.sm, dr.p, dr.scale);
+        }
+        *reinterpret_cast<float4 *>(orow + c) = w;
+    };
+    auto put1 = [&](int c, float v) {
+        if constexpr (DROP) {
+            if (o2row != nullptr) o2row[c] = v;
+            if (dr.p > 0.f) {
+                const uint64_t idx = ibase + (uint64_t)c;
+                const uint64_t h = splitmix64((idx >> 1) + dr.sm);
+                const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+                v *= ((float)(w >> 8) * (1.0f / 16777216.0f) >= dr.p) ? dr.scale : 0.f;
+            }
+        }
+        orow[c] = v;
+    };
     float mean = 0.f, rstd = 1.f;
 #ifndef GIST_LN_STREAMING      // dev A/B build flag: always take the streaming path
     if constexpr (TPR == 256 && VEC == 4) {
@@ -90,7 +157,7 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y,
                 if (use_lynorm) *reinterpret_cast<float4 *>(yr + c) = w;
                 if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f);
                             w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
-                *reinterpret_cast<float4 *>(orow + c) = w;
+                put4(c, w);
             }
             return;
         }
@@ -133,12 +200,12 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y,
             if (use_lynorm) *reinterpret_cast<float4 *>(yr + c) = v;
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4 *>(orow + c) = v;
+            put4(c, v);
         } else {
             float v = (yr[c] - mean) * rstd;
             if (use_lynorm) yr[c] = v;
             if (relu) v = fmaxf(v, 0.f);
-            orow[c] = v;
+            put1(c, v);
         }
     }
 }
@@ -276,16 +343,161 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// dropout: counter based (splitmix64 finaliser of seed-mixed element index)
+// backward + bias-gradient partials in one pass (d <= 1024, 16-byte rows): a workgroup owns
+// kLnCsRows = 16 consecutive rows, wave w the rows r0 + w + 4 j (j = 0..3; all four read before the
+// first is reduced).  dy of a row is formed exactly as in ln_relu_bwd_kernel<64, 4>; every lane also
+// adds what it stores into per-column sums (rows in j order), the four waves' sums meet in LDS in wave
+// order, and the workgroup writes col_partials[blockIdx.x][0..d): the bias gradient is the sum of the
+// chunks' rows in chunk order (gist_adam_segments_f32 forms it; gist_colsum_chunks_f32 on its own).
+// U = ceil(d / 256) quads per lane.
 // ---------------------------------------------------------------------------
-// One hash serves two consecutive elements (even index -> low word, odd -> high word).
-__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p, float scale) {
-    const uint64_t h = splitmix64((idx >> 1) + seed * 0x9E3779B97F4A7C15ULL);
-    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
-    const float u = (float)(w >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? scale : 0.f;
+constexpr int kLnCsRows = 16;
+
+template <int U>
+__global__ __launch_bounds__(256) void ln_relu_bwd_cs_kernel(
+    const float *__restrict__ d_out, int64_t ldg, const float *yhat, int64_t ldy,
+    const float *__restrict__ rstd_in, float *dy, int64_t lddy, int n_rows, int d, int use_lynorm,
+    int relu, float *__restrict__ col_partials) {
+    __shared__ __attribute__((aligned(16))) float part[3][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * kLnCsRows;
+    float4 gq[4][U], yq[4][U];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r0 + wave + 4 * j;
+        const bool live = row < n_rows;
+        const float *gr = d_out + (int64_t)(live ? row : 0) * ldg;
+        const float *yr = yhat + (int64_t)(live ? row : 0) * ldy;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane * 4 + 256 * u;
+            const bool in = live && c < d;
+            gq[j][u] = in ? *reinterpret_cast<const float4 *>(gr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            yq[j][u] = in ? *reinterpret_cast<const float4 *>(yr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 cs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r0 + wave + 4 * j;
+        const bool live = row < n_rows;                      // wave-uniform
+        float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (relu) {
+                gq[j][u].x = yq[j][u].x > 0.f ? gq[j][u].x : 0.f; gq[j][u].y = yq[j][u].y > 0.f ? gq[j][u].y : 0.f;
+                gq[j][u].z = yq[j][u].z > 0.f ? gq[j][u].z : 0.f; gq[j][u].w = yq[j][u].w > 0.f ? gq[j][u].w : 0.f;
+            }
+        if (use_lynorm) {
+            float s1 = 0.f, s2 = 0.f;
+            if (live) {                                      // same per-lane order as ln_relu_bwd_kernel<64, 4>
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (lane * 4 + 256 * u < d) {
+                        const float4 g = gq[j][u], yv = yq[j][u];
+                        s1 += (g.x + g.y) + (g.z + g.w);
+                        s2 += (g.x * yv.x + g.y * yv.y) + (g.z * yv.z + g.w * yv.w);
+                    }
+            }
+            m1 = wave_sum(s1) / (float)d;
+            m2 = wave_sum(s2) / (float)d;
+            if (live) rstd = rstd_in[row];
+        }
+        if (!live) continue;
+        float *dr = dy + (int64_t)row * lddy;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane * 4 + 256 * u;
+            if (c >= d) break;
+            float4 o = gq[j][u];
+            if (use_lynorm) {
+                const float4 yv = yq[j][u];
+                o.x = rstd * (o.x - m1 - yv.x * m2); o.y = rstd * (o.y - m1 - yv.y * m2);
+                o.z = rstd * (o.z - m1 - yv.z * m2); o.w = rstd * (o.w - m1 - yv.w * m2);
+            }
+            *reinterpret_cast<float4 *>(dr + c) = o;
+            cs[u].x += o.x; cs[u].y += o.y; cs[u].z += o.z; cs[u].w += o.w;
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) *reinterpret_cast<float4 *>(&part[wave - 1][lane * 4 + 256 * u]) = cs[u];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *pr = col_partials + (int64_t)blockIdx.x * d;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane * 4 + 256 * u;
+            if (c >= d) break;
+            float4 o = cs[u];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 q = *reinterpret_cast<const float4 *>(&part[w][c]);
+                o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+            }
+            *reinterpret_cast<float4 *>(pr + c) = o;
+        }
+    }
 }
 
+// column sums of g per 16-row chunk, in the order of the fused producers: INTERLEAVED (the LayerNorm
+// backward: rows r0 + w + 4 j summed over j for w = 0..3, then ((w0 + w1) + w2) + w3) or sequential (the
+// class layer's dZ kernel).  Fallback producer for shapes the fused kernels do not take.
+template <bool INTERLEAVED>
+__global__ void colsum_rows16_kernel(const float *__restrict__ g, int64_t ldg, int n_rows, int d,
+                                     float *__restrict__ partials) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const int r0 = blockIdx.y * 16;
+    auto at = [&](int r) { return r < n_rows ? g[(int64_t)r * ldg + c] : 0.f; };
+    float out;
+    if constexpr (INTERLEAVED) {
+        float a[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            a[w] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[w] += at(r0 + w + 4 * j);
+        }
+        out = ((a[0] + a[1]) + a[2]) + a[3];
+    } else {
+        out = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out += at(r0 + r);
+    }
+    partials[(int64_t)blockIdx.y * d + c] = out;
+}
+
+// out[j] = the chunks' sum in the order gist_adam_segments_f32 forms it: four partial sums over the
+// chunks q, q + 4, ... (ascending), added in q order
+__global__ __launch_bounds__(256) void colsum_chunks_kernel(const float *__restrict__ partials, int chunks, int d,
+                                                           float *__restrict__ out) {
+    __shared__ float part[3][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + e;
+    float acc = 0.f;
+    if (c < d) {
+        int k = q;
+        for (; k + 28 < chunks; k += 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partials[(int64_t)(k + 4 * u) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; k < chunks; k += 4) acc += partials[(int64_t)k * d + c];
+    }
+    if (q > 0) part[q - 1][e] = acc;
+    __syncthreads();
+    if (q == 0 && c < d) out[c] = ((acc + part[0][e]) + part[1][e]) + part[2][e];
+}
+
+// ---------------------------------------------------------------------------
+// dropout: counter based (splitmix64 finaliser of seed-mixed element index)
+// ---------------------------------------------------------------------------
 // Fast path (d % 4 == 0, 16-B aligned rows, even offset): one thread = 4 consecutive
 // elements of one row = two hashes, one 16-B load and store, one 64-bit division.
 __global__ void dropout_vec4_kernel(float *__restrict__ z, int64_t ldz, int64_t n_rows, int64_t d,
@@ -331,7 +543,7 @@ __global__ void dropout_kernel(float *__restrict__ z, int64_t ldz, int64_t n_row
 __global__ __launch_bounds__(256) void narrow_nn_drop_kernel(
     const float *__restrict__ dy, int64_t lddy, const float *__restrict__ w, int64_t ldw,
     float *__restrict__ dz, int64_t lddz, int n_rows, int n_cols, int kc, float p, float scale,
-    uint64_t seed, uint64_t offset) {
+    uint64_t seed, uint64_t offset, float *__restrict__ dy_col_partials) {
     __shared__ __attribute__((aligned(16))) float sdy[64][16];
     const int r0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * 1024 + threadIdx.x * 4;
@@ -340,6 +552,13 @@ __global__ __launch_bounds__(256) void narrow_nn_drop_kernel(
         sdy[c][r] = (c < kc && r0 + r < n_rows) ? dy[(int64_t)(r0 + r) * lddy + c] : 0.f;
     }
     __syncthreads();
+    // column sums of this 16-row chunk of dy (the layer's bias gradient in 16-row chunks), rows in order
+    if (dy_col_partials != nullptr && blockIdx.x == 0 && threadIdx.x < kc) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += sdy[threadIdx.x][r];
+        dy_col_partials[(int64_t)blockIdx.y * kc + threadIdx.x] = sacc;
+    }
     if (c0 >= n_cols) return;
     float4 acc[16];
 #pragma unroll
@@ -474,16 +693,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// slabs != NULL: the logits are still the split-K partial sums of the class layer's projection (dense
+// [n_slabs][n_rows][n_classes]); the row's logits = slabs summed in slab order + bias are formed here
+// exactly as the split-K reduce pass would (gemm.hip) and stored to `logits` first.
 __global__ __launch_bounds__(256) void xent_grad_kernel(
-    const float *__restrict__ logits, int64_t ldl, const int32_t *__restrict__ labels,
+    float *logits, int64_t ldl, const int32_t *__restrict__ labels,
     const uint8_t *__restrict__ mask, float inv_count, float *__restrict__ d_logits, int64_t ldg,
-    float *__restrict__ row_nll, int n_rows, int n_classes) {
+    float *__restrict__ row_nll, int n_rows, int n_classes, const float *__restrict__ slabs,
+    int64_t slab_stride, int n_slabs, const float *__restrict__ bias) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const int lane = threadIdx.x & 63;
-    const float *lr = logits + (int64_t)row * ldl;
+    float *lr = logits + (int64_t)row * ldl;
     float *gr = d_logits + (int64_t)row * ldg;
     const bool on = mask ? mask[row] != 0 : true;
+    if (slabs != nullptr) {
+        for (int c = lane; c < n_classes; c += 64) {
+            const int64_t i = (int64_t)row * n_classes + c;
+            float sacc = 0.f;
+            for (int k = 0; k < n_slabs; ++k) sacc += slabs[k * slab_stride + i];
+            if (bias) sacc += bias[c];
+            lr[c] = sacc;                  // read back below by the same lane only
+        }
+    }
     float mx = -INFINITY;
     for (int c = lane; c < n_classes; c += 64) mx = fmaxf(mx, lr[c]);
     mx = wave_max(mx);
@@ -500,21 +732,23 @@ __global__ __launch_bounds__(256) void xent_grad_kernel(
     if (lane == 0) row_nll[row] = on ? -((lr[lab] - mx) - logf(se)) : 0.f;
 }
 
-// loss = inv_count * sum_i row_nll[i], fixed-order tree (deterministic)
-__global__ __launch_bounds__(1024) void xent_loss_kernel(const float *__restrict__ row_nll,
-                                                         int n_rows, float inv_count,
-                                                         float *__restrict__ loss) {
-    __shared__ float red[16];
+// loss = inv_count * sum_i row_nll[i] by one 256-thread workgroup, fixed-order tree (deterministic);
+// shared by xent_loss_kernel and the finishing block of adam_segments_kernel
+__device__ __forceinline__ void loss_reduce_256(const float *__restrict__ row_nll, int n_rows,
+                                                float inv_count, float *__restrict__ loss, float *red) {
     float s = 0.f;
-    for (int i = threadIdx.x; i < n_rows; i += 1024) s += row_nll[i];
+    for (int i = threadIdx.x; i < n_rows; i += 256) s += row_nll[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += red[w];
-        loss[0] = t * inv_count;
-    }
+    if (threadIdx.x == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_count;
+}
+
+__global__ __launch_bounds__(256) void xent_loss_kernel(const float *__restrict__ row_nll,
+                                                        int n_rows, float inv_count,
+                                                        float *__restrict__ loss) {
+    __shared__ float red[4];
+    loss_reduce_256(row_nll, n_rows, inv_count, loss, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -535,6 +769,127 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
         v[i] = vv;
         const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
         p[i] = pv - step_size * (mv / denom);
+    }
+}
+
+// Adam over the arena with DEFERRED gradient reductions (gist_adam_segments_f32): inside a listed
+// segment [begin, end) the gradient of element i is not grads[i] but the sum of n_src arrays
+// src[s * stride + (i - begin)] -- the split-K slabs of a weight-gradient projection, or the per-row-chunk
+// column sums of a bias gradient -- formed here (and written back to grads) instead of by a reduce launch
+// of its own.  A workgroup owns 1024 consecutive elements; the segments that touch its range are found
+// once per workgroup (uniform), so outside them the loop is adam_kernel's.
+//   * slab segments (few sources): summed inline in source order, four loads in flight;
+//   * chunk-sum segments (`ded`: many sources, few elements -- a bias gradient in 16-row chunks): the
+//     arena workgroups skip them and DEDICATED workgroups take 64 elements each, four threads per element
+//     over the sources q, q + 4, ... (eight loads in flight), the four partial sums added in q order
+//     (chunk_sum4: the order gist_colsum_chunks_f32 uses too) -- a thread that walked 128 chunks for each
+//     of its 4 elements set the kernel's duration (76 us at h = 512 against 6 for the plain kernel).
+// One more workgroup reduces the step's loss when row_nll != NULL.
+constexpr int kAdamMaxSegs = 2 * GIST_MAX_LAYERS;
+struct AdamSegs {
+    int n;
+    int n_src[kAdamMaxSegs];
+    int ded_first[kAdamMaxSegs];      // first dedicated workgroup of the segment (-1: inline)
+    int n_ded;                         // dedicated workgroups in total
+    int64_t begin[kAdamMaxSegs], end[kAdamMaxSegs], stride[kAdamMaxSegs];
+    const float *src[kAdamMaxSegs];
+};
+
+// sum over sources q, q + 4, q + 8, ... in ascending order (q = 0..3)
+__device__ __forceinline__ float chunk_partial4(const float *__restrict__ src, int64_t stride, int n_src, int q) {
+    float acc = 0.f;
+    int k = q;
+    for (; k + 28 < n_src; k += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(k + 4 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; k < n_src; k += 4) acc += src[(int64_t)k * stride];
+    return acc;
+}
+
+__device__ __forceinline__ void adam_update(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                            int64_t i, float gv, float beta1, float beta2, float eps, float wd,
+                                            float step_size, float inv_bc2_sqrt) {
+    const float pv = p[i];
+    if (wd != 0.f) gv = fmaf(wd, pv, gv);
+    const float mv = m[i] + (1.f - beta1) * (gv - m[i]);        // lerp_ like torch
+    const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
+    p[i] = pv - step_size * (mv / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_segments_kernel(
+    float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
+    float beta1, float beta2, float eps, float wd, float step_size, float inv_bc2_sqrt, AdamSegs segs,
+    const float *__restrict__ row_nll, int n_loss_rows, float inv_count, float *__restrict__ loss) {
+    __shared__ float red[4];
+    __shared__ float part[3][64];
+    const int64_t n_chunks = (n + 1023) / 1024;
+    if ((int64_t)blockIdx.x >= n_chunks) {
+        const int idx = (int)((int64_t)blockIdx.x - n_chunks);
+        if (idx >= segs.n_ded) {
+            if (row_nll != nullptr) loss_reduce_256(row_nll, n_loss_rows, inv_count, loss, red);
+            return;
+        }
+        int sg = -1;                                       // uniform: the segment this workgroup serves
+        for (int s = 0; s < segs.n; ++s)                   // (the last one that starts at or before idx)
+            if (segs.ded_first[s] >= 0 && segs.ded_first[s] <= idx &&
+                (sg < 0 || segs.ded_first[s] > segs.ded_first[sg]))
+                sg = s;
+        if (sg < 0) return;
+        const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const int64_t i = segs.begin[sg] + (int64_t)(idx - segs.ded_first[sg]) * 64 + e;
+        const bool live = i < segs.end[sg];
+        float acc = 0.f;
+        if (live) acc = chunk_partial4(segs.src[sg] + (i - segs.begin[sg]), segs.stride[sg], segs.n_src[sg], q);
+        if (q > 0) part[q - 1][e] = acc;
+        __syncthreads();
+        if (q == 0 && live) {
+            const float gv = ((acc + part[0][e]) + part[1][e]) + part[2][e];
+            g[i] = gv;
+            adam_update(p, m, v, i, gv, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        }
+        return;
+    }
+    const int64_t lo = (int64_t)blockIdx.x * 1024;
+    const int64_t hi = lo + 1024 < n ? lo + 1024 : n;
+    unsigned touch = 0;                                   // uniform: segments intersecting [lo, hi)
+    for (int s = 0; s < segs.n; ++s)
+        if (segs.begin[s] < hi && segs.end[s] > lo) touch |= 1u << s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = lo + threadIdx.x + 256 * u;
+        if (i >= hi) break;
+        float gv;
+        int sg = -1;
+        for (unsigned t = touch; t; t &= t - 1) {
+            const int s = __builtin_ctz(t);
+            if (i >= segs.begin[s] && i < segs.end[s]) sg = s;
+        }
+        if (sg >= 0) {
+            if (segs.ded_first[sg] >= 0) continue;        // a dedicated workgroup owns this element
+            const float *src = segs.src[sg] + (i - segs.begin[sg]);
+            const int64_t stride = segs.stride[sg];
+            const int ns = segs.n_src[sg];
+            float acc = 0.f;
+            int k = 0;
+            for (; k + 4 <= ns; k += 4) {                 // source order, four loads in flight
+                const float t0 = src[(int64_t)k * stride], t1 = src[(int64_t)(k + 1) * stride];
+                const float t2 = src[(int64_t)(k + 2) * stride], t3 = src[(int64_t)(k + 3) * stride];
+                acc += t0; acc += t1; acc += t2; acc += t3;
+            }
+            for (; k < ns; ++k) acc += src[(int64_t)k * stride];
+            gv = acc;
+            g[i] = acc;
+        } else {
+            gv = g[i];
+        }
+        adam_update(p, m, v, i, gv, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
     }
 }
 
@@ -569,25 +924,61 @@ __global__ __launch_bounds__(256) void argmax_correct_kernel(
 // ===========================================================================
 using namespace gist;
 
-extern "C" int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t ldo, float *rstd,
-                                    int64_t n_rows, int64_t d, int use_lynorm, int relu,
-                                    float eps, gist_stream_t stream) {
-    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_ln_relu_fwd_f32: negative size");
+namespace gist {
+static int ln_relu_fwd_ex(const char *name, float *y, int64_t ldy, float *out, int64_t ldo, float *rstd,
+                          int64_t n_rows, int64_t d, int use_lynorm, int relu, float eps,
+                          const DropOut *drop, hipStream_t st) {
+    if (n_rows < 0 || d < 0) { set_error("%s: negative size", name); return GIST_EINVAL; }
     if (n_rows == 0 || d == 0) return GIST_OK;
-    GIST_REQUIRE(y && out, "gist_ln_relu_fwd_f32: null pointer");
-    GIST_REQUIRE(ldy >= d && ldo >= d, "gist_ln_relu_fwd_f32: leading dimension < d");
-    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_ln_relu_fwd_f32: size >= 2^31");
-    const bool v4 = d % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out);
-    hipStream_t st = as_stream(stream);
+    if (!y || !out) { set_error("%s: null pointer", name); return GIST_EINVAL; }
+    if (ldy < d || ldo < d) { set_error("%s: leading dimension < d", name); return GIST_EINVAL; }
+    if (n_rows >= (1LL << 31) || d >= (1LL << 31)) { set_error("%s: size >= 2^31", name); return GIST_EINVAL; }
+    bool v4 = d % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out);
+    DropOut dr{};
+    const bool dropping = drop != nullptr && (drop->p > 0.f || drop->out2 != nullptr);
+    if (dropping) {
+        dr = *drop;
+        if (dr.out2 != nullptr) {
+            if (dr.ldo2 < d) { set_error("%s: leading dimension < d", name); return GIST_EINVAL; }
+            v4 = v4 && dr.ldo2 % 4 == 0 && aligned16(dr.out2);
+        }
+    }
     const bool wide = d > 1024;
     const unsigned grid = (unsigned)(wide ? n_rows : ceil_div(n_rows, 4));
-#define L(TPR, V)                                                                              \
-    hipLaunchKernelGGL((ln_relu_fwd_kernel<TPR, V>), dim3(grid), dim3(256), 0, st, y, ldy, out, \
-                       ldo, rstd, (int)n_rows, (int)d, use_lynorm, relu, eps)
+#define L(TPR, V)                                                                                   \
+    do {                                                                                            \
+        if (dropping)                                                                               \
+            hipLaunchKernelGGL((ln_relu_fwd_kernel<TPR, V, true>), dim3(grid), dim3(256), 0, st, y, \
+                               ldy, out, ldo, rstd, (int)n_rows, (int)d, use_lynorm, relu, eps, dr); \
+        else                                                                                        \
+            hipLaunchKernelGGL((ln_relu_fwd_kernel<TPR, V, false>), dim3(grid), dim3(256), 0, st, y, \
+                               ldy, out, ldo, rstd, (int)n_rows, (int)d, use_lynorm, relu, eps, dr); \
+    } while (0)
     if (wide) { if (v4) L(256, 4); else L(256, 1); }
     else { if (v4) L(64, 4); else L(64, 1); }
 #undef L
-    return launch_status("gist_ln_relu_fwd_f32");
+    return launch_status(name);
+}
+}  // namespace gist
+
+extern "C" int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t ldo, float *rstd,
+                                    int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                    float eps, gist_stream_t stream) {
+    return gist::ln_relu_fwd_ex("gist_ln_relu_fwd_f32", y, ldy, out, ldo, rstd, n_rows, d, use_lynorm, relu,
+                                eps, nullptr, gist::as_stream(stream));
+}
+
+extern "C" int gist_ln_relu_fwd_drop_f32(float *y, int64_t ldy, float *out, int64_t ldo, float *out2,
+                                         int64_t ldo2, float *rstd, int64_t n_rows, int64_t d,
+                                         int use_lynorm, int relu, float eps, float p, uint64_t seed,
+                                         uint64_t offset, int64_t mask_ld, gist_stream_t stream) {
+    GIST_REQUIRE(p >= 0.f && p < 1.f, "gist_ln_relu_fwd_drop_f32: p must be in [0,1)");
+    GIST_REQUIRE(mask_ld >= d || p == 0.f, "gist_ln_relu_fwd_drop_f32: mask_ld < d");
+    gist::DropOut dr{};
+    dr.out2 = out2; dr.ldo2 = ldo2; dr.p = p; dr.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+    dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.offset = offset; dr.mask_ld = mask_ld;
+    return gist::ln_relu_fwd_ex("gist_ln_relu_fwd_drop_f32", y, ldy, out, ldo, rstd, n_rows, d, use_lynorm,
+                                relu, eps, &dr, gist::as_stream(stream));
 }
 
 namespace gist {
@@ -623,6 +1014,69 @@ extern "C" int gist_ln_relu_bwd_f32(const float *d_out, int64_t ldg, const float
                                 nullptr, gist::as_stream(stream));
 }
 
+extern "C" int64_t gist_row_chunks16(int64_t n_rows) { return n_rows <= 0 ? 0 : gist::ceil_div(n_rows, 16); }
+
+namespace gist {
+int colsum_rows16(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, bool interleaved,
+                  hipStream_t st) {
+    if (n_rows <= 0 || d <= 0) return GIST_OK;
+    const dim3 grid((unsigned)ceil_div(d, 256), (unsigned)ceil_div(n_rows, 16));
+    if (interleaved)
+        hipLaunchKernelGGL(colsum_rows16_kernel<true>, grid, dim3(256), 0, st, g, ldg, (int)n_rows, (int)d, partials);
+    else
+        hipLaunchKernelGGL(colsum_rows16_kernel<false>, grid, dim3(256), 0, st, g, ldg, (int)n_rows, (int)d, partials);
+    return launch_status("gist_colsum_rows16");
+}
+
+// ln_relu_bwd_ex + col_partials [ceil(n_rows / 16)][d]: one kernel when d <= 1024 and the rows are
+// 16-byte aligned, else the plain backward followed by the chunk sums of dy (same format, same order)
+int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                       float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                       float *col_partials, hipStream_t st) {
+    GIST_REQUIRE(col_partials != nullptr, "gist_ln_relu_bwd_colsum_f32: null col_partials");
+    const bool v4 = d % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && aligned16(d_out) &&
+                    aligned16(yhat) && aligned16(dy) && aligned16(col_partials);
+    if (!(v4 && d <= 1024 && n_rows > 0 && d > 0 && d_out && yhat && dy && (!use_lynorm || rstd) &&
+          ldg >= d && ldy >= d && lddy >= d && n_rows < (1LL << 31) - 16)) {
+        const int rc = ln_relu_bwd_ex(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu,
+                                      nullptr, st);
+        if (rc != GIST_OK) return rc;
+        return colsum_rows16(dy, lddy, n_rows, d, col_partials, true, st);
+    }
+    const unsigned grid = (unsigned)ceil_div(n_rows, kLnCsRows);
+    const int U = (int)ceil_div(d, 256);
+#define L(UU)                                                                                         \
+    hipLaunchKernelGGL((ln_relu_bwd_cs_kernel<UU>), dim3(grid), dim3(256), 0, st, d_out, ldg, yhat, ldy, \
+                       rstd, dy, lddy, (int)n_rows, (int)d, use_lynorm, relu, col_partials)
+    switch (U) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 3: L(3); break;
+        default: L(4); break;
+    }
+#undef L
+    return launch_status("gist_ln_relu_bwd_colsum_f32");
+}
+}  // namespace gist
+
+extern "C" int gist_ln_relu_bwd_colsum_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
+                                           const float *rstd, float *dy, int64_t lddy, int64_t n_rows,
+                                           int64_t d, int use_lynorm, int relu, float *col_partials,
+                                           gist_stream_t stream) {
+    return gist::ln_relu_bwd_colsum(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu,
+                                    col_partials, gist::as_stream(stream));
+}
+
+extern "C" int gist_colsum_chunks_f32(const float *partials, int64_t chunks, int64_t d, float *out,
+                                      gist_stream_t stream) {
+    GIST_REQUIRE(chunks >= 0 && d >= 0, "gist_colsum_chunks_f32: negative size");
+    if (d == 0) return GIST_OK;
+    GIST_REQUIRE(out && (partials || chunks == 0), "gist_colsum_chunks_f32: null pointer");
+    hipLaunchKernelGGL(gist::colsum_chunks_kernel, dim3((unsigned)gist::ceil_div(d, 64)), dim3(256), 0,
+                       gist::as_stream(stream), partials, (int)chunks, (int)d, out);
+    return gist::launch_status("gist_colsum_chunks_f32");
+}
+
 extern "C" int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d, float p,
                                 uint64_t seed, uint64_t offset, gist_stream_t stream) {
     GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_dropout_f32: negative size");
@@ -643,26 +1097,47 @@ extern "C" int gist_dropout_f32(float *z, int64_t ldz, int64_t n_rows, int64_t d
     return launch_status("gist_dropout_f32");
 }
 
-extern "C" int gist_gemm_nn_dropout_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
-                                        float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
-                                        float p, uint64_t seed, uint64_t offset, void *workspace,
-                                        int64_t workspace_bytes, gist_stream_t stream) {
-    GIST_REQUIRE(p >= 0.f && p < 1.f, "gist_gemm_nn_dropout_f32: p must be in [0,1)");
-    GIST_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gist_gemm_nn_dropout_f32: negative size");
+namespace gist {
+// + dy_col_partials (NULL or [ceil(m / 16)][k]): column sums of g per 16-row chunk, rows in order
+int gemm_nn_dropout_ex(const char *name, const float *g, int64_t ldg, const float *w, int64_t ldw, float *z,
+                       int64_t ldz, int64_t m, int64_t n, int64_t k, float p, uint64_t seed, uint64_t offset,
+                       void *workspace, int64_t workspace_bytes, float *dy_col_partials, hipStream_t st) {
+    if (!(p >= 0.f && p < 1.f)) { set_error("%s: p must be in [0,1)", name); return GIST_EINVAL; }
+    if (m < 0 || n < 0 || k < 0) { set_error("%s: negative size", name); return GIST_EINVAL; }
     const bool narrow = k >= 1 && k <= 64 && m > 0 && n > 0 && g && w && z && n % 4 == 0 &&
                         ldw % 4 == 0 && ldz % 4 == 0 && aligned16(w) && aligned16(z) &&
                         (offset & 1) == 0 && ldg >= k && ldw >= n && ldz >= n &&
                         m < (1LL << 31) && n < (1LL << 31);
     if (!narrow) {      // any other shape: the projection kernel, then the mask in place
-        const int rc = gist_gemm_nn_f32(g, ldg, w, ldw, z, ldz, m, n, k, workspace, workspace_bytes, stream);
-        if (rc != GIST_OK || p == 0.f) return rc;
-        return gist_dropout_f32(z, ldz, m, n, p, seed, offset, stream);
+        int rc = gist_gemm_nn_f32(g, ldg, w, ldw, z, ldz, m, n, k, workspace, workspace_bytes, st);
+        if (rc == GIST_OK && p != 0.f) rc = gist_dropout_f32(z, ldz, m, n, p, seed, offset, st);
+        if (rc == GIST_OK && dy_col_partials != nullptr) rc = colsum_rows16(g, ldg, m, k, dy_col_partials, false, st);
+        return rc;
     }
-    hipLaunchKernelGGL(gist::narrow_nn_drop_kernel,
-                       dim3((unsigned)gist::ceil_div(n, 1024), (unsigned)gist::ceil_div(m, 16)), dim3(256),
-                       0, gist::as_stream(stream), g, ldg, w, ldw, z, ldz, (int)m, (int)n, (int)k, p,
-                       p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset);
-    return gist::launch_status("gist_gemm_nn_dropout_f32");
+    hipLaunchKernelGGL(narrow_nn_drop_kernel, dim3((unsigned)ceil_div(n, 1024), (unsigned)ceil_div(m, 16)),
+                       dim3(256), 0, st, g, ldg, w, ldw, z, ldz, (int)m, (int)n, (int)k, p,
+                       p > 0.f ? 1.0f / (1.0f - p) : 1.0f, seed, offset, dy_col_partials);
+    return launch_status(name);
+}
+}  // namespace gist
+
+extern "C" int gist_gemm_nn_dropout_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
+                                        float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                                        float p, uint64_t seed, uint64_t offset, void *workspace,
+                                        int64_t workspace_bytes, gist_stream_t stream) {
+    return gist::gemm_nn_dropout_ex("gist_gemm_nn_dropout_f32", g, ldg, w, ldw, z, ldz, m, n, k, p, seed,
+                                    offset, workspace, workspace_bytes, nullptr, gist::as_stream(stream));
+}
+
+extern "C" int gist_gemm_nn_dropout_colsum_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
+                                               float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                                               float p, uint64_t seed, uint64_t offset, void *workspace,
+                                               int64_t workspace_bytes, float *g_col_partials,
+                                               gist_stream_t stream) {
+    GIST_REQUIRE(g_col_partials != nullptr, "gist_gemm_nn_dropout_colsum_f32: null g_col_partials");
+    return gist::gemm_nn_dropout_ex("gist_gemm_nn_dropout_colsum_f32", g, ldg, w, ldw, z, ldz, m, n, k, p,
+                                    seed, offset, workspace, workspace_bytes, g_col_partials,
+                                    gist::as_stream(stream));
 }
 
 extern "C" int64_t gist_colsum_partials(int64_t n_rows) {
@@ -710,25 +1185,48 @@ extern "C" int gist_colsum_f32(const float *g, int64_t ldg, int64_t n_rows, int6
                            gist::as_stream(stream));
 }
 
+namespace gist {
+// slabs (NULL: logits hold the values) / loss (NULL: the caller reduces row_loss later, e.g. inside
+// gist_adam_segments_f32)
+int softmax_xent_ex(const char *name, float *logits, int64_t ldl, const float *slabs, int64_t slab_stride,
+                    int n_slabs, const float *bias, const int32_t *labels, const uint8_t *mask, int64_t count,
+                    float *row_loss, float *loss, float *d_logits, int64_t ldg, int64_t n_rows,
+                    int64_t n_classes, hipStream_t st) {
+    if (!(n_rows > 0 && n_classes > 0)) { set_error("%s: empty input", name); return GIST_EINVAL; }
+    if (!(logits && labels && d_logits && row_loss)) { set_error("%s: null pointer", name); return GIST_EINVAL; }
+    if (!(ldl >= n_classes && ldg >= n_classes)) { set_error("%s: leading dimension < n_classes", name); return GIST_EINVAL; }
+    if (count <= 0) { set_error("%s: count must be > 0", name); return GIST_EINVAL; }
+    if (!(n_rows < (1LL << 31) && ldg < (1LL << 31))) { set_error("%s: size >= 2^31", name); return GIST_EINVAL; }
+    if (slabs != nullptr && n_slabs < 1) { set_error("%s: n_slabs < 1", name); return GIST_EINVAL; }
+    const float inv = 1.0f / (float)count;
+    hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st, logits, ldl,
+                       labels, mask, inv, d_logits, ldg, row_loss, (int)n_rows, (int)n_classes, slabs,
+                       slab_stride, n_slabs, bias);
+    if (loss != nullptr)
+        hipLaunchKernelGGL(xent_loss_kernel, dim3(1), dim3(256), 0, st, row_loss, (int)n_rows, inv, loss);
+    return launch_status(name);
+}
+}  // namespace gist
+
 extern "C" int gist_softmax_xent_f32(const float *logits, int64_t ldl, const int32_t *labels,
                                      const uint8_t *mask, int64_t count, float *row_loss,
                                      float *loss, float *d_logits, int64_t ldg, int64_t n_rows,
                                      int64_t n_classes, gist_stream_t stream) {
-    GIST_REQUIRE(n_rows > 0 && n_classes > 0, "gist_softmax_xent_f32: empty input");
-    GIST_REQUIRE(logits && labels && loss && d_logits && row_loss,
-                 "gist_softmax_xent_f32: null pointer");
-    GIST_REQUIRE(ldl >= n_classes && ldg >= n_classes,
-                 "gist_softmax_xent_f32: leading dimension < n_classes");
-    GIST_REQUIRE(count > 0, "gist_softmax_xent_f32: count must be > 0");
-    GIST_REQUIRE(n_rows < (1LL << 31) && ldg < (1LL << 31), "gist_softmax_xent_f32: size >= 2^31");
-    hipStream_t st = as_stream(stream);
-    const float inv = 1.0f / (float)count;
-    hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st,
-                       logits, ldl, labels, mask, inv, d_logits, ldg, row_loss, (int)n_rows,
-                       (int)n_classes);
-    hipLaunchKernelGGL(xent_loss_kernel, dim3(1), dim3(1024), 0, st, row_loss, (int)n_rows, inv,
-                       loss);
-    return launch_status("gist_softmax_xent_f32");
+    GIST_REQUIRE(loss != nullptr, "gist_softmax_xent_f32: null pointer");
+    return gist::softmax_xent_ex("gist_softmax_xent_f32", const_cast<float *>(logits), ldl, nullptr, 0, 0,
+                                 nullptr, labels, mask, count, row_loss, loss, d_logits, ldg, n_rows,
+                                 n_classes, gist::as_stream(stream));
+}
+
+extern "C" int gist_softmax_xent_slabs_f32(float *logits, int64_t ldl, const float *slabs,
+                                           int64_t slab_stride, int64_t n_slabs, const float *bias,
+                                           const int32_t *labels, const uint8_t *mask, int64_t count,
+                                           float *row_loss, float *loss, float *d_logits, int64_t ldg,
+                                           int64_t n_rows, int64_t n_classes, gist_stream_t stream) {
+    GIST_REQUIRE(n_slabs >= 0 && n_slabs < 4096, "gist_softmax_xent_slabs_f32: bad n_slabs");
+    return gist::softmax_xent_ex("gist_softmax_xent_slabs_f32", logits, ldl, n_slabs > 0 ? slabs : nullptr,
+                                 slab_stride, (int)n_slabs, bias, labels, mask, count, row_loss, loss,
+                                 d_logits, ldg, n_rows, n_classes, gist::as_stream(stream));
 }
 
 extern "C" int gist_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
@@ -748,6 +1246,51 @@ extern "C" int gist_adam_f32(float *param, const float *grad, float *exp_avg, fl
                        exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size,
                        inv_bc2_sqrt);
     return launch_status("gist_adam_f32");
+}
+
+extern "C" int gist_adam_segments_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                                      int64_t n, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, int64_t step, const gist_grad_segment *segments,
+                                      int64_t n_segments, const float *row_loss, int64_t n_loss_rows,
+                                      int64_t loss_count, float *loss, gist_stream_t stream) {
+    GIST_REQUIRE(n >= 0, "gist_adam_segments_f32: n < 0");
+    GIST_REQUIRE(n_segments >= 0 && n_segments <= gist::kAdamMaxSegs, "gist_adam_segments_f32: too many segments");
+    GIST_REQUIRE(n_segments == 0 || segments != nullptr, "gist_adam_segments_f32: null segments");
+    GIST_REQUIRE(row_loss == nullptr || (loss != nullptr && loss_count > 0 && n_loss_rows >= 0 &&
+                                         n_loss_rows < (1LL << 31)),
+                 "gist_adam_segments_f32: bad loss arguments");
+    if (n == 0 && row_loss == nullptr) return GIST_OK;
+    GIST_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), "gist_adam_segments_f32: null pointer");
+    GIST_REQUIRE(step >= 1, "gist_adam_segments_f32: step is 1-based");
+    gist::AdamSegs sg{};
+    for (int64_t i = 0; i < n_segments; ++i) {
+        const gist_grad_segment &q = segments[i];
+        if (q.src == nullptr || q.end <= q.begin) continue;
+        GIST_REQUIRE(q.begin >= 0 && q.end <= n && q.n_src >= 1 && q.stride >= q.end - q.begin,
+                     "gist_adam_segments_f32: bad segment %d", (int)i);
+        for (int j = 0; j < sg.n; ++j)
+            GIST_REQUIRE(q.end <= sg.begin[j] || q.begin >= sg.end[j], "gist_adam_segments_f32: overlapping segments");
+        sg.begin[sg.n] = q.begin; sg.end[sg.n] = q.end; sg.stride[sg.n] = q.stride;
+        sg.n_src[sg.n] = q.n_src; sg.src[sg.n] = q.src;
+        // many sources, few elements (a bias gradient in row chunks): dedicated workgroups of 64 elements
+        sg.ded_first[sg.n] = -1;
+        if (q.n_src > 16 && q.end - q.begin <= 65536) {
+            sg.ded_first[sg.n] = sg.n_ded;
+            sg.n_ded += (int)gist::ceil_div(q.end - q.begin, 64);
+        }
+        ++sg.n;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const int64_t chunks = gist::ceil_div(n, 1024);
+    GIST_REQUIRE(chunks < (1LL << 31) - 2, "gist_adam_segments_f32: arena too large");
+    hipLaunchKernelGGL(gist::adam_segments_kernel, dim3((unsigned)(chunks + sg.n_ded + (row_loss ? 1 : 0))), dim3(256), 0,
+                       gist::as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
+                       weight_decay, step_size, inv_bc2_sqrt, sg, row_loss, (int)n_loss_rows,
+                       row_loss ? 1.0f / (float)loss_count : 0.f, loss);
+    return gist::launch_status("gist_adam_segments_f32");
 }
 
 extern "C" int gist_argmax_correct_i32(const float *logits, int64_t ldl, const int32_t *labels,

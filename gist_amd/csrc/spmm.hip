@@ -48,13 +48,43 @@ __device__ __forceinline__ void vstore(float *p, const float (&v)[VEC]) {
 
 constexpr int kSpmmWavesPerBlock = 4;
 
-template <int VEC, int LPR>
+// gist_dropout_f32's mask applied where a value is produced or consumed instead of by a pass of its own
+// (gist_spmm_csr_drop_f32): element (row, c) of the operand has mask index base + row * ld + c.
+//   mode 1 (forward):  what the aggregation stores to y is multiplied by y's mask;
+//   mode 2 (backward): x is read through its mask (base = src_base) and the old y of the `y +=` through
+//                      y's -- the aggregation of a gradient whose dropout pass has not run.
+__device__ __forceinline__ float drop_keep(uint64_t idx, uint64_t sm, float p, float scale) {
+    const uint64_t h = splitmix64((idx >> 1) + sm);
+    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+    return ((float)(w >> 8) * (1.0f / 16777216.0f) >= p) ? scale : 0.f;
+}
+template <int VEC>
+__device__ __forceinline__ void drop_vec(float (&v)[VEC], uint64_t idx0, const SpmmDrop &dr) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] *= drop_keep(idx0 + k, dr.sm, dr.p, dr.scale);
+}
+__device__ __forceinline__ void drop_f4(float4 &v, uint64_t idx0, const SpmmDrop &dr) {
+    const float inv = 1.0f / 16777216.0f;
+    if ((idx0 & 1) == 0) {                 // the usual case: two hashes cover the quad
+        const uint64_t pair = idx0 >> 1;
+        const uint64_t h0 = splitmix64(pair + dr.sm), h1 = splitmix64(pair + 1 + dr.sm);
+        v.x *= ((float)((uint32_t)h0 >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+        v.y *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+        v.z *= ((float)((uint32_t)h1 >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+        v.w *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+    } else {
+        v.x *= drop_keep(idx0, dr.sm, dr.p, dr.scale); v.y *= drop_keep(idx0 + 1, dr.sm, dr.p, dr.scale);
+        v.z *= drop_keep(idx0 + 2, dr.sm, dr.p, dr.scale); v.w *= drop_keep(idx0 + 3, dr.sm, dr.p, dr.scale);
+    }
+}
+
+template <int VEC, int LPR, bool DROP = false>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int n_rows, int d, const float *__restrict__ out_scale,
     const float *__restrict__ src_scale, int accumulate, int n_row_blocks,
-    int n_col_tiles, int xcd_tiles) {
+    int n_col_tiles, int xcd_tiles, SpmmDrop dr) {
     constexpr int G = kWave / LPR;
     // ---- block -> (row block, column tile) -------------------------------
     int rb, ct;
@@ -160,6 +190,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 #pragma unroll
             for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
         }
+        if constexpr (DROP) drop_vec<VEC>(o, dr.y_base + (uint64_t)row * (uint64_t)dr.ld + (uint64_t)c0, dr);
         vstore<VEC>(yp, o);
     }
 }
@@ -179,12 +210,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // half starts 2408 bytes into a 4816-byte row.  Sources are still gathered 16 bytes per lane (the
 // last lane of a row reads two floats past d, inside the row pitch, and never stores them);
 // the result leaves as two 8-byte stores.
-template <int VEC, bool HALF = false>
+template <int VEC, bool HALF = false, bool DROP = false>
 __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int n_rows, int d, const float *__restrict__ out_scale,
-    const float *__restrict__ src_scale, int accumulate, int n_col_tiles, int chunk_rows) {
+    const float *__restrict__ src_scale, int accumulate, int n_col_tiles, int chunk_rows, SpmmDrop dr) {
     static_assert(!HALF || VEC == 4, "HALF is the 16-byte-load / 8-byte-store variant");
     __shared__ float part[3][kWave * VEC];
     // Row chunks (~ one METIS part: consecutive batch rows whose neighbours are mostly in the
@@ -261,6 +292,11 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
             }
             lo[0] = fmaf(os, acc[0], lo[0]); lo[1] = fmaf(os, acc[1], lo[1]);
             hi[0] = fmaf(os, acc[2], hi[0]); hi[1] = fmaf(os, acc[3], hi[1]);
+            if constexpr (DROP) {
+                const uint64_t i0 = dr.y_base + (uint64_t)row * (uint64_t)dr.ld + (uint64_t)c0;
+                drop_vec<2>(lo, i0, dr);
+                drop_vec<2>(hi, i0 + 2, dr);
+            }
             vstore<2>(yp, lo);
             if (upper) vstore<2>(yp + 2, hi);
         } else {
@@ -273,6 +309,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit_kernel(
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = os * acc[k];
             }
+            if constexpr (DROP) drop_vec<VEC>(o, dr.y_base + (uint64_t)row * (uint64_t)dr.ld + (uint64_t)c0, dr);
             vstore<VEC>(yp, o);
         }
     }
@@ -331,6 +368,7 @@ struct L2Args {
     int accumulate;
     const int32_t *row_blocks;
     int n_blocks, n_col_tiles, row_split;
+    SpmmDrop dr;
 };
 
 #ifdef L2_PROBE_NO_LDS
@@ -370,8 +408,10 @@ __device__ __forceinline__ void l2_local(const unsigned char *tb, int cnt, int o
 
 // Cross-block neighbours of a chunk: lanes in rmask hold the id `u` and scale `us` of one; 4 row
 // reads from global memory in flight (the mask is wave-uniform).
+template <bool SRC_DROP>
 __device__ __forceinline__ void l2_remote(const float *xc, int64_t ldx, bool active,
-                                          unsigned long long rmask, int u, float us, float (&acc)[4]) {
+                                          unsigned long long rmask, int u, float us, float (&acc)[4],
+                                          const SpmmDrop &dr, int c0) {
     while (rmask) {
         float4 rv[4];
         float rs[4];
@@ -385,7 +425,11 @@ __device__ __forceinline__ void l2_remote(const float *xc, int64_t ldx, bool act
                                                             __builtin_bit_cast(int, us), j));
             rs[t] = on ? s0 : 0.f;
             rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (on && active) rv[t] = *reinterpret_cast<const float4 *>(xc + (int64_t)uu * ldx);
+            if (on && active) {
+                rv[t] = *reinterpret_cast<const float4 *>(xc + (int64_t)uu * ldx);
+                if constexpr (SRC_DROP)
+                    drop_f4(rv[t], dr.src_base + (uint64_t)uu * (uint64_t)dr.ld + (uint64_t)c0, dr);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -395,6 +439,7 @@ __device__ __forceinline__ void l2_remote(const float *xc, int64_t ldx, bool act
     }
 }
 
+template <int DROP>      // 0 none, 1 mask on what is stored (forward), 2 masks on x and on the old y (backward)
 __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // ---- workgroup -> unit: units of one block stay on one XCD (blocks b, b + 8, .. share one)
@@ -455,6 +500,8 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
         for (int t = 0; t < kL2Pre; ++t) {
             const int r = wave + t * kL2Waves;
             if (r < nloc) {
+                if constexpr (DROP == 2)
+                    if (active) drop_f4(v[t], a.dr.src_base + (uint64_t)(r0 + r) * (uint64_t)a.dr.ld + (uint64_t)c0, a.dr);
                 v[t].x *= sc[t]; v[t].y *= sc[t]; v[t].z *= sc[t]; v[t].w *= sc[t];
                 *reinterpret_cast<float4 *>(tb + (r << 10)) = v[t];
             }
@@ -507,19 +554,24 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
         if (!rmask) return;
         if (staged) u = rem ? a.col[base + lane] : r0;
         const float us = (rem && a.src_scale) ? a.src_scale[u] : 1.f;
-        l2_remote(xc, a.ldx, active, rmask, u, us, acc);
+        l2_remote<DROP == 2>(xc, a.ldx, active, rmask, u, us, acc, a.dr, c0);
     };
     auto store = [&](int lr, float4 prev, float sx, float sy, float sz, float sw) {
         if (!active) return;
         const int row = r0 + lr;
         const float os = lr < nloc ? rsc[lr] : (a.out_scale ? a.out_scale[row] : 1.f);
         float4 *yp = reinterpret_cast<float4 *>(a.y + (int64_t)row * a.ldy + c0);
-        *yp = make_float4(fmaf(os, sx, prev.x), fmaf(os, sy, prev.y), fmaf(os, sz, prev.z),
-                          fmaf(os, sw, prev.w));
+        float4 o = make_float4(fmaf(os, sx, prev.x), fmaf(os, sy, prev.y), fmaf(os, sz, prev.z),
+                               fmaf(os, sw, prev.w));
+        if constexpr (DROP == 1) drop_f4(o, a.dr.y_base + (uint64_t)row * (uint64_t)a.dr.ld + (uint64_t)c0, a.dr);
+        *yp = o;
     };
     auto previous = [&](int lr) {                          // y's old value, read early (accumulate)
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.accumulate && active) p = *reinterpret_cast<const float4 *>(a.y + (int64_t)(r0 + lr) * a.ldy + c0);
+        if (a.accumulate && active) {
+            p = *reinterpret_cast<const float4 *>(a.y + (int64_t)(r0 + lr) * a.ldy + c0);
+            if constexpr (DROP == 2) drop_f4(p, a.dr.y_base + (uint64_t)(r0 + lr) * (uint64_t)a.dr.ld + (uint64_t)c0, a.dr);
+        }
         return p;
     };
 
@@ -631,7 +683,11 @@ __global__ void in_degree_norm_kernel(const int32_t *__restrict__ rowptr, int64_
 template <int VEC, bool HALF = false>
 static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
-                       const float *src_scale, int accumulate, hipStream_t st) {
+                       const float *src_scale, int accumulate, hipStream_t st,
+                       const SpmmDrop *drop = nullptr) {
+    const bool dropping = drop != nullptr && drop->mode == 1 && drop->p > 0.f;
+    SpmmDrop dr{};
+    if (dropping) dr = *drop;
     const int lanes = (int)ceil_div(d, VEC);
     int lpr = 8;
     while (lpr < 64 && lpr < lanes) lpr <<= 1;
@@ -646,9 +702,14 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
             set_error("gist_spmm_csr_f32: grid too large");
             return GIST_EINVAL;
         }
-        hipLaunchKernelGGL((spmm_csr_rowsplit_kernel<VEC, HALF>), dim3((unsigned)g2), dim3(256), 0,
-                           st, rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,
-                           src_scale, accumulate, n_col_tiles, chunk_rows);
+        if (dropping)
+            hipLaunchKernelGGL((spmm_csr_rowsplit_kernel<VEC, HALF, true>), dim3((unsigned)g2), dim3(256), 0,
+                               st, rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,
+                               src_scale, accumulate, n_col_tiles, chunk_rows, dr);
+        else
+            hipLaunchKernelGGL((spmm_csr_rowsplit_kernel<VEC, HALF, false>), dim3((unsigned)g2), dim3(256), 0,
+                               st, rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,
+                               src_scale, accumulate, n_col_tiles, chunk_rows, dr);
         return launch_status("gist_spmm_csr_f32");
     }
     const int64_t grid = xcd_tiles ? (int64_t)kXcds * ceil_div(n_col_tiles, kXcds) * n_row_blocks
@@ -657,10 +718,17 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
         set_error("gist_spmm_csr_f32: grid too large");
         return GIST_EINVAL;
     }
-#define GIST_SPMM_LAUNCH(L)                                                                   \
-    hipLaunchKernelGGL((spmm_csr_kernel<VEC, L>), dim3((unsigned)grid), dim3(256), 0, st,     \
-                       rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,           \
-                       src_scale, accumulate, n_row_blocks, n_col_tiles, xcd_tiles)
+#define GIST_SPMM_LAUNCH(L)                                                                       \
+    do {                                                                                          \
+        if (dropping)                                                                             \
+            hipLaunchKernelGGL((spmm_csr_kernel<VEC, L, true>), dim3((unsigned)grid), dim3(256), 0, st, \
+                               rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,       \
+                               src_scale, accumulate, n_row_blocks, n_col_tiles, xcd_tiles, dr);  \
+        else                                                                                      \
+            hipLaunchKernelGGL((spmm_csr_kernel<VEC, L, false>), dim3((unsigned)grid), dim3(256), 0, st, \
+                               rowptr, col, x, ldx, y, ldy, (int)n_rows, (int)d, out_scale,       \
+                               src_scale, accumulate, n_row_blocks, n_col_tiles, xcd_tiles, dr);  \
+    } while (0)
     switch (lpr) {
         case 8: GIST_SPMM_LAUNCH(8); break;
         case 16: GIST_SPMM_LAUNCH(16); break;
@@ -688,8 +756,11 @@ static int l2_row_split(int64_t nb, int n_col_tiles) {
 static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
                             float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
                             const float *src_scale, int accumulate, const int32_t *row_blocks,
-                            int64_t n_row_blocks, hipStream_t st) {
+                            int64_t n_row_blocks, hipStream_t st, const SpmmDrop *drop = nullptr) {
     L2Args a;
+    a.dr = SpmmDrop{};
+    const int dmode = (drop != nullptr && drop->p > 0.f) ? drop->mode : 0;
+    if (dmode) a.dr = *drop;
     a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
     a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
     a.accumulate = accumulate; a.row_blocks = row_blocks;
@@ -705,16 +776,24 @@ static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const flo
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_csr_lds2_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kL2LdsBytes);
+        hipError_t e = hipSuccess;
+        for (const void *fn : {reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<0>),
+                               reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<1>),
+                               reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<2>)})
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LdsBytes);
         if (e != hipSuccess) {
             set_error("gist_spmm_csr_blocked_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return GIST_ELAUNCH;
         }
         once.done(dev);
     }
-    hipLaunchKernelGGL(spmm_csr_lds2_kernel, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
+    if (dmode == 1)
+        hipLaunchKernelGGL(spmm_csr_lds2_kernel<1>, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
+    else if (dmode == 2)
+        hipLaunchKernelGGL(spmm_csr_lds2_kernel<2>, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
+    else
+        hipLaunchKernelGGL(spmm_csr_lds2_kernel<0>, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 
@@ -739,6 +818,61 @@ extern "C" int gist_in_degree_norm_f32(const int32_t *rowptr, int64_t n_rows, fl
     return gist::launch_status("gist_in_degree_norm_f32");
 }
 
+namespace gist {
+static int spmm_generic(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
+                        int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
+                        const float *src_scale, int accumulate, hipStream_t st, const SpmmDrop *drop) {
+    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
+        return launch_spmm<4>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                              accumulate, st, drop);
+    // d = 4q + 2 wide enough for the workgroup-per-row kernel, 16-byte source rows with room
+    // for the last lane's over-read, 8-byte destination: gather 16 bytes per lane anyway
+    if (d % 4 == 2 && d >= 4 * kWave && ldx % 4 == 0 && ldx >= d + 2 && aligned16(x) && ldy % 2 == 0 &&
+        aligned8(y))
+        return launch_spmm<4, true>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                                    accumulate, st, drop);
+    if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y))
+        return launch_spmm<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                              accumulate, st, drop);
+    return launch_spmm<1>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
+                          accumulate, st, drop);
+}
+
+static bool lds2_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y) {
+    return d >= 128 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y);
+}
+
+// Which calls can carry the dropout mask themselves: forward (mode 1) every kernel but the matrix-core
+// one; backward (mode 2) the LDS-staged kernel only (it reads every source element once).
+bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
+                     const int32_t *row_blocks) {
+    const bool mfma = row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y) && d >= 1536 &&
+                      (int)tune(GIST_TUNE_SPMM_KERNEL) != 1;
+    if ((int)tune(GIST_TUNE_SPMM_KERNEL) == 2 && lds2_takes(d, ldx, ldy, x, y)) return false;
+    if (mode == 1) return !mfma;
+    if (mode == 2) return row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y) && !mfma;
+    return false;
+}
+
+int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y, int64_t ldy,
+              int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale, int accumulate,
+              const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st) {
+    GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_spmm_csr_drop_f32: negative size");
+    if (n_rows == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(rowptr && x && y, "gist_spmm_csr_drop_f32: null pointer");
+    GIST_REQUIRE(ldx >= d && ldy >= d, "gist_spmm_csr_drop_f32: leading dimension < d");
+    GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_spmm_csr_drop_f32: size >= 2^31");
+    GIST_REQUIRE(dr.mode == 1 || dr.mode == 2, "gist_spmm_csr_drop_f32: mode must be 1 or 2");
+    GIST_REQUIRE(dr.p >= 0.f && dr.p < 1.f && dr.ld >= d, "gist_spmm_csr_drop_f32: bad mask description");
+    GIST_REQUIRE(spmm_drop_takes(dr.mode, d, ldx, ldy, x, y, row_blocks),
+                 "gist_spmm_csr_drop_f32: this shape cannot carry the mask (use gist_dropout_f32)");
+    if (row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y))
+        return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
+                                row_blocks, n_row_blocks, st, &dr);
+    return spmm_generic(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate, st, &dr);
+}
+}  // namespace gist
+
 extern "C" int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *x,
                                  int64_t ldx, float *y, int64_t ldy, int64_t n_rows, int64_t d,
                                  const float *out_scale, const float *src_scale, int accumulate,
@@ -749,21 +883,27 @@ extern "C" int gist_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, cons
     GIST_REQUIRE(rowptr && x && y, "gist_spmm_csr_f32: null pointer");
     GIST_REQUIRE(ldx >= d && ldy >= d, "gist_spmm_csr_f32: leading dimension < d");
     GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_spmm_csr_f32: size >= 2^31");
-    hipStream_t st = as_stream(stream);
-    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y))
-        return launch_spmm<4>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
-                              accumulate, st);
-    // d = 4q + 2 wide enough for the workgroup-per-row kernel, 16-byte source rows with room
-    // for the last lane's over-read, 8-byte destination: gather 16 bytes per lane anyway
-    if (d % 4 == 2 && d >= 4 * kWave && ldx % 4 == 0 && ldx >= d + 2 && aligned16(x) && ldy % 2 == 0 &&
-        aligned8(y))
-        return launch_spmm<4, true>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
-                                    accumulate, st);
-    if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned8(x) && aligned8(y))
-        return launch_spmm<2>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
-                              accumulate, st);
-    return launch_spmm<1>(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,
-                          accumulate, st);
+    return spmm_generic(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
+                        as_stream(stream), nullptr);
+}
+
+/* Aggregation with gist_dropout_f32's mask folded in (see SpmmDrop); row_blocks = NULL: no locality blocks. */
+extern "C" int gist_spmm_csr_drop_f32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
+                                      float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
+                                      const float *src_scale, int accumulate, const int32_t *row_blocks,
+                                      int64_t n_row_blocks, int mode, float p, uint64_t seed, uint64_t y_offset,
+                                      uint64_t src_offset, int64_t mask_ld, gist_stream_t stream) {
+    gist::SpmmDrop dr{};
+    dr.mode = mode; dr.p = p; dr.scale = (p > 0.f && p < 1.f) ? 1.0f / (1.0f - p) : 1.f;
+    dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.y_base = y_offset; dr.src_base = src_offset; dr.ld = mask_ld;
+    return gist::spmm_drop(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate, row_blocks,
+                           n_row_blocks, dr, gist::as_stream(stream));
+}
+
+extern "C" int gist_spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
+                                    int has_row_blocks) {
+    static const int32_t dummy = 0;
+    return gist::spmm_drop_takes(mode, d, ldx, ldy, x, y, has_row_blocks ? &dummy : nullptr) ? 1 : 0;
 }
 
 extern "C" int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col, const float *x,

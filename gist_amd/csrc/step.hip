@@ -238,6 +238,70 @@ B3Step b3_layout(const gist_step_plan *p, char *base) {
 }
 }  // namespace
 
+// ---- fused sequence: slabs of the deferred split-K projections, bias-gradient chunk sums -------------
+namespace {
+struct FusedLayout {
+    float *dw_slabs[GIST_MAX_LAYERS]; int64_t dw_bytes[GIST_MAX_LAYERS];   // dW_k = dY_k^T . Z_k
+    float *logit_slabs; int64_t logit_bytes;                               // class layer's Y = Z . W^T
+    float *partials[GIST_MAX_LAYERS];                                      // [row_chunks16(n_max)][n_out_k]
+    int64_t bytes, partial_floats;
+};
+
+// the largest slab need over the batch sizes a plan sees (the split count depends on the reduction
+// length); a batch that would need more falls back to one k slice inside the launcher
+int64_t slab_need(int64_t m, int64_t n, int64_t k_max, bool k_is_rows) {
+    int64_t need = 0;
+    for (int q = 8; q >= 4; --q) {
+        const int64_t rows = k_max * q / 8;
+        if (rows <= 0) continue;
+        const int64_t b = k_is_rows ? gemm_f32_slab_bytes(m, n, rows) : gemm_f32_slab_bytes(rows, n, m);
+        need = b > need ? b : need;
+    }
+    return need;
+}
+
+FusedLayout fused_layout(const gist_step_plan *p, char *base, float *partials) {
+    FusedLayout f{};
+    const int L1 = p->n_layers;
+    int64_t off = 0, poff = 0;
+    auto take = [&](int64_t bytes) {
+        char *q = base ? base + off : nullptr;
+        off += ceil_div(bytes, 256) * 256;
+        return reinterpret_cast<float *>(q);
+    };
+    const int64_t chunks = gist_row_chunks16(p->n_max);
+    for (int k = 0; k < L1; ++k) {
+        const gist_layer_desc &l = p->layer[k];
+        f.dw_bytes[k] = slab_need(l.n_out, 2 * l.n_in, p->n_max, true);
+        f.dw_slabs[k] = f.dw_bytes[k] > 0 ? take(f.dw_bytes[k]) : nullptr;
+        f.partials[k] = partials ? partials + poff : nullptr;
+        poff += ceil_div(chunks * l.n_out, 64) * 64;
+    }
+    const gist_layer_desc &last = p->layer[L1 - 1];
+    f.logit_bytes = slab_need(2 * last.n_in, last.n_out, p->n_max, false);
+    f.logit_slabs = f.logit_bytes > 0 ? take(f.logit_bytes) : nullptr;
+    f.bytes = off;
+    f.partial_floats = poff;
+    return f;
+}
+}  // namespace
+
+extern "C" int64_t gist_step_fused_workspace_bytes(const gist_step_plan *plan) {
+    if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS || plan->n_max <= 0) return 0;
+    return fused_layout(plan, nullptr, nullptr).bytes;
+}
+// bytes reserved for the slabs of layer k's weight gradient (k == n_layers: the class layer's logits)
+extern "C" int64_t gist_step_fused_slab_bytes(const gist_step_plan *plan, int32_t k) {
+    if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS || plan->n_max <= 0) return 0;
+    if (k < 0 || k > plan->n_layers) return 0;
+    const FusedLayout f = fused_layout(plan, nullptr, nullptr);
+    return k == plan->n_layers ? f.logit_bytes : f.dw_bytes[k];
+}
+extern "C" int64_t gist_step_col_partials_floats(const gist_step_plan *plan) {
+    if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS || plan->n_max <= 0) return 0;
+    return fused_layout(plan, nullptr, nullptr).partial_floats;
+}
+
 extern "C" int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan) {
     if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS) return 0;
     if (gist_gemm_get_mode() == 2) return b3_layout(plan, nullptr).bytes;
@@ -271,6 +335,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     ActiveTimer active(p->timer);
     const bool train = (flags & GIST_STEP_TRAIN) != 0;
     const bool drop = train && p->p_drop > 0.f;
+    const bool blocked = p->row_blocks != nullptr && p->n_row_blocks > 0;
 
     // Split operands kept by the step (see gist_step_plan.h3_workspace); off = per-call splits
     // inside gist_gemm_*.
@@ -284,6 +349,41 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         b3 = b3_layout(p, static_cast<char *>(p->h3_workspace));
         if (b3.bytes > p->h3_workspace_bytes) b3 = B3Step{};
     }
+
+    // ---- the fused sequence (gist_step_plan.fuse): what each layer folds ----------------------------
+    const bool fuse = p->fuse != 0 && n <= p->n_max;
+    FusedLayout fl{};
+    bool defer = false;            // slabs + chunk sums consumed by the loss kernel / the optimiser
+    if (fuse && p->col_partials != nullptr && aligned16(p->col_partials)) {
+        fl = fused_layout(p, static_cast<char *>(p->fused_workspace), p->col_partials);
+        defer = p->fused_workspace == nullptr ? fl.bytes == 0
+                                              : (aligned16(p->fused_workspace) && fl.bytes <= p->fused_workspace_bytes);
+        if (!defer) fl = FusedLayout{};
+    }
+    uint64_t offs[GIST_MAX_LAYERS];
+    {
+        uint64_t off = drop_offset;
+        for (int k = 0; k < L1; ++k) {
+            offs[k] = off;
+            if (drop) off += round_up2((uint64_t)n * 2 * p->layer[k].n_in);
+        }
+    }
+    bool plain[GIST_MAX_LAYERS], fwd_fold[GIST_MAX_LAYERS], bwd_fold[GIST_MAX_LAYERS];
+    for (int k = 0; k < L1; ++k) {
+        const gist_layer_desc &l = p->layer[k];
+        plain[k] = !h3.layer[k].on && !b3.layer[k].on;
+        // forward: dropout([h | ah]) written by the producers, the aggregation reads hsrc[k]
+        fwd_fold[k] = fuse && drop && plain[k] && p->hsrc[k] != nullptr && (offs[k] & 1) == 0 &&
+                      (k > 0 || (flags & GIST_STEP_EXTRACT)) &&
+                      p->ld_hsrc[k] >= l.n_in &&
+                      spmm_drop_takes(1, l.n_in, p->ld_hsrc[k], l.ldz, p->hsrc[k], l.Z + l.n_in, blocked ? p->row_blocks : nullptr);
+        // backward: the mask of dZ_k applied by the reverse aggregation as it reads dZ_k
+        bwd_fold[k] = fuse && drop && plain[k] && k > 0 && k < L1 - 1 && (offs[k] & 1) == 0 &&
+                      spmm_drop_takes(2, l.n_in, 2 * l.n_in, 2 * l.n_in, p->dZ + l.n_in, p->dZ, blocked ? p->row_blocks : nullptr);
+    }
+    const float keep = drop ? 1.0f / (1.0f - p->p_drop) : 1.f;
+    const uint64_t sm = p->seed * 0x9E3779B97F4A7C15ULL;
+
     if (b3.any) {      // this step's weights, one read each
         Scope sc(p->timer, 3, 0, 0, 0, st);
         for (int k = 0; k < L1; ++k) {
@@ -326,17 +426,23 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
 
     if (flags & GIST_STEP_EXTRACT) {
         GIST_REQUIRE(ids != nullptr, "gist_sage_step: null ids");
-        GIST_TRY(gist_extract_batch(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n,
-                                    p->remap, p->rowptr, p->col, p->t_rowptr, p->t_col,
-                                    p->col_capacity, p->norm, p->feat, p->ld_feat,
-                                    p->layer[0].n_in, p->layer[0].Z, p->layer[0].ldz,
-                                    p->labels_all, p->labels, s));
+        const gist_layer_desc &l0 = p->layer[0];
+        if (fwd_fold[0])
+            GIST_TRY(gist_extract_batch_drop(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n,
+                                             p->remap, p->rowptr, p->col, p->t_rowptr, p->t_col,
+                                             p->col_capacity, p->norm, p->feat, p->ld_feat, l0.n_in, l0.Z,
+                                             l0.ldz, p->labels_all, p->labels, p->hsrc[0], p->ld_hsrc[0],
+                                             p->p_drop, p->seed, offs[0], 2 * l0.n_in, s));
+        else
+            GIST_TRY(gist_extract_batch(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n,
+                                        p->remap, p->rowptr, p->col, p->t_rowptr, p->t_col,
+                                        p->col_capacity, p->norm, p->feat, p->ld_feat,
+                                        l0.n_in, l0.Z, l0.ldz, p->labels_all, p->labels, s));
     }
 
     // ---- block structure of the batch, once for all its aggregations ----------------
     const void *prep_fwd = nullptr, *prep_bwd = nullptr;
-    if (p->row_blocks != nullptr && p->n_row_blocks > 0 && p->spmm_prepared != nullptr &&
-        aligned16(p->spmm_prepared)) {
+    if (blocked && p->spmm_prepared != nullptr && aligned16(p->spmm_prepared)) {
         const int64_t one = gist_spmm_blocks_bytes(p->n_row_blocks);
         bool wide = false;      // is there an aggregation the prepared kernel takes?
         for (int k = 0; k < L1; ++k)
@@ -353,16 +459,22 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     }
 
     // ---- forward (modules.py:310-314 / :218-237) ---------------------------------
-    uint64_t offs[GIST_MAX_LAYERS];
-    uint64_t off = drop_offset;
+    int logit_slabs = 0;           // > 1: the class layer's logits are still split-K slabs
     for (int k = 0; k < L1; ++k) {
         const gist_layer_desc &l = p->layer[k];
         {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
-            GIST_TRY(step_spmm(p, p->rowptr, p->col, l.Z, l.ldz, l.Z + l.n_in, l.ldz, n, l.n_in,
-                               p->norm, nullptr, 0, prep_fwd, s));
+            if (fwd_fold[k]) {      // source = the undropped input, store = dropout(ah)
+                SpmmDrop dr{};
+                dr.mode = 1; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
+                dr.y_base = offs[k] + (uint64_t)l.n_in; dr.src_base = 0; dr.ld = 2 * l.n_in;
+                GIST_TRY(spmm_drop(p->rowptr, p->col, p->hsrc[k], p->ld_hsrc[k], l.Z + l.n_in, l.ldz, n, l.n_in,
+                                   p->norm, nullptr, 0, blocked ? p->row_blocks : nullptr, p->n_row_blocks, dr, st));
+            } else {
+                GIST_TRY(step_spmm(p, p->rowptr, p->col, l.Z, l.ldz, l.Z + l.n_in, l.ldz, n, l.n_in,
+                                   p->norm, nullptr, 0, prep_fwd, s));
+            }
         }
-        offs[k] = off;
         if (h3.layer[k].on) {
             // dropout + split of Z_k in one pass (both layouts when training); the dropped
             // fp32 Z_k is never written: the backward only needs its transposed split
@@ -370,12 +482,11 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
             H3Dual d{};
             d.src = l.Z; d.ld = l.ldz; d.rows = n; d.cols = 2 * l.n_in;
-            d.p = drop ? p->p_drop : 0.f; d.seed = p->seed; d.offset = off;
+            d.p = drop ? p->p_drop : 0.f; d.seed = p->seed; d.offset = offs[k];
             d.fixed_shift = hl.shift;
             d.dst_r = hl.Zs; d.inv_r = hl.inv_zr;
             d.dst_t = train ? hl.ZsT : nullptr; d.inv_t = hl.inv_zt;
             GIST_TRY(h3_dual_split(d, st));
-            if (drop) off += round_up2((uint64_t)n * 2 * l.n_in);
             GIST_TRY(h3_gemm_presplit("gist_sage_step", hl.Zs, hl.inv_zr, hl.Ws, hl.inv_wr, l.b, l.Y,
                                       l.ldy, n, l.n_out, 2 * l.n_in, st));
         } else if (b3.layer[k].on) {
@@ -383,47 +494,75 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
             B3Dual d{};
             d.src = l.Z; d.ld = l.ldz; d.rows = n; d.cols = 2 * l.n_in;
-            d.p = drop ? p->p_drop : 0.f; d.seed = p->seed; d.offset = off;
+            d.p = drop ? p->p_drop : 0.f; d.seed = p->seed; d.offset = offs[k];
             d.dst_r = hl.Zs;
             d.dst_t = train ? hl.ZsT : nullptr;
             GIST_TRY(b3_dual_split(d, st));
-            if (drop) off += round_up2((uint64_t)n * 2 * l.n_in);
             GIST_TRY(b3_gemm_presplit("gist_sage_step", hl.Zs, hl.Ws, l.b, l.Y, l.ldy, n, l.n_out,
                                       2 * l.n_in, b3.slabs, b3.slab_bytes, st));
         } else {
-            if (drop) {
-                GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, off, s));
-                off += round_up2((uint64_t)n * 2 * l.n_in);
-            }
+            if (drop && !fwd_fold[k])
+                GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, offs[k], s));
             Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
-            GIST_TRY(gist_gemm_nt_f32(l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out,
-                                      2 * l.n_in, p->workspace, p->workspace_bytes, s));
+            if (defer && k == L1 - 1 && fl.logit_slabs != nullptr) {      // the loss kernel sums the slabs
+                GIST_TRY(gemm_slabs(0, l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out, 2 * l.n_in,
+                                    fl.logit_slabs, fl.logit_bytes, &logit_slabs, st));
+            } else {
+                GIST_TRY(gist_gemm_nt_f32(l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out,
+                                          2 * l.n_in, p->workspace, p->workspace_bytes, s));
+            }
         }
         if (k + 1 < L1) {
             const gist_layer_desc &nx = p->layer[k + 1];
-            GIST_TRY(gist_ln_relu_fwd_f32(l.Y, l.ldy, nx.Z, nx.ldz,
-                                          p->use_layernorm ? l.rstd : nullptr, n, l.n_out,
-                                          p->use_layernorm, 1, 1e-5f, s));
+            if (fwd_fold[k + 1])
+                GIST_TRY(gist_ln_relu_fwd_drop_f32(l.Y, l.ldy, nx.Z, nx.ldz, p->hsrc[k + 1], p->ld_hsrc[k + 1],
+                                                   p->use_layernorm ? l.rstd : nullptr, n, l.n_out,
+                                                   p->use_layernorm, 1, 1e-5f, p->p_drop, p->seed,
+                                                   offs[k + 1], 2 * nx.n_in, s));
+            else
+                GIST_TRY(gist_ln_relu_fwd_f32(l.Y, l.ldy, nx.Z, nx.ldz,
+                                              p->use_layernorm ? l.rstd : nullptr, n, l.n_out,
+                                              p->use_layernorm, 1, 1e-5f, s));
         }
     }
     const gist_layer_desc &last = p->layer[L1 - 1];
-    GIST_TRY(gist_softmax_xent_f32(last.Y, last.ldy, p->labels, nullptr, n, p->row_loss, p->loss,
-                                   p->dlogits, p->ldc, n, last.n_out, s));
+    // the optimiser kernel reduces the loss when it runs with deferred work anyway
+    const bool loss_in_adam = train && defer;
+    GIST_TRY(softmax_xent_ex("gist_sage_step", last.Y, last.ldy, logit_slabs > 1 ? fl.logit_slabs : nullptr,
+                             n * last.n_out, logit_slabs > 1 ? logit_slabs : 0, last.b, p->labels, nullptr, n,
+                             p->row_loss, loss_in_adam ? nullptr : p->loss, p->dlogits, p->ldc, n,
+                             last.n_out, st));
     if (!train) return GIST_OK;
 
     // ---- backward --------------------------------------------
+    gist_grad_segment segs[2 * GIST_MAX_LAYERS];
+    int n_segs = 0;
+    const int64_t chunks16 = gist_row_chunks16(n);
+    auto bias_segment = [&](int k) {      // db_k = chunk sums, formed by the optimiser
+        const gist_layer_desc &l = p->layer[k];
+        gist_grad_segment &g = segs[n_segs++];
+        g.begin = l.db - p->grads; g.end = g.begin + l.n_out;
+        g.src = fl.partials[k]; g.stride = l.n_out; g.n_src = (int32_t)chunks16;
+    };
     for (int k = L1 - 1; k >= 0; --k) {
         const gist_layer_desc &l = p->layer[k];
         const float *dy;
         int64_t lddy;
+        bool db_done = false;      // this layer's bias gradient is already in chunks
         if (k == L1 - 1) {
             dy = p->dlogits;
             lddy = p->ldc;
         } else {
             const int64_t i_next = p->layer[k + 1].n_in;      // == l.n_out
-            GIST_TRY(ln_relu_bwd_ex(p->dZ, 2 * i_next, l.Y, l.ldy,
-                                    p->use_layernorm ? l.rstd : nullptr, l.Y, l.ldy, n, l.n_out,
-                                    p->use_layernorm, 1, h3.layer[k].on ? h3.rowmax : nullptr, st));
+            if (defer && plain[k]) {
+                GIST_TRY(ln_relu_bwd_colsum(p->dZ, 2 * i_next, l.Y, l.ldy, p->use_layernorm ? l.rstd : nullptr,
+                                            l.Y, l.ldy, n, l.n_out, p->use_layernorm, 1, fl.partials[k], st));
+                db_done = true;
+            } else {
+                GIST_TRY(ln_relu_bwd_ex(p->dZ, 2 * i_next, l.Y, l.ldy,
+                                        p->use_layernorm ? l.rstd : nullptr, l.Y, l.ldy, n, l.n_out,
+                                        p->use_layernorm, 1, h3.layer[k].on ? h3.rowmax : nullptr, st));
+            }
             dy = l.Y;
             lddy = l.ldy;
         }
@@ -494,25 +633,58 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
             continue;
         }
-        if (k > 0) {      // dZ with its dropout mask
+        if (k > 0) {      // dZ with its dropout mask (or the mask left to the reverse aggregation)
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
-            GIST_TRY(gist_gemm_nn_dropout_f32(dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
-                                              2 * l.n_in, l.n_out, drop ? p->p_drop : 0.f, p->seed,
-                                              offs[k], p->workspace, p->workspace_bytes, s));
+            const bool chunk_db = defer && k == L1 - 1;      // the class layer's dZ kernel sees dlogits in 16-row chunks
+            GIST_TRY(gemm_nn_dropout_ex("gist_sage_step", dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
+                                        2 * l.n_in, l.n_out, (drop && !bwd_fold[k]) ? p->p_drop : 0.f, p->seed,
+                                        offs[k], p->workspace, p->workspace_bytes,
+                                        chunk_db ? fl.partials[k] : nullptr, st));
+            db_done = db_done || chunk_db;
         }
         {
             Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
-            GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
-                                      2 * l.n_in, n, p->workspace, p->workspace_bytes, s));
+            if (defer && fl.dw_slabs[k] != nullptr) {      // the optimiser sums the slabs
+                int ns = 1;
+                GIST_TRY(gemm_slabs(2, dy, lddy, l.Z, l.ldz, nullptr, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in, n,
+                                    fl.dw_slabs[k], fl.dw_bytes[k], &ns, st));
+                if (ns > 1) {
+                    gist_grad_segment &g = segs[n_segs++];
+                    g.begin = l.dW - p->grads; g.end = g.begin + l.n_out * 2 * l.n_in;
+                    g.src = fl.dw_slabs[k]; g.stride = l.n_out * 2 * l.n_in; g.n_src = ns;
+                }
+            } else {
+                GIST_TRY(gist_gemm_tn_f32(dy, lddy, l.Z, l.ldz, l.dW, 2 * l.n_in, l.n_out,
+                                          2 * l.n_in, n, p->workspace, p->workspace_bytes, s));
+            }
         }
-        GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
+        if (defer) {
+            if (!db_done)      // (a one-layer model: no dZ kernel has seen dlogits)
+                GIST_TRY(colsum_rows16(dy, lddy, n, l.n_out, fl.partials[k], k == L1 - 1 ? false : true, st));
+            bias_segment(k);
+        } else {
+            GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
+        }
         if (k > 0) {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
-            GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                               2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
+            if (bwd_fold[k]) {
+                SpmmDrop dr{};
+                dr.mode = 2; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
+                dr.y_base = offs[k]; dr.src_base = offs[k] + (uint64_t)l.n_in; dr.ld = 2 * l.n_in;
+                GIST_TRY(spmm_drop(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
+                                   l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st));
+            } else {
+                GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
+            }
         }
     }
-    GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
-                           beta2, eps, weight_decay, adam_step, s));
+    if (defer)
+        GIST_TRY(gist_adam_segments_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
+                                        beta2, eps, weight_decay, adam_step, segs, n_segs, p->row_loss, n, n,
+                                        p->loss, s));
+    else
+        GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
+                               beta2, eps, weight_decay, adam_step, s));
     return GIST_OK;
 }

@@ -184,8 +184,23 @@ __global__ __launch_bounds__(256) void induced_fill2_kernel(CsrPair p,
     }
 }
 
+// Layer 0's dropout folded into the gather (gist_extract_batch_drop): z0 receives the features under
+// gist_dropout_f32's mask (element index offset + i * mask_ld + c), x0 the features themselves (the
+// source of layer 0's aggregation).
+struct GatherDrop {
+    float *x0; int64_t ldx0;
+    float p, scale;
+    uint64_t sm, offset;
+    int64_t mask_ld;
+};
+__device__ __forceinline__ float gather_keep(uint64_t idx, const GatherDrop &g) {
+    const uint64_t h = splitmix64((idx >> 1) + g.sm);
+    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+    return ((float)(w >> 8) * (1.0f / 16777216.0f) >= g.p) ? g.scale : 0.f;
+}
+
 // features + label of batch row i, and remap[ids[i]] back to -1 (runs after both fills)
-template <int VEC>
+template <int VEC, bool DROP = false>
 __global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restrict__ feat,
                                                            int64_t ld_feat,
                                                            const int32_t *__restrict__ ids,
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restri
                                                            float *__restrict__ z0, int64_t ldz0,
                                                            const int32_t *__restrict__ labels_all,
                                                            int32_t *__restrict__ labels,
-                                                           int32_t *__restrict__ remap) {
+                                                           int32_t *__restrict__ remap, GatherDrop gd) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_ids) return;
     const int lane = threadIdx.x & 63;
@@ -201,6 +216,18 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restri
     const float *s = feat + (int64_t)v * ld_feat;
     float *o = z0 + (int64_t)i * ldz0;
     for (int c = lane * VEC; c < d; c += kWave * VEC) {
+        if constexpr (DROP) {
+            float t[VEC];
+            float *o2 = gd.x0 + (int64_t)i * gd.ldx0;
+            const uint64_t i0 = gd.offset + (uint64_t)i * (uint64_t)gd.mask_ld + (uint64_t)c;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) t[k] = s[c + k];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o2[c + k] = t[k];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[c + k] = t[k] * gather_keep(i0 + k, gd);
+            continue;
+        }
         if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + c) = *reinterpret_cast<const float4 *>(s + c);
         else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o + c) = *reinterpret_cast<const float2 *>(s + c);
         else o[c] = s[c];
@@ -413,13 +440,13 @@ extern "C" int gist_mean_rows_f32(const float *src, int64_t stride, int64_t n_sr
     return launch_status("gist_mean_rows_f32");
 }
 
-extern "C" int gist_extract_batch(const int32_t *g_rowptr, const int32_t *g_col,
+static int extract_impl(const int32_t *g_rowptr, const int32_t *g_col,
                                   const int32_t *g_t_rowptr, const int32_t *g_t_col,
                                   const int32_t *ids, int64_t n, int32_t *remap, int32_t *rowptr,
                                   int32_t *col, int32_t *t_rowptr, int32_t *t_col,
                                   int64_t col_capacity, float *norm, const float *feat,
                                   int64_t ld_feat, int64_t n_feat, float *z0, int64_t ldz0,
-                                  const int32_t *labels_all, int32_t *labels,
+                                  const int32_t *labels_all, int32_t *labels, const GatherDrop *drop,
                                   gist_stream_t stream) {
     GIST_REQUIRE(n > 0 && n < (1LL << 31) - 8, "gist_extract_batch: bad n");
     GIST_REQUIRE(g_rowptr && g_col && g_t_rowptr && g_t_col && ids && remap && rowptr && col &&
@@ -438,14 +465,56 @@ extern "C" int gist_extract_batch(const int32_t *g_rowptr, const int32_t *g_col,
     hipLaunchKernelGGL(scan_rowptr2_kernel, dim3(2), dim3(1024), 0, st, rowptr, t_rowptr, (int)n);
     hipLaunchKernelGGL(induced_fill2_kernel, dim3(nb4, 2), dim3(256), 0, st, p, ids, (int)n, remap,
                        col_capacity);
+    GatherDrop gd{};
+    if (drop != nullptr) {
+        gd = *drop;
+        GIST_REQUIRE(gd.x0 != nullptr && gd.ldx0 >= n_feat && gd.mask_ld >= n_feat && gd.p >= 0.f && gd.p < 1.f,
+                     "gist_extract_batch_drop: bad dropout arguments");
+        if (n_feat % 2 == 0)
+            hipLaunchKernelGGL((gather_batch_kernel<2, true>), dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
+                               (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap, gd);
+        else
+            hipLaunchKernelGGL((gather_batch_kernel<1, true>), dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
+                               (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap, gd);
+        return launch_status("gist_extract_batch_drop");
+    }
     if (n_feat % 4 == 0 && ld_feat % 4 == 0 && ldz0 % 4 == 0 && aligned16(feat) && aligned16(z0))
         hipLaunchKernelGGL(gather_batch_kernel<4>, dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
-                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap);
+                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap, gd);
     else if (n_feat % 2 == 0 && ld_feat % 2 == 0 && ldz0 % 2 == 0 && aligned8(feat) && aligned8(z0))
         hipLaunchKernelGGL(gather_batch_kernel<2>, dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
-                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap);
+                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap, gd);
     else
         hipLaunchKernelGGL(gather_batch_kernel<1>, dim3(nb4), dim3(256), 0, st, feat, ld_feat, ids,
-                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap);
+                           (int)n, (int)n_feat, z0, ldz0, labels_all, labels, remap, gd);
     return launch_status("gist_extract_batch");
+}
+
+extern "C" int gist_extract_batch(const int32_t *g_rowptr, const int32_t *g_col,
+                                  const int32_t *g_t_rowptr, const int32_t *g_t_col,
+                                  const int32_t *ids, int64_t n, int32_t *remap, int32_t *rowptr,
+                                  int32_t *col, int32_t *t_rowptr, int32_t *t_col,
+                                  int64_t col_capacity, float *norm, const float *feat,
+                                  int64_t ld_feat, int64_t n_feat, float *z0, int64_t ldz0,
+                                  const int32_t *labels_all, int32_t *labels,
+                                  gist_stream_t stream) {
+    return extract_impl(g_rowptr, g_col, g_t_rowptr, g_t_col, ids, n, remap, rowptr, col, t_rowptr, t_col,
+                        col_capacity, norm, feat, ld_feat, n_feat, z0, ldz0, labels_all, labels, nullptr,
+                        stream);
+}
+
+extern "C" int gist_extract_batch_drop(const int32_t *g_rowptr, const int32_t *g_col,
+                                       const int32_t *g_t_rowptr, const int32_t *g_t_col,
+                                       const int32_t *ids, int64_t n, int32_t *remap, int32_t *rowptr,
+                                       int32_t *col, int32_t *t_rowptr, int32_t *t_col,
+                                       int64_t col_capacity, float *norm, const float *feat,
+                                       int64_t ld_feat, int64_t n_feat, float *z0, int64_t ldz0,
+                                       const int32_t *labels_all, int32_t *labels, float *x0, int64_t ldx0,
+                                       float p, uint64_t seed, uint64_t offset, int64_t mask_ld,
+                                       gist_stream_t stream) {
+    GatherDrop gd{};
+    gd.x0 = x0; gd.ldx0 = ldx0; gd.p = p; gd.scale = (p > 0.f && p < 1.f) ? 1.0f / (1.0f - p) : 1.f;
+    gd.sm = seed * 0x9E3779B97F4A7C15ULL; gd.offset = offset; gd.mask_ld = mask_ld;
+    return extract_impl(g_rowptr, g_col, g_t_rowptr, g_t_col, ids, n, remap, rowptr, col, t_rowptr, t_col,
+                        col_capacity, norm, feat, ld_feat, n_feat, z0, ldz0, labels_all, labels, &gd, stream);
 }

@@ -83,11 +83,12 @@ class ParamArena(object):
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
     __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
-                 'row_blocks')
+                 'row_blocks', 'batcher')
 
     def __init__(self):
         self.ready = True
         self.row_blocks = None      # int32 [n_blocks + 1]: row ranges of the batch's METIS parts
+        self.batcher = None         # set on lazy batches: who extracts them
 
 
 class ClusterBatcher(object):
@@ -124,18 +125,25 @@ class ClusterBatcher(object):
         b.t_rowptr, b.t_col = self.t_rowptr[:n + 1], self.t_col
         b.norm, b.labels, b.ids = self.norm[:n], self.lab[:n], ids
         b.ready = False
+        b.batcher = self
         return b
 
-    def extract(self, ids, z0_left):
+    def extract(self, ids, z0_left, drop=None):
         """ids: int32 device tensor (node ids in the training graph); z0_left: the [n, F]
-        left half of layer 0's [h | ah] buffer, filled with the gathered features."""
+        left half of layer 0's [h | ah] buffer, filled with the gathered features.
+        drop = (x0, p, seed, offset, mask_ld): layer 0's dropout folded into the gather
+        (gist_extract_batch_drop): z0_left receives dropout(features), x0 the features."""
         n = ids.numel()
         if n > self.n_max:
             raise ValueError('gist_amd: batch of %d rows exceeds n_max=%d' % (n, self.n_max))
         g = self.g
         rp, trp = self.rowptr[:n + 1], self.t_rowptr[:n + 1]
-        hip.extract_batch(g, ids, self.remap, rp, self.col, trp, self.t_col, self.norm, self.feat,
-                          z0_left, self.labels, self.lab)
+        if drop is not None:
+            hip.extract_batch_drop(g, ids, self.remap, rp, self.col, trp, self.t_col, self.norm, self.feat,
+                                   z0_left, self.labels, self.lab, *drop)
+        else:
+            hip.extract_batch(g, ids, self.remap, rp, self.col, trp, self.t_col, self.norm, self.feat,
+                              z0_left, self.labels, self.lab)
         b = Batch()
         b.n, b.rowptr, b.col, b.t_rowptr, b.t_col = n, rp, self.col, trp, self.t_col
         b.norm, b.labels, b.ids = self.norm[:n], self.lab[:n], ids
@@ -179,6 +187,18 @@ class SageEngine(object):
         self._ws = hip.workspace(need, device)
         self._ws2 = torch.empty(max(int(need), 1 << 20), dtype=torch.uint8, device=device)
         self._drop_offsets = []
+        # The fused sequence (include/gist_hip.h, gist_step_plan.fuse; GIST_STEP_FUSE=0 = the un-fused
+        # one): H[k] = undropped input of layer k where its dropout is folded into the producers,
+        # bias-gradient chunk sums and the slabs of deferred split-K projections.
+        self.fuse = os.environ.get('GIST_STEP_FUSE', '1') != '0'
+        self.H = [None] * self.L1
+        if self.fuse and self.p_drop > 0.0:
+            for k, (i, o) in enumerate(self.dims):
+                ld = i if i % 4 == 0 else _round_up(i + 2, 4)
+                self.H[k] = torch.zeros(self.n_max, ld, **f32)
+        self._fused = None          # op-by-op path's own slabs / chunk sums (lazy)
+        self._segments = []
+        self._logit_slabs_n = 1
         self.plan = None
         self._spmm_prep = None      # prepared block structure of the current batch (native step)
         self._plan_keep = None
@@ -250,8 +270,22 @@ class SageEngine(object):
             P.h3_workspace, P.h3_workspace_bytes = self._h3_ws.data_ptr(), need
         if self._spmm_prep is not None:
             P.spmm_prepared, P.spmm_prepared_bytes = self._spmm_prep.data_ptr(), self._spmm_prep.numel()
+        P.fuse = int(self.fuse)
+        self._fused_ws = self._col_partials = None
+        if self.fuse:
+            for k in range(self.L1):
+                if self.H[k] is not None:
+                    P.hsrc[k], P.ld_hsrc[k] = self.H[k].data_ptr(), self.H[k].stride(0)
+            nf = L_.gist_step_col_partials_floats(ctypes.byref(P))
+            self._col_partials = torch.zeros(max(int(nf), 4), dtype=torch.float32, device=self.device)
+            P.col_partials = self._col_partials.data_ptr()
+            nb = L_.gist_step_fused_workspace_bytes(ctypes.byref(P))
+            if nb > 0:
+                self._fused_ws = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+                P.fused_workspace, P.fused_workspace_bytes = self._fused_ws.data_ptr(), int(nb)
         self.plan = P
-        self._plan_keep = (batcher, g, self._ws, self._ws2, self._h3_ws)     # keep every buffer alive
+        self._plan_keep = (batcher, g, self._ws, self._ws2, self._h3_ws, self._fused_ws,
+                           self._col_partials)     # keep every buffer alive
         return P
 
     def enable_timer(self, capacity):
@@ -332,12 +366,66 @@ class SageEngine(object):
         self.drop_calls += numel + (numel & 1)
         return off
 
-    def forward(self, b, training):
+    # -- op-by-op path: the SAME sequence gist_sage_step issues, one C-ABI call per kernel ----------
+    def _fused_buffers(self):
+        """Slabs / chunk sums of the op-by-op path, sized like the native step's (the split counts of
+        the deferred projections must agree: gist_step_fused_slab_bytes)."""
+        if self._fused is not None:
+            return self._fused
+        import ctypes
+        from . import _lib
+        L = _lib.load()
+        P = _lib.StepPlan()
+        P.n_layers, P.n_max = self.L1, self.n_max
+        for k, (i, o) in enumerate(self.dims):
+            P.layer[k].n_in, P.layer[k].n_out = i, o
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        chunks = int(L.gist_row_chunks16(self.n_max))
+        fb = {'dw': [], 'partials': []}
+        for k, (i, o) in enumerate(self.dims):
+            nb = int(L.gist_step_fused_slab_bytes(ctypes.byref(P), k))
+            fb['dw'].append(torch.empty(nb, **u8) if nb > 0 else None)
+            fb['partials'].append(torch.zeros(max(chunks * o, 4), **f32))
+        nb = int(L.gist_step_fused_slab_bytes(ctypes.byref(P), self.L1))
+        fb['logits'] = torch.empty(nb, **u8) if nb > 0 else None
+        self._fused = fb
+        return fb
+
+    def _offsets(self, n, training):
+        """Dropout counter base of every layer for this step (gist_sage_step's layer k uses
+        drop_offset + sum_{j<k} round_up(n * 2 * n_in_j, 2))."""
+        offs = []
+        if training and self.p_drop > 0.0:
+            for (i, o) in self.dims:
+                offs.append(self._drop_offset(n * 2 * i))
+        return offs
+
+    def forward(self, b, training, _step=False):
         """GCN.forward (modules.py:310-314) on the batch whose features already sit in
-        Z[0][:, :F].  Returns the logits view [n, C]."""
+        Z[0][:, :F] (a lazy batch is extracted first).  Returns the logits view [n, C].
+        _step: called by train_step -- the class layer's logits may stay split-K slabs for the loss
+        kernel and a lazy batch's feature gather carries layer 0's dropout, like gist_sage_step."""
         n = b.n
         A = self.arena
-        self._drop_offsets = []
+        drop = training and self.p_drop > 0.0
+        blocked = b.row_blocks is not None and b.row_blocks.numel() > 1
+        rb = b.row_blocks if blocked else None
+        self._drop_offsets = offs = self._offsets(n, training)
+        fold = [False] * self.L1
+        if self.fuse and drop:
+            for k, (i, o) in enumerate(self.dims):
+                fold[k] = (self.H[k] is not None and (k > 0 or (_step and not b.ready)) and
+                           hip.spmm_drop_takes(1, i, self.H[k][:n, :i], self.Z[k][:n, i:], blocked))
+        self._fwd_fold = fold
+        if not b.ready:
+            if b.batcher is None:
+                raise RuntimeError('gist_amd: lazy batch without a batcher')
+            i0 = self.dims[0][0]
+            dr = (self.H[0][:n, :i0], self.p_drop, self.seed, offs[0], 2 * i0) if fold[0] else None
+            b.batcher.extract(b.ids, self.z0_left(n), drop=dr)
+            b.ready = True
+        self._logit_slabs_n = 1
         for k, (i, o) in enumerate(self.dims):
             z = self.Z[k][:n]
             if not training and o < i and k == self.L1 - 1 and self.project_first:
@@ -353,32 +441,63 @@ class SageEngine(object):
                 hip.spmm(b.rowptr, b.col, p_buf, self.Y[k][:n, :o], out_scale=b.norm,
                          accumulate=True)
                 continue
-            hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm, row_blocks=b.row_blocks)
-            if training and self.p_drop > 0.0:
-                off = self._drop_offset(n * 2 * i)
-                self._drop_offsets.append(off)
-                hip.dropout_(z, self.p_drop, self.seed, off)
+            if fold[k]:      # source = the undropped input, store = dropout(ah)
+                hip.spmm_drop(b.rowptr, b.col, self.H[k][:n, :i], z[:, i:], 1, self.p_drop, self.seed,
+                              offs[k] + i, 0, 2 * i, out_scale=b.norm, row_blocks=rb)
+            else:
+                hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm, row_blocks=b.row_blocks)
+                if drop:
+                    hip.dropout_(z, self.p_drop, self.seed, offs[k])
             last = k == self.L1 - 1
             if last:
+                if self.fuse and training and _step:      # the loss kernel sums the split-K slabs
+                    fb = self._fused_buffers()
+                    if fb['logits'] is not None:
+                        self._logit_slabs_n = hip.gemm_slabs('nt', z, A.W[k], A.b[k], self.Y[k][:n, :o],
+                                                             fb['logits'])
+                        continue
                 hip.gemm_nt(z, A.W[k], A.b[k], self.Y[k][:n, :o])
             else:
                 y = self.Y[k][:n]
                 hip.gemm_nt(z, A.W[k], A.b[k], y)
                 i_next = self.dims[k + 1][0]
-                hip.ln_relu_fwd(y, self.Z[k + 1][:n, :i_next],
-                                self.rstd[k][:n] if self.use_layernorm else None,
-                                self.use_layernorm, True)
+                rstd = self.rstd[k][:n] if self.use_layernorm else None
+                if fold[k + 1]:
+                    hip.ln_relu_fwd_drop(y, self.Z[k + 1][:n, :i_next], self.H[k + 1][:n, :i_next], rstd,
+                                         self.use_layernorm, True, self.p_drop, self.seed, offs[k + 1],
+                                         2 * i_next)
+                else:
+                    hip.ln_relu_fwd(y, self.Z[k + 1][:n, :i_next], rstd, self.use_layernorm, True)
         return self.logits(n)
 
-    def loss_and_backward(self, b, mask=None, count=None):
-        """CE (mean over masked rows) + full backward into the gradient arena."""
+    def loss_and_backward(self, b, mask=None, count=None, _step=False):
+        """CE (mean over masked rows) + full backward into the gradient arena.  With the fused
+        sequence inside train_step (_step, self.fuse, no mask) the bias gradients and split weight
+        gradients are left in chunks / slabs for adam_step, like gist_sage_step does; called on its
+        own, the gradient arena is complete on return."""
         n = b.n
         A = self.arena
-        hip.softmax_xent(self.logits(n), b.labels, mask, n if count is None else count,
-                         self.row_loss[:n], self.loss, self.dlogits[:n])
+        defer = self.fuse and mask is None and _step
+        drop = bool(self._drop_offsets)
+        blocked = b.row_blocks is not None and b.row_blocks.numel() > 1
+        fb = self._fused_buffers() if defer else None
+        self._segments = []
+        self._loss_rows = n if defer else 0
+        if defer:
+            hip.softmax_xent_slabs(self.logits(n), fb['logits'], self._logit_slabs_n, A.b[-1], b.labels, None, n,
+                                   self.row_loss[:n], None, self.dlogits[:n])
+        else:
+            if self._logit_slabs_n > 1:
+                raise RuntimeError('gist_amd: masked loss after a slab forward')
+            hip.softmax_xent(self.logits(n), b.labels, mask, n if count is None else count,
+                             self.row_loss[:n], self.loss, self.dlogits[:n])
+        L = hip._lib.load()
+        chunks = int(L.gist_row_chunks16(n))
+        goff = lambda t: (t.data_ptr() - A.grads.data_ptr()) // 4
         for k in range(self.L1 - 1, -1, -1):
             i, o = self.dims[k]
             z = self.Z[k][:n]
+            db_done = False
             if k == self.L1 - 1:
                 dy = self.dlogits[:n, :o]
             else:
@@ -386,23 +505,57 @@ class SageEngine(object):
                 i_next = self.dims[k + 1][0]
                 d_out = self.dZ[:n * 2 * i_next].view(n, 2 * i_next)[:, :i_next]
                 dy = self.Y[k][:n]
-                hip.ln_relu_bwd(d_out, dy, self.rstd[k][:n] if self.use_layernorm else None, dy,
-                                self.use_layernorm, True)
-            hip.gemm_tn(dy, z, A.dW[k])
-            hip.colsum(dy, A.db[k], self.partials)
+                rstd = self.rstd[k][:n] if self.use_layernorm else None
+                if defer:
+                    hip.ln_relu_bwd_colsum(d_out, dy, rstd, dy, self.use_layernorm, True, fb['partials'][k])
+                    db_done = True
+                else:
+                    hip.ln_relu_bwd(d_out, dy, rstd, dy, self.use_layernorm, True)
+            bwd_fold = False
             if k > 0:
                 dz = self.dZ[:n * 2 * i].view(n, 2 * i)
-                if self._drop_offsets:
-                    hip.gemm_nn_dropout_(dy, A.W[k], dz, self.p_drop, self.seed, self._drop_offsets[k])
+                bwd_fold = (self.fuse and drop and k < self.L1 - 1 and
+                            hip.spmm_drop_takes(2, i, dz[:, i:], dz[:, :i], blocked))
+                p_here = self.p_drop if (drop and not bwd_fold) else 0.0
+                off = self._drop_offsets[k] if drop else 0
+                if defer and k == self.L1 - 1:
+                    hip.gemm_nn_dropout_colsum_(dy, A.W[k], dz, p_here, self.seed, off, fb['partials'][k])
+                    db_done = True
                 else:
-                    hip.gemm_nn_dropout_(dy, A.W[k], dz, 0.0, self.seed, 0)
-                hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
-                         accumulate=True, row_blocks=b.row_blocks)
+                    hip.gemm_nn_dropout_(dy, A.W[k], dz, p_here, self.seed, off)
+            if defer and fb['dw'][k] is not None:
+                ns = hip.gemm_slabs('tn', dy, z, None, A.dW[k], fb['dw'][k])
+                if ns > 1:
+                    self._segments.append((goff(A.dW[k]), goff(A.dW[k]) + o * 2 * i, fb['dw'][k], o * 2 * i, ns))
+            else:
+                hip.gemm_tn(dy, z, A.dW[k])
+            if defer:
+                if not db_done:
+                    raise RuntimeError('gist_amd: one-layer models take the native step')
+                self._segments.append((goff(A.db[k]), goff(A.db[k]) + o, fb['partials'][k], o, chunks))
+            else:
+                hip.colsum(dy, A.db[k], self.partials)
+            if k > 0:
+                if bwd_fold:
+                    hip.spmm_drop(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], 2, self.p_drop, self.seed,
+                                  self._drop_offsets[k], self._drop_offsets[k] + i, 2 * i, src_scale=b.norm,
+                                  accumulate=True, row_blocks=b.row_blocks)
+                else:
+                    hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
+                             accumulate=True, row_blocks=b.row_blocks)
         return self.loss
 
     def adam_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
         A = self.arena
         A.step += 1
+        if self._segments or getattr(self, '_loss_rows', 0):
+            n = self._loss_rows
+            hip.adam_segments_(A.params, A.grads, A.exp_avg, A.exp_avg_sq, A.step, lr, self._segments,
+                               row_loss=self.row_loss[:n] if n else None, n_loss_rows=n, loss_count=n,
+                               loss=self.loss if n else None, beta1=betas[0], beta2=betas[1], eps=eps,
+                               weight_decay=weight_decay)
+            self._segments, self._loss_rows = [], 0
+            return
         hip.adam_(A.params, A.grads, A.exp_avg, A.exp_avg_sq, A.step, lr, betas[0], betas[1], eps,
                   weight_decay)
 
@@ -412,10 +565,8 @@ class SageEngine(object):
         plan attached (attach_batcher) and no mask this is a single gist_sage_step call."""
         if self.plan is not None and mask is None and hip._prof is None:
             return self._native_step(b, lr, weight_decay, train=True)
-        if not b.ready:
-            raise RuntimeError('gist_amd: lazy batch needs the native step plan')
-        self.forward(b, training=True)
-        loss = self.loss_and_backward(b, mask, count)
+        self.forward(b, training=True, _step=mask is None)
+        loss = self.loss_and_backward(b, mask, count, _step=True)
         self.adam_step(lr, weight_decay)
         return loss
 

@@ -482,3 +482,154 @@ def mean_rows(src, stride, n_src, n, out):
                                     _vec(out, 'out', torch.float32, n), _stream()),
                'gist_mean_rows_f32')
     return out
+
+
+# -- fused forms (include/gist_hip.h: dropout folded into producers / consumers, deferred reductions) --
+def spmm_drop_takes(mode, d, x, y, has_row_blocks):
+    L = _lib.load()
+    xp, ldx = _mat(x, 'x')
+    yp, ldy = _mat(y, 'y')
+    return bool(L.gist_spmm_drop_takes(int(mode), d, ldx, ldy, xp, yp, int(bool(has_row_blocks))))
+
+
+def spmm_drop(rowptr, col, x, y, mode, p, seed, y_offset, src_offset, mask_ld, out_scale=None,
+              src_scale=None, accumulate=False, row_blocks=None):
+    """spmm with gist_dropout_f32's mask folded in (gist_spmm_csr_drop_f32)."""
+    L = _lib.load()
+    n = rowptr.numel() - 1
+    xp, ldx = _mat(x, 'x')
+    yp, ldy = _mat(y, 'y')
+    d = x.shape[1]
+    nb = 0 if row_blocks is None else row_blocks.numel() - 1
+    with _Timed('spmm', (n, x.shape[0], d)):
+        rc = L.gist_spmm_csr_drop_f32(_vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32), xp,
+                                      ldx, yp, ldy, n, d, _opt(out_scale, 'out_scale', torch.float32, n),
+                                      _opt(src_scale, 'src_scale', torch.float32, x.shape[0]),
+                                      int(bool(accumulate)), _opt(row_blocks, 'row_blocks', torch.int32), nb,
+                                      int(mode), float(p), int(seed), int(y_offset), int(src_offset),
+                                      int(mask_ld), _stream())
+    _lib.check(rc, 'gist_spmm_csr_drop_f32')
+    return y
+
+
+def gemm_slabs(layout, a, b, bias, c, slabs):
+    """gist_gemm_slabs_f32: layout 'nt' (c = a @ b.T + bias), 'nn' (c = a @ b), 'tn' (c = a.T @ b).
+    Returns the slab count (1: c is final)."""
+    import ctypes
+    L = _lib.load()
+    code = {'nt': 0, 'nn': 1, 'tn': 2}[layout]
+    ap, lda = _mat(a, 'a')
+    bp, ldb = _mat(b, 'b')
+    cp, ldc = _mat(c, 'c')
+    m, n = c.shape
+    k = a.shape[1] if code != 2 else a.shape[0]
+    ns = ctypes.c_int32(1)
+    with _Timed('gemm', (layout, m, n, k)):
+        rc = L.gist_gemm_slabs_f32(code, ap, lda, bp, ldb, _opt(bias, 'bias', torch.float32, n), cp, ldc, m, n,
+                                   k, slabs.data_ptr() if slabs is not None else None,
+                                   slabs.numel() * slabs.element_size() if slabs is not None else 0,
+                                   ctypes.byref(ns), _stream())
+    _lib.check(rc, 'gist_gemm_slabs_f32')
+    return ns.value
+
+
+def ln_relu_fwd_drop(y, out, out2, rstd, use_lynorm, relu, p, seed, offset, mask_ld, eps=LN_EPS):
+    L = _lib.load()
+    yp, ldy = _mat(y, 'y')
+    op, ldo = _mat(out, 'out')
+    o2p, ldo2 = _mat(out2, 'out2') if out2 is not None else (None, 0)
+    n, d = y.shape
+    _lib.check(L.gist_ln_relu_fwd_drop_f32(yp, ldy, op, ldo, o2p, ldo2, _opt(rstd, 'rstd', torch.float32, n), n,
+                                           d, int(bool(use_lynorm)), int(bool(relu)), eps, float(p), int(seed),
+                                           int(offset), int(mask_ld), _stream()), 'gist_ln_relu_fwd_drop_f32')
+    return out
+
+
+def ln_relu_bwd_colsum(d_out, yhat, rstd, dy, use_lynorm, relu, col_partials):
+    L = _lib.load()
+    gp, ldg = _mat(d_out, 'd_out')
+    yp, ldy = _mat(yhat, 'yhat')
+    dp, ldd = _mat(dy, 'dy')
+    n, d = yhat.shape
+    _lib.check(L.gist_ln_relu_bwd_colsum_f32(gp, ldg, yp, ldy, _opt(rstd, 'rstd', torch.float32, n), dp, ldd, n,
+                                             d, int(bool(use_lynorm)), int(bool(relu)),
+                                             _vec(col_partials, 'col_partials', torch.float32,
+                                                  L.gist_row_chunks16(n) * d), _stream()),
+               'gist_ln_relu_bwd_colsum_f32')
+    return dy
+
+
+def colsum_chunks(partials, chunks, d, out):
+    L = _lib.load()
+    _lib.check(L.gist_colsum_chunks_f32(_vec(partials, 'partials', torch.float32, chunks * d), chunks, d,
+                                        _vec(out, 'out', torch.float32, d), _stream()), 'gist_colsum_chunks_f32')
+    return out
+
+
+def gemm_nn_dropout_colsum_(g, w, z, p, seed, offset, g_col_partials):
+    L = _lib.load()
+    gp, ldg = _mat(g, 'g')
+    wp, ldw = _mat(w, 'w')
+    zp, ldz = _mat(z, 'z')
+    m, k = g.shape
+    n = w.shape[1]
+    wsp, wsb = _ws_for(m, n, k, g.device)
+    with _Timed('gemm', ('nn', m, n, k)):
+        rc = L.gist_gemm_nn_dropout_colsum_f32(gp, ldg, wp, ldw, zp, ldz, m, n, k, float(p), int(seed),
+                                               int(offset), wsp, wsb,
+                                               _vec(g_col_partials, 'g_col_partials', torch.float32,
+                                                    L.gist_row_chunks16(m) * k), _stream())
+    _lib.check(rc, 'gist_gemm_nn_dropout_colsum_f32')
+    return z
+
+
+def softmax_xent_slabs(logits, slabs, n_slabs, bias, labels, mask, count, row_loss, loss, d_logits):
+    L = _lib.load()
+    lp, ldl = _mat(logits, 'logits')
+    gp, ldg = _mat(d_logits, 'd_logits')
+    n, c = logits.shape
+    _lib.check(L.gist_softmax_xent_slabs_f32(lp, ldl, slabs.data_ptr() if n_slabs > 1 else None, n * c,
+                                             n_slabs if n_slabs > 1 else 0, _opt(bias, 'bias', torch.float32, c),
+                                             _vec(labels, 'labels', torch.int32, n),
+                                             _opt(mask, 'mask', torch.uint8, n), int(count),
+                                             _vec(row_loss, 'row_loss', torch.float32, n),
+                                             _opt(loss, 'loss', torch.float32, 1), gp, ldg, n, c, _stream()),
+               'gist_softmax_xent_slabs_f32')
+    return loss
+
+
+def adam_segments_(param, grad, exp_avg, exp_avg_sq, step, lr, segments, row_loss=None, n_loss_rows=0,
+                   loss_count=0, loss=None, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """segments = [(begin, end, src_tensor, stride, n_src)] (gist_adam_segments_f32)."""
+    L = _lib.load()
+    n = param.numel()
+    arr = (_lib.GradSegment * max(len(segments), 1))()
+    for i, (b, e, src, stride, n_src) in enumerate(segments):
+        arr[i].begin, arr[i].end, arr[i].src, arr[i].stride, arr[i].n_src = b, e, src.data_ptr(), stride, n_src
+    _lib.check(L.gist_adam_segments_f32(_vec(param, 'param', torch.float32), _vec(grad, 'grad', torch.float32, n),
+                                        _vec(exp_avg, 'exp_avg', torch.float32, n),
+                                        _vec(exp_avg_sq, 'exp_avg_sq', torch.float32, n), n, lr, beta1, beta2,
+                                        eps, weight_decay, int(step), arr, len(segments),
+                                        _opt(row_loss, 'row_loss', torch.float32), int(n_loss_rows),
+                                        int(loss_count), _opt(loss, 'loss', torch.float32, 1), _stream()),
+               'gist_adam_segments_f32')
+    return param
+
+
+def extract_batch_drop(g, ids, remap, rowptr, col, t_rowptr, t_col, norm, feat, z0_left, labels_all, labels,
+                       x0, p, seed, offset, mask_ld):
+    """gist_extract_batch_drop: extraction whose feature gather writes dropout(feat) to z0 and feat to x0."""
+    L = _lib.load()
+    n = ids.numel()
+    fp, ldf = _mat(feat, 'feat')
+    zp, ldz = _mat(z0_left, 'z0')
+    xp, ldx = _mat(x0, 'x0')
+    _lib.check(L.gist_extract_batch_drop(
+        _vec(g.rowptr, 'g.rowptr', torch.int32), _vec(g.col, 'g.col', torch.int32),
+        _vec(g.t_rowptr, 'g.t_rowptr', torch.int32), _vec(g.t_col, 'g.t_col', torch.int32),
+        _vec(ids, 'ids', torch.int32), n, _vec(remap, 'remap', torch.int32),
+        _vec(rowptr, 'rowptr', torch.int32, n + 1), _vec(col, 'col', torch.int32),
+        _vec(t_rowptr, 't_rowptr', torch.int32, n + 1), _vec(t_col, 't_col', torch.int32),
+        col.numel(), _vec(norm, 'norm', torch.float32, n), fp, ldf, feat.shape[1], zp, ldz,
+        _opt(labels_all, 'labels_all', torch.int32), _opt(labels, 'labels', torch.int32, n),
+        xp, ldx, float(p), int(seed), int(offset), int(mask_ld), _stream()), 'gist_extract_batch_drop')

@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 8 */
+int gist_abi_version(void);   /* currently 9 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -100,6 +100,26 @@ int gist_spmm_csr_prepared_f32(const int32_t *rowptr, const int32_t *col,
                                const int32_t *row_blocks, int64_t n_row_blocks,
                                const void *prepared, gist_stream_t stream);
 
+/* The same aggregation with gist_dropout_f32's mask folded in, so that nn.Dropout on the concatenated
+ * [h | ah] (cluster_gcn/modules.py:230-231) and its backward cost no pass of their own.  Element
+ * (row, c) of y has mask index y_offset + row * mask_ld + c, of x src_offset + row * mask_ld + c
+ * (the operands are column windows of a [rows, mask_ld] tensor the mask is defined on).
+ *   mode 1 (forward):  what is stored to y is multiplied by y's mask -- y = dropout(aggregate(x));
+ *   mode 2 (backward): x is read through its mask and, with accumulate, the old y through y's --
+ *                      the aggregation of a gradient whose dropout pass has not been run.
+ * Bit-identical to running gist_dropout_f32 after (mode 1) / before (mode 2) the plain call.
+ * row_blocks as in gist_spmm_csr_blocked_f32 (NULL: none).  Not every kernel can carry the mask
+ * (gist_spmm_drop_takes, host function: 1 if this call is accepted; otherwise GIST_EINVAL). */
+int gist_spmm_csr_drop_f32(const int32_t *rowptr, const int32_t *col,
+                           const float *x, int64_t ldx, float *y, int64_t ldy,
+                           int64_t n_rows, int64_t d,
+                           const float *out_scale, const float *src_scale, int accumulate,
+                           const int32_t *row_blocks, int64_t n_row_blocks,
+                           int mode, float p, uint64_t seed, uint64_t y_offset, uint64_t src_offset,
+                           int64_t mask_ld, gist_stream_t stream);
+int gist_spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
+                         int has_row_blocks);
+
 /* ---------------------------------------------------------------------------
  * Data preparation (HOST function, host pointers)
  * ------------------------------------------------------------------------- */
@@ -145,6 +165,17 @@ int gist_gemm_nn_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
 int gist_gemm_tn_f32(const float *g, int64_t ldg, const float *a, int64_t lda,
                      float *d, int64_t ldd, int64_t m, int64_t n, int64_t k,
                      void *workspace, int64_t workspace_bytes, gist_stream_t stream);
+
+/* gist_gemm_{nt,nn,tn}_f32 (layout 0, 1, 2) on the fp32 kernel's split-K path WITHOUT the reduce pass:
+ * when the call splits its k range, the partial sums stay as dense slabs [*n_slabs][m][n] at `slabs`
+ * (gist_gemm_workspace_bytes(m, n, k) bytes) and c is not written; the CONSUMER sums them in slab
+ * order and adds the bias (gist_softmax_xent_slabs_f32 for the class layer's logits,
+ * gist_adam_segments_f32 for a weight gradient) -- one launch less per projection where the
+ * consumer reads the values anyway.  *n_slabs = 1: c holds the finished result (bias included).
+ * Same reference call sites as the three entry points above. */
+int gist_gemm_slabs_f32(int layout, const float *a, int64_t lda, const float *b, int64_t ldb,
+                        const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                        void *slabs, int64_t slab_bytes, int32_t *n_slabs, gist_stream_t stream);
 
 /* How the three entry points above form their products (GIST_GEMM_MODE = bf16x3 | f32 | f16x3 is
  * read once at first use; gist_gemm_set_mode overrides it; process-wide: set it before sizing
@@ -201,6 +232,30 @@ int gist_ln_relu_fwd_f32(float *y, int64_t ldy, float *out, int64_t ldo,
                          float *rstd, int64_t n_rows, int64_t d,
                          int use_lynorm, int relu, float eps, gist_stream_t stream);
 
+/* gist_ln_relu_fwd_f32 with the NEXT layer's dropout folded in: `out` (the left half of the next
+ * layer's [h | ah]) receives dropout(h) under gist_dropout_f32's mask at element index
+ * offset + row * mask_ld + c (mask_ld = the width of the tensor the mask is defined on, 2 * in of the
+ * next layer), `out2` (NULL: none) the undropped h -- the source of the next layer's aggregation,
+ * which modules.py:223-231 runs BEFORE the dropout.  p = 0: out = h.  Replaces modules.py:234-236 of
+ * layer k and the left half of nn.Dropout, :230-231, of layer k + 1. */
+int gist_ln_relu_fwd_drop_f32(float *y, int64_t ldy, float *out, int64_t ldo, float *out2, int64_t ldo2,
+                              float *rstd, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                              float eps, float p, uint64_t seed, uint64_t offset, int64_t mask_ld,
+                              gist_stream_t stream);
+
+/* gist_ln_relu_bwd_f32 that also leaves the bias gradient of the layer in chunks:
+ * col_partials[gist_row_chunks16(n_rows)][d] = column sums of dy per 16 consecutive rows.  The sum of the
+ * chunks in chunk order is db (gist_colsum_chunks_f32, or gist_adam_segments_f32 where it is consumed).
+ * One kernel for d <= 1024 with 16-byte aligned rows; other shapes run the plain backward and a chunk-sum
+ * pass (same layout, same summation order).  Replaces autograd of modules.py:233-236 wrt the bias. */
+int64_t gist_row_chunks16(int64_t n_rows);                                 /* host function */
+int gist_ln_relu_bwd_colsum_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
+                                const float *rstd, float *dy, int64_t lddy, int64_t n_rows, int64_t d,
+                                int use_lynorm, int relu, float *col_partials, gist_stream_t stream);
+/* out[j] = sum over chunks (in order) of partials[chunk][j]. */
+int gist_colsum_chunks_f32(const float *partials, int64_t chunks, int64_t d, float *out,
+                           gist_stream_t stream);
+
 /* dy[n_rows,d] from d_out: undo relu (mask yhat > 0) and LayerNorm
  * (dy = rstd * (g - mean(g) - yhat * mean(g*yhat))).  dy may alias yhat.
  * Replaces autograd of modules.py:234-236. */
@@ -228,6 +283,14 @@ int gist_gemm_nn_dropout_f32(const float *g, int64_t ldg, const float *w, int64_
                              float p, uint64_t seed, uint64_t offset,
                              void *workspace, int64_t workspace_bytes, gist_stream_t stream);
 
+/* gist_gemm_nn_dropout_f32 that also leaves g's column sums per 16 consecutive rows in
+ * g_col_partials[gist_row_chunks16(m)][k] (the class layer's bias gradient in chunks: g = d_logits). */
+int gist_gemm_nn_dropout_colsum_f32(const float *g, int64_t ldg, const float *w, int64_t ldw,
+                                    float *z, int64_t ldz, int64_t m, int64_t n, int64_t k,
+                                    float p, uint64_t seed, uint64_t offset,
+                                    void *workspace, int64_t workspace_bytes, float *g_col_partials,
+                                    gist_stream_t stream);
+
 /* out[j] = sum_i g[i, j], deterministic two-stage reduction.
  * `partials` must hold gist_colsum_partials(n_rows) * d floats.
  * Replaces autograd of nn.Linear wrt its bias (db), modules.py:233. */
@@ -252,12 +315,43 @@ int gist_softmax_xent_f32(const float *logits, int64_t ldl, const int32_t *label
                           float *loss, float *d_logits, int64_t ldg, int64_t n_rows,
                           int64_t n_classes, gist_stream_t stream);
 
+/* gist_softmax_xent_f32 whose logits are still split-K slabs (gist_gemm_slabs_f32: dense
+ * [n_slabs][n_rows][n_classes]; n_slabs = 0: `logits` already holds the values): the kernel forms
+ * logits = slabs summed in slab order + bias (bias may be NULL), stores them to `logits` and proceeds.
+ * loss may be NULL: the mean of row_loss is then left to gist_adam_segments_f32 (one launch less). */
+int gist_softmax_xent_slabs_f32(float *logits, int64_t ldl, const float *slabs, int64_t slab_stride,
+                                int64_t n_slabs, const float *bias, const int32_t *labels,
+                                const uint8_t *mask, int64_t count, float *row_loss, float *loss,
+                                float *d_logits, int64_t ldg, int64_t n_rows, int64_t n_classes,
+                                gist_stream_t stream);
+
 /* One Adam step (coupled L2 like torch.optim.Adam) over a flat parameter arena.
  * step is 1-based.  Replaces optimizer.step(),
  * cluster_gcn/cluster_gcn_ist_distrib.py:405-407,417; cluster_gcn/cluster_gcn.py:78-80,105. */
 int gist_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                   int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, gist_stream_t stream);
+
+/* gist_adam_f32 with DEFERRED gradient reductions: inside segment s, the gradient of arena element i
+ * in [begin, end) is sum_{q < n_src} src[q * stride + (i - begin)], summed in q order -- the split-K
+ * slabs of a weight-gradient projection (gist_gemm_slabs_f32) or a bias gradient's row-chunk sums
+ * (gist_ln_relu_bwd_colsum_f32, gist_gemm_nn_dropout_colsum_f32) -- formed inside the optimiser kernel,
+ * which also writes it to grad[i].  Elements outside every segment use grad[i].  Segments must not
+ * overlap; at most 2 * GIST_MAX_LAYERS; `segments` is HOST memory.  row_loss != NULL: loss[0] =
+ * sum(row_loss[0..n_loss_rows)) / loss_count as well (the reduction gist_softmax_xent_f32 would launch).
+ * Same reference call site as gist_adam_f32. */
+typedef struct gist_grad_segment {
+    int64_t begin, end;      /* element range of the arena                       */
+    const float *src;        /* NULL: grad[i] as is                              */
+    int64_t stride;          /* elements between consecutive sources             */
+    int32_t n_src;
+} gist_grad_segment;
+int gist_adam_segments_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                           int64_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int64_t step,
+                           const gist_grad_segment *segments, int64_t n_segments,
+                           const float *row_loss, int64_t n_loss_rows, int64_t loss_count, float *loss,
+                           gist_stream_t stream);
 
 /* correct[0] += #{i : mask[i] && argmax_j logits[i,j] == labels[i]} (first max wins,
  * like numpy argmax).  Replaces calc_acc / calc_f1(micro), cluster_gcn/utils.py:47-67. */
@@ -305,6 +399,21 @@ int gist_extract_batch(const int32_t *g_rowptr, const int32_t *g_col,
                        const float *feat, int64_t ld_feat, int64_t n_feat,
                        float *z0, int64_t ldz0,
                        const int32_t *labels_all, int32_t *labels, gist_stream_t stream);
+
+/* gist_extract_batch with layer 0's dropout folded into the feature gather: z0 receives
+ * dropout(features) under gist_dropout_f32's mask (element index offset + i * mask_ld + c; mask_ld =
+ * 2 * n_feat, the width of layer 0's [h | ah]) and x0 [n, n_feat] (ldx0) the features themselves, which
+ * layer 0's aggregation reads (modules.py:223-231 aggregates before it drops).  p = 0: z0 = x0. */
+int gist_extract_batch_drop(const int32_t *g_rowptr, const int32_t *g_col,
+                            const int32_t *g_t_rowptr, const int32_t *g_t_col,
+                            const int32_t *ids, int64_t n, int32_t *remap,
+                            int32_t *rowptr, int32_t *col, int32_t *t_rowptr, int32_t *t_col,
+                            int64_t col_capacity, float *norm,
+                            const float *feat, int64_t ld_feat, int64_t n_feat,
+                            float *z0, int64_t ldz0,
+                            const int32_t *labels_all, int32_t *labels,
+                            float *x0, int64_t ldx0, float p, uint64_t seed, uint64_t offset,
+                            int64_t mask_ld, gist_stream_t stream);
 
 /* dst[i, 0:d] = src[ids[i], 0:d]  -- the ndata['feat'] gather of g.subgraph
  * (partition_utils.py:23) written straight into the left half of layer 0's
@@ -418,7 +527,34 @@ typedef struct gist_step_plan {
      * blocks once after the extraction and its wide aggregations run gist_spmm_csr_prepared_f32;
      * NULL / too small = every aggregation builds what it needs itself. */
     void *spmm_prepared; int64_t spmm_prepared_bytes;
+    /* Fused sequence (fuse != 0; every buffer optional, NULL = that fusion is off).  A training step is
+     * launch-bound at small widths (per-rank h = 512: 41 launches, half of them on the ~4.5 us launch
+     * floor), so the step removes launches that only move a result from one kernel to the next:
+     *   - dropout is applied where its operand is produced or consumed: hsrc[k] = [n_max, n_in_k] holds
+     *     the UNDROPPED input of layer k (the aggregation's source) while Z_k receives dropout([h | ah])
+     *     from the feature gather / LayerNorm epilogue (left half) and the aggregation's store (right
+     *     half); the gradient's mask is applied as the reverse aggregation reads it
+     *     (gist_ln_relu_fwd_drop_f32, gist_extract_batch_drop, gist_spmm_csr_drop_f32);
+     *   - bias gradients leave the LayerNorm backward / the class layer's dZ kernel as 16-row chunk sums
+     *     in col_partials (sum over layers of gist_row_chunks16(n_max) * n_out floats) and split-K
+     *     projections whose consumer reads the values anyway keep their slabs in fused_workspace
+     *     (gist_step_fused_workspace_bytes): the class layer's logits are summed by the loss kernel, the
+     *     weight gradients and the chunk sums by the optimiser (gist_adam_segments_f32), which also
+     *     reduces the loss.
+     * Results equal the un-fused sequence's up to the summation order of the bias gradients. */
+    int32_t fuse;
+    float *hsrc[GIST_MAX_LAYERS]; int64_t ld_hsrc[GIST_MAX_LAYERS];   /* ld % 4 == 0 and >= n_in + 2 keeps the 16-byte gathers */
+    float *col_partials;
+    void *fused_workspace; int64_t fused_workspace_bytes;
 } gist_step_plan;
+
+/* Bytes of fused_workspace / floats of col_partials the plan's shapes need.  Host functions. */
+int64_t gist_step_fused_workspace_bytes(const gist_step_plan *plan);
+int64_t gist_step_col_partials_floats(const gist_step_plan *plan);
+/* Slab bytes the fused sequence reserves for layer k's weight-gradient projection (k == n_layers: the
+ * class layer's logits): what a caller issuing the same sequence op by op passes to gist_gemm_slabs_f32
+ * to get the same split counts. */
+int64_t gist_step_fused_slab_bytes(const gist_step_plan *plan, int32_t k);
 
 /* Bytes of h3_workspace the plan's shapes need in the current GEMM mode (0: no layer qualifies, or
  * mode 0). Host function. */

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Dev tool: per-kernel time of the training step at a given width (rocprofv3 --kernel-trace --stats).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
+EXTRA="${@:2}"
 H=${1:-512}
 rm -rf /tmp/sk
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sk -o t -- python3 $R/bench.py --n-hidden $H --steps 200 --warmup 20 --no-second-leg --no-cpu-baseline --no-kernel-timing > /tmp/sk.log 2>&1
-tail -1 /tmp/sk.log | python3 -c "
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sk -o t -- python3 $R/bench.py --n-hidden $H $EXTRA --steps 200 --warmup 20 --no-second-leg --no-cpu-baseline --no-kernel-timing > /tmp/sk.log 2>&1
+grep '^{"metric"' /tmp/sk.log | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], 'value', d['value'])"
 python3 - <<PY
