@@ -238,6 +238,152 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restri
     }
 }
 
+// ---- the whole extraction in ONE launch, for batches that are unions of parts ------------------------
+// A cluster batch is the union of `batch_size` parts of a fixed partition (partition_utils.py:20-25), so
+// "is node u in the batch, and at which row" needs no mark pass: with part_of[u] and pos_in_part[u]
+// (static) and the epoch's tables part_batch[p] / part_row0[p] (which batch of the epoch part p belongs to,
+// at which row of it), row(u) = part_batch[part_of[u]] == j ? part_row0[part_of[u]] + pos_in_part[u] : -1.
+// grid = (ceil(n_max / 4), 3) workgroups of 4 waves, one wave per batch row:
+//   y = 0 / 1  induced in-edge / out-edge CSR: count the row's kept neighbours (ballot + popcount, the
+//              kept ones' new ids stashed in LDS in edge order), publish the count, GRID BARRIER over the
+//              2 * gridDim.x workgroups of these two roles, prefix sum of the counts before the row ->
+//              row pointer, copy the stash (rows with more than 256 kept neighbours walk their list again);
+//   y = 2      feature + label gather (optionally with layer 0's dropout), independent of the others.
+// The barrier is a monotonic 64-bit ticket counter in `scratch` (every launch adds exactly
+// 2 * gridDim.x, gridDim.x fixed per scratch buffer); the host launches this kernel only when all its
+// barrier workgroups are co-resident (<= half of the device's workgroup slots), and a workgroup that
+// waits longer than ~1 s gives up and raises the error word instead of hanging the queue.
+// Integer work: bit exact against the 5-launch path.
+struct PartsArgs {
+    CsrPair p;
+    const int32_t *ids;
+    int n, n_max;
+    const int32_t *part_of, *pos_in_part, *part_batch, *part_row0;
+    int batch;
+    int64_t capacity;
+    float *norm;
+    unsigned long long *ticket;      // scratch: [0] ticket counter, [1] error word
+    int32_t *counts;                 // scratch: [2][n_max] raw kept-neighbour counts
+    // gather
+    const float *feat; int64_t ld_feat; int d;
+    float *z0; int64_t ldz0;
+    const int32_t *labels_all; int32_t *labels;
+    GatherDrop gd; int drop;
+};
+
+constexpr int kStash = 256;
+
+__global__ __launch_bounds__(256) void extract_parts_kernel(PartsArgs a) {
+    __shared__ int32_t stash[4][kStash];
+    __shared__ int wsum[4];
+    __shared__ int wcnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (blockIdx.y == 2) {                                   // ---- features + label of row i
+        if (i >= a.n) return;
+        const int v = a.ids[i];
+        const float *s = a.feat + (int64_t)v * a.ld_feat;
+        float *o = a.z0 + (int64_t)i * a.ldz0;
+        if (a.drop) {
+            float *o2 = a.gd.x0 + (int64_t)i * a.gd.ldx0;
+            const uint64_t i0 = a.gd.offset + (uint64_t)i * (uint64_t)a.gd.mask_ld;
+            for (int c = lane; c < a.d; c += kWave) {
+                const float t = s[c];
+                o2[c] = t;
+                o[c] = t * gather_keep(i0 + (uint64_t)c, a.gd);
+            }
+        } else {
+            for (int c = lane; c < a.d; c += kWave) o[c] = s[c];
+        }
+        if (lane == 0 && a.labels_all) a.labels[i] = a.labels_all[v];
+        return;
+    }
+    const int which = blockIdx.y;
+    const int32_t *rowptr = a.p.rowptr[which], *col = a.p.col[which];
+    const bool live = i < a.n;
+    int beg = 0, end = 0;
+    if (live) {
+        const int v = a.ids[i];
+        beg = rowptr[v];
+        end = rowptr[v + 1];
+    }
+    auto new_id = [&](int e) {                               // row of neighbour e in this batch, or -1
+        const int u = col[e];
+        const int pid = a.part_of[u];
+        return a.part_batch[pid] == a.batch ? a.part_row0[pid] + a.pos_in_part[u] : -1;
+    };
+    int cnt = 0;
+    for (int base = beg; base < end; base += kWave) {
+        const int e = base + lane;
+        const int r = e < end ? new_id(e) : -1;
+        const unsigned long long m = __ballot(r >= 0);
+        if (r >= 0) {
+            const int pos = cnt + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < kStash) stash[wave][pos] = r;
+        }
+        cnt += __popcll(m);
+    }
+    int32_t *counts = a.counts + (int64_t)which * a.n_max;
+    if (lane == 0) {
+        wcnt[wave] = cnt;
+        if (live) {
+            __hip_atomic_store(counts + i, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (which == 0) a.norm[i] = cnt > 0 ? 1.f / (float)cnt : 0.f;
+        }
+    }
+    // ---- grid barrier over the CSR roles ------------------------------------------------------------
+    __threadfence();                                         // every wave: its count is out at device scope
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long nwg = 2ULL * gridDim.x;
+        const unsigned long long ticket = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (ticket / nwg + 1ULL) * nwg;
+        long spins = 0;
+        while (__hip_atomic_load(a.ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1L << 23)) {                      // ~1 s: give up loudly, never hang
+                __hip_atomic_store(a.ticket + 1, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence();
+    // ---- rows before this workgroup's first row: all 256 threads sum the published counts -----------
+    const int first = blockIdx.x * 4;
+    int part = 0;
+    for (int k = threadIdx.x; k < first; k += 256)
+        part += __hip_atomic_load(counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    int w = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int k = 0; k < wave; ++k) w += wcnt[k];
+    if (!live) return;
+    int32_t *sub_rowptr = a.p.sub_rowptr[which], *sub_col = a.p.sub_col[which];
+    if (lane == 0) {
+        sub_rowptr[i] = w;
+        if (i == a.n - 1) sub_rowptr[a.n] = w + cnt;
+    }
+    if (cnt <= kStash) {
+        for (int k = lane; k < cnt; k += kWave)
+            if ((int64_t)w + k < a.capacity) sub_col[w + k] = stash[wave][k];
+    } else {
+        int64_t wp = w;
+        for (int base = beg; base < end; base += kWave) {
+            const int e = base + lane;
+            const int r = e < end ? new_id(e) : -1;
+            const unsigned long long m = __ballot(r >= 0);
+            if (r >= 0) {
+                const int64_t pos = wp + __popcll(m & ((1ULL << lane) - 1ULL));
+                if (pos < a.capacity) sub_col[pos] = r;
+            }
+            wp += __popcll(m);
+        }
+    }
+}
+
 // dst[i, :] = src[ids[i], :]; one wave per row
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src,
@@ -517,4 +663,70 @@ extern "C" int gist_extract_batch_drop(const int32_t *g_rowptr, const int32_t *g
     gd.sm = seed * 0x9E3779B97F4A7C15ULL; gd.offset = offset; gd.mask_ld = mask_ld;
     return extract_impl(g_rowptr, g_col, g_t_rowptr, g_t_col, ids, n, remap, rowptr, col, t_rowptr, t_col,
                         col_capacity, norm, feat, ld_feat, n_feat, z0, ldz0, labels_all, labels, &gd, stream);
+}
+
+
+// ---- one-launch extraction for batches that are unions of parts (see extract_parts_kernel) ------------
+extern "C" int64_t gist_extract_parts_scratch_bytes(int64_t n_max) {
+    return n_max <= 0 ? 0 : 16 + 8 * n_max;
+}
+
+// 1 if a batch buffer set sized for n_max rows may use gist_extract_parts_batch on the current device
+extern "C" int gist_extract_parts_supported(int64_t n_max) {
+    if (n_max <= 0) return 0;
+    static std::atomic<int> cus{0};
+    int c = cus.load(std::memory_order_relaxed);
+    if (c == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        cus.store(c, std::memory_order_relaxed);
+    }
+    // barrier workgroups (2 * ceil(n_max / 4), 256 threads, 4 KiB of LDS) must all be resident: a CU holds
+    // 8 such workgroups; use at most half of the slots
+    return 2 * ceil_div(n_max, 4) <= (int64_t)c * 4 ? 1 : 0;
+}
+
+extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *g_col,
+                                        const int32_t *g_t_rowptr, const int32_t *g_t_col,
+                                        const int32_t *ids, int64_t n, int64_t n_max,
+                                        const int32_t *part_of, const int32_t *pos_in_part,
+                                        const int32_t *part_batch, const int32_t *part_row0, int32_t batch,
+                                        int32_t *rowptr, int32_t *col, int32_t *t_rowptr, int32_t *t_col,
+                                        int64_t col_capacity, float *norm, const float *feat, int64_t ld_feat,
+                                        int64_t n_feat, float *z0, int64_t ldz0, const int32_t *labels_all,
+                                        int32_t *labels, float *x0, int64_t ldx0, float p, uint64_t seed,
+                                        uint64_t offset, int64_t mask_ld, void *scratch, gist_stream_t stream) {
+    GIST_REQUIRE(n > 0 && n <= n_max && n_max < (1LL << 31) - 8, "gist_extract_parts_batch: bad n");
+    GIST_REQUIRE(g_rowptr && g_col && g_t_rowptr && g_t_col && ids && part_of && pos_in_part && part_batch &&
+                     part_row0 && rowptr && col && t_rowptr && t_col && norm && feat && z0 && scratch,
+                 "gist_extract_parts_batch: null pointer");
+    GIST_REQUIRE(n_feat > 0 && ld_feat >= n_feat && ldz0 >= n_feat && n_feat < (1LL << 31),
+                 "gist_extract_parts_batch: bad feature shape");
+    GIST_REQUIRE(col_capacity >= 0 && batch >= 0, "gist_extract_parts_batch: bad capacity / batch index");
+    GIST_REQUIRE(aligned8(scratch), "gist_extract_parts_batch: scratch must be 8-byte aligned");
+    GIST_REQUIRE(gist_extract_parts_supported(n_max) == 1,
+                 "gist_extract_parts_batch: n_max too large for a one-launch extraction on this device");
+    PartsArgs a{};
+    a.p.rowptr[0] = g_rowptr; a.p.col[0] = g_col; a.p.sub_rowptr[0] = rowptr; a.p.sub_col[0] = col;
+    a.p.rowptr[1] = g_t_rowptr; a.p.col[1] = g_t_col; a.p.sub_rowptr[1] = t_rowptr; a.p.sub_col[1] = t_col;
+    a.ids = ids; a.n = (int)n; a.n_max = (int)n_max;
+    a.part_of = part_of; a.pos_in_part = pos_in_part; a.part_batch = part_batch; a.part_row0 = part_row0;
+    a.batch = batch; a.capacity = col_capacity; a.norm = norm;
+    a.ticket = static_cast<unsigned long long *>(scratch);
+    a.counts = reinterpret_cast<int32_t *>(static_cast<char *>(scratch) + 16);
+    a.feat = feat; a.ld_feat = ld_feat; a.d = (int)n_feat; a.z0 = z0; a.ldz0 = ldz0;
+    a.labels_all = labels_all; a.labels = labels;
+    a.drop = 0;
+    if (x0 != nullptr) {
+        GIST_REQUIRE(ldx0 >= n_feat && mask_ld >= n_feat && p >= 0.f && p < 1.f,
+                     "gist_extract_parts_batch: bad dropout arguments");
+        a.drop = 1;
+        a.gd.x0 = x0; a.gd.ldx0 = ldx0; a.gd.p = p; a.gd.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+        a.gd.sm = seed * 0x9E3779B97F4A7C15ULL; a.gd.offset = offset; a.gd.mask_ld = mask_ld;
+    }
+    hipLaunchKernelGGL(extract_parts_kernel, dim3((unsigned)ceil_div(n_max, 4), 3), dim3(256), 0,
+                       as_stream(stream), a);
+    return launch_status("gist_extract_parts_batch");
 }

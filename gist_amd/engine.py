@@ -83,12 +83,13 @@ class ParamArena(object):
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
     __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
-                 'row_blocks', 'batcher')
+                 'row_blocks', 'batcher', 'parts')
 
     def __init__(self):
         self.ready = True
         self.row_blocks = None      # int32 [n_blocks + 1]: row ranges of the batch's METIS parts
         self.batcher = None         # set on lazy batches: who extracts them
+        self.parts = None           # (part_of, pos_in_part, [part_batch; part_row0], batch index) -- sampler
 
 
 class ClusterBatcher(object):
@@ -197,6 +198,7 @@ class SageEngine(object):
                 ld = i if i % 4 == 0 else _round_up(i + 2, 4)
                 self.H[k] = torch.zeros(self.n_max, ld, **f32)
         self._fused = None          # op-by-op path's own slabs / chunk sums (lazy)
+        self._extract_scratch = None    # barrier ticket + counts of the one-launch extraction
         self._segments = []
         self._logit_slabs_n = 1
         self.plan = None
@@ -288,6 +290,13 @@ class SageEngine(object):
                            self._col_partials)     # keep every buffer alive
         return P
 
+    def check_extract(self):
+        """Raises if a workgroup of the one-launch extraction ever gave up at its grid barrier (the
+        error word of gist_extract_parts_batch's scratch); one small D2H read, call it off the hot path."""
+        if self._extract_scratch is not None and int(self._extract_scratch[1].item()) != 0:
+            raise RuntimeError('gist_amd: gist_extract_parts_batch timed out at its grid barrier; '
+                               'the batches extracted since the last check are invalid')
+
     def enable_timer(self, capacity):
         """HIP-event timing of every SpMM/GEMM issued by the native step (gist_timer_*)."""
         from . import _lib
@@ -348,6 +357,19 @@ class SageEngine(object):
                 self.plan.spmm_prepared_bytes = self._spmm_prep.numel()
         else:
             self.plan.row_blocks, self.plan.n_row_blocks = None, 0
+        # one-launch extraction when the batch comes with its part tables (gist_extract_parts_batch)
+        P = self.plan
+        if b.parts is not None and not b.ready and self.fuse and L.gist_extract_parts_supported(self.n_max):
+            part_of, pos, tab, j = b.parts
+            if self._extract_scratch is None:
+                self._extract_scratch = torch.zeros(int(L.gist_extract_parts_scratch_bytes(self.n_max)) // 8 + 1,
+                                                    dtype=torch.int64, device=self.device)
+            P.part_of, P.pos_in_part = part_of.data_ptr(), pos.data_ptr()
+            P.part_batch, P.part_row0 = tab[0].data_ptr(), tab[1].data_ptr()
+            P.batch_index, P.extract_scratch = int(j), self._extract_scratch.data_ptr()
+        else:
+            P.part_of = P.pos_in_part = P.part_batch = P.part_row0 = P.extract_scratch = None
+            P.batch_index = -1
         rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
                               eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())
         _lib.check(rc, 'gist_sage_step')

@@ -149,6 +149,31 @@ class EngineClusterIter(ClusterIter):
         self.native = False
         self._epoch_ids = None
         self._offsets = None
+        # One-launch extraction (gist_extract_parts_batch): every node's part and position in it.  Only
+        # when the parts really partition the train graph (disjoint; the reference's METIS output is).
+        self._part_of = self._pos_in_part = None
+        n_nodes = tg.number_of_nodes()
+        total = sum(len(p) for p in self.par_li)
+        if 0 < total <= n_nodes:
+            part_of = np.full(n_nodes, -1, np.int32)
+            pos = np.zeros(n_nodes, np.int32)
+            ok = True
+            for k, p in enumerate(self.par_li):
+                if len(p) == 0:
+                    continue
+                if (part_of[p] != -1).any() or len(np.unique(p)) != len(p):
+                    ok = False
+                    break
+                part_of[p] = k
+                pos[p] = np.arange(len(p), dtype=np.int32)
+            if ok:
+                # nodes outside every part can never be in a batch: park them on a part id that no
+                # epoch table maps to a batch
+                part_of[part_of < 0] = len(self.par_li)
+                self._part_of_host = part_of
+                self._part_of = torch.from_numpy(part_of).to(tg.device)
+                self._pos_in_part = torch.from_numpy(pos).to(tg.device)
+        self._extract_scratch = None
 
     def bind(self, engine, native=True):
         """Feed `engine`.  native=True attaches the C++ step driver: batches are then only
@@ -188,9 +213,26 @@ class EngineClusterIter(ClusterIter):
         self._epoch_blocks = torch.from_numpy(
             np.concatenate(blocks) if blocks else np.zeros(0, np.int32)).to(self.g.device)
         self._block_offsets = boff
+        # which batch of this epoch each part belongs to, and the batch row of its first node
+        self._part_tables = None
+        if self._part_of is not None:
+            n_parts = len(self.par_li) + 1
+            tab = np.full((2, n_parts), -1, np.int32)
+            row = 0
+            for s_, p in enumerate(used):
+                j = s_ // self.batch_size
+                if s_ % self.batch_size == 0:
+                    row = 0
+                if len(p):
+                    pid = int(self._part_of_host[p[0]])
+                    tab[0, pid], tab[1, pid] = j, row
+                row += len(p)
+            self._part_tables = torch.from_numpy(tab).to(self.g.device)
 
     def __iter__(self):
         self.n = 0
+        if self.engine is not None:
+            self.engine.check_extract()          # (last epoch's one-launch extractions all met their barrier)
         self._upload_epoch()
         return self
 
@@ -205,6 +247,8 @@ class EngineClusterIter(ClusterIter):
                 batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
             batch.row_blocks = self._epoch_blocks[int(self._block_offsets[self.n]):
                                                   int(self._block_offsets[self.n + 1])]
+            if self._part_tables is not None:
+                batch.parts = (self._part_of, self._pos_in_part, self._part_tables, self.n)
             self.n += 1
             return batch
         random.shuffle(self.par_li)
