@@ -98,7 +98,7 @@ SIGNATURES = {
                                        _i64, _p, _p, _p, _i64, _f, _u64, _u64, _i64, _p]),
     'gist_extract_parts_scratch_bytes': (_i64, [_i64]),
     'gist_extract_parts_supported': (_int, [_i64]),
-    'gist_extract_parts_batch': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64,
+    'gist_extract_parts_batch': (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64,
                                         _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _f, _u64, _u64, _i64, _p,
                                         _p]),
     'gist_sage_step': (_int, [_p, _p, _i64, _u64, _f, _f, _f, _f, _f, _i64, _int, _p]),
@@ -135,7 +135,7 @@ class StepPlan(ctypes.Structure):
                 ('spmm_prepared', _p), ('spmm_prepared_bytes', _i64),
                 ('fuse', _i32), ('hsrc', _p * GIST_MAX_LAYERS), ('ld_hsrc', _i64 * GIST_MAX_LAYERS),
                 ('col_partials', _p), ('fused_workspace', _p), ('fused_workspace_bytes', _i64),
-                ('part_of', _p), ('pos_in_part', _p), ('part_batch', _p), ('part_row0', _p),
+                ('node_part', _p), ('part_slot', _p),
                 ('batch_index', _i32), ('extract_scratch', _p)]
 
 

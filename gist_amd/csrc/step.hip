@@ -427,13 +427,11 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     if (flags & GIST_STEP_EXTRACT) {
         GIST_REQUIRE(ids != nullptr, "gist_sage_step: null ids");
         const gist_layer_desc &l0 = p->layer[0];
-        const bool by_parts = fuse && p->part_of && p->pos_in_part && p->part_batch && p->part_row0 &&
-                              p->extract_scratch && p->batch_index >= 0 && n <= p->n_max &&
+        const bool by_parts = fuse && p->node_part && p->part_slot && p->extract_scratch && p->batch_index >= 0 && n <= p->n_max &&
                               gist_extract_parts_supported(p->n_max) == 1;
         if (by_parts)
             GIST_TRY(gist_extract_parts_batch(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n, p->n_max,
-                                              p->part_of, p->pos_in_part, p->part_batch, p->part_row0,
-                                              p->batch_index, p->rowptr, p->col, p->t_rowptr, p->t_col,
+                                              p->node_part, p->part_slot, p->batch_index, p->rowptr, p->col, p->t_rowptr, p->t_col,
                                               p->col_capacity, p->norm, p->feat, p->ld_feat, l0.n_in, l0.Z,
                                               l0.ldz, p->labels_all, p->labels,
                                               fwd_fold[0] ? p->hsrc[0] : nullptr, p->ld_hsrc[0], p->p_drop,

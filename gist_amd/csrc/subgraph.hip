@@ -240,30 +240,29 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restri
 
 // ---- the whole extraction in ONE launch, for batches that are unions of parts ------------------------
 // A cluster batch is the union of `batch_size` parts of a fixed partition (partition_utils.py:20-25), so
-// "is node u in the batch, and at which row" needs no mark pass: with part_of[u] and pos_in_part[u]
-// (static) and the epoch's tables part_batch[p] / part_row0[p] (which batch of the epoch part p belongs to,
-// at which row of it), row(u) = part_batch[part_of[u]] == j ? part_row0[part_of[u]] + pos_in_part[u] : -1.
-// grid = (ceil(n_max / 4), 3) workgroups of 4 waves, one wave per batch row:
+// "is node u in the batch, and at which row" needs no mark pass: with node_part[u] = (part of u, position
+// of u in it) (static) and the epoch's table part_slot[p] = (which batch of the epoch part p belongs to,
+// at which row of it), row(u) = slot.batch == j ? slot.row + position : -1.
+// grid = (ceil(n / 16), 3) workgroups of 16 waves, one wave per batch row:
 //   y = 0 / 1  induced in-edge / out-edge CSR: count the row's kept neighbours (ballot + popcount, the
-//              kept ones' new ids stashed in LDS in edge order), publish the count, GRID BARRIER over the
-//              2 * gridDim.x workgroups of these two roles, prefix sum of the counts before the row ->
-//              row pointer, copy the stash (rows with more than 256 kept neighbours walk their list again);
+//              kept ones' new ids stashed in LDS in edge order), publish the workgroup's total, sum the
+//              totals of the workgroups before this one (decoupled look-back, below) -> row pointers, copy
+//              the stash (rows with more than 256 kept neighbours walk their list again);
 //   y = 2      feature + label gather (optionally with layer 0's dropout), independent of the others.
-// The barrier is a monotonic 64-bit ticket counter in `scratch` (every launch adds exactly
-// 2 * gridDim.x, gridDim.x fixed per scratch buffer); the host launches this kernel only when all its
-// barrier workgroups are co-resident (<= half of the device's workgroup slots), and a workgroup that
-// waits longer than ~1 s gives up and raises the error word instead of hanging the queue.
+// A workgroup that waits longer than ~1 s for a predecessor gives up and raises the error word instead
+// of hanging the queue.
 // Integer work: bit exact against the 5-launch path.
 struct PartsArgs {
     CsrPair p;
     const int32_t *ids;
     int n, n_max;
-    const int32_t *part_of, *pos_in_part, *part_batch, *part_row0;
+    const int32_t *node_part, *part_slot;   // [N][2] = (part, position), [parts][2] = (batch, first row)
     int batch;
     int64_t capacity;
     float *norm;
-    unsigned long long *ticket;      // scratch: [0] ticket counter, [1] error word
-    int32_t *counts;                 // scratch: [2][n_max] raw kept-neighbour counts
+    unsigned long long *error;       // scratch word [1]: raised when a workgroup gave up waiting
+    unsigned long long *slots;       // scratch: [2][gridDim.x] (launch epoch << 31 | kept-neighbour total)
+    unsigned long long epoch;        // this launch's number (never 0, never reused with this scratch)
     // gather
     const float *feat; int64_t ld_feat; int d;
     float *z0; int64_t ldz0;
@@ -272,13 +271,14 @@ struct PartsArgs {
 };
 
 constexpr int kStash = 256;
+constexpr int kPartsWaves = 16;
 
-__global__ __launch_bounds__(256) void extract_parts_kernel(PartsArgs a) {
-    __shared__ int32_t stash[4][kStash];
-    __shared__ int wsum[4];
-    __shared__ int wcnt[4];
+__global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsArgs a) {
+    __shared__ int32_t stash[kPartsWaves][kStash];
+    __shared__ int wcnt[kPartsWaves];
+    __shared__ int wbase;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave;
+    const int i = blockIdx.x * kPartsWaves + wave;
     if (blockIdx.y == 2) {                                   // ---- features + label of row i
         if (i >= a.n) return;
         const int v = a.ids[i];
@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256) void extract_parts_kernel(PartsArgs a) {
     }
     const int which = blockIdx.y;
     const int32_t *rowptr = a.p.rowptr[which], *col = a.p.col[which];
+    const int2 *node_part = reinterpret_cast<const int2 *>(a.node_part);
+    const int2 *part_slot = reinterpret_cast<const int2 *>(a.part_slot);
     const bool live = i < a.n;
     int beg = 0, end = 0;
     if (live) {
@@ -307,58 +309,89 @@ __global__ __launch_bounds__(256) void extract_parts_kernel(PartsArgs a) {
         beg = rowptr[v];
         end = rowptr[v + 1];
     }
-    auto new_id = [&](int e) {                               // row of neighbour e in this batch, or -1
-        const int u = col[e];
-        const int pid = a.part_of[u];
-        return a.part_batch[pid] == a.batch ? a.part_row0[pid] + a.pos_in_part[u] : -1;
+    auto new_id = [&](int e, bool in) {                      // row of neighbour e in this batch, or -1
+        if (!in) return -1;
+        const int2 np = node_part[col[e]];                   // (part, position in the part)
+        const int2 ps = part_slot[np.x];                     // (batch of the epoch, first row)
+        return ps.x == a.batch ? ps.y + np.y : -1;
     };
     int cnt = 0;
-    for (int base = beg; base < end; base += kWave) {
-        const int e = base + lane;
-        const int r = e < end ? new_id(e) : -1;
-        const unsigned long long m = __ballot(r >= 0);
-        if (r >= 0) {
-            const int pos = cnt + __popcll(m & ((1ULL << lane) - 1ULL));
-            if (pos < kStash) stash[wave][pos] = r;
+    for (int base = beg; base < end; base += 2 * kWave) {    // two chunks' loads in flight
+        const int e0 = base + lane, e1 = e0 + kWave;
+        const int r0 = new_id(e0, e0 < end), r1 = new_id(e1, e1 < end);
+        const unsigned long long m0 = __ballot(r0 >= 0), m1 = __ballot(r1 >= 0);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        if (r0 >= 0) {
+            const int pos = cnt + __popcll(m0 & below);
+            if (pos < kStash) stash[wave][pos] = r0;
         }
-        cnt += __popcll(m);
+        cnt += __popcll(m0);
+        if (r1 >= 0) {
+            const int pos = cnt + __popcll(m1 & below);
+            if (pos < kStash) stash[wave][pos] = r1;
+        }
+        cnt += __popcll(m1);
     }
-    int32_t *counts = a.counts + (int64_t)which * a.n_max;
     if (lane == 0) {
         wcnt[wave] = cnt;
-        if (live) {
-            __hip_atomic_store(counts + i, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (which == 0) a.norm[i] = cnt > 0 ? 1.f / (float)cnt : 0.f;
-        }
+        if (live && which == 0) a.norm[i] = cnt > 0 ? 1.f / (float)cnt : 0.f;
     }
-    // ---- grid barrier over the CSR roles ------------------------------------------------------------
-    __threadfence();                                         // every wave: its count is out at device scope
+    // ---- exclusive prefix over the workgroups: decoupled look-back, no barrier, no read-modify-write --
+    // Each workgroup PUBLISHES (launch epoch << 31 | its kept-neighbour total) in its own slot with one
+    // device-scope store and reads the slots of the workgroups BEFORE it (wave 0: up to 128 slots, two per
+    // lane), re-reading the ones whose epoch is not this launch's yet.  A workgroup waits only for
+    // lower-numbered ones, which the hardware dispatched earlier and which wait for nobody above them, so
+    // the chain always drains -- no co-residency condition.  (Measured first: a grid barrier on ONE ticket
+    // counter.  Device-scope read-modify-writes on one address complete at ~0.1-0.3 us each on this
+    // multi-die part: 260 arrivals took 26 us, 1030 took 340; device-scope FENCES write back and
+    // invalidate the XCD's whole L2, which the gather workgroups keep dirty: 206 us.)
+    unsigned long long *slots = a.slots + (int64_t)which * gridDim.x;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long nwg = 2ULL * gridDim.x;
-        const unsigned long long ticket = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = (ticket / nwg + 1ULL) * nwg;
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < kPartsWaves; ++k) t += wcnt[k];
+        __hip_atomic_store(slots + blockIdx.x, (a.epoch << 31) | (unsigned long long)(unsigned)t, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+        const int nb = (int)blockIdx.x;                      // slots to read: [0, nb)
+        unsigned long long v0 = 0, v1 = 0;
         long spins = 0;
-        while (__hip_atomic_load(a.ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1L << 23)) {                      // ~1 s: give up loudly, never hang
-                __hip_atomic_store(a.ticket + 1, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const bool need0 = lane < nb && (v0 >> 31) != a.epoch;
+            const bool need1 = lane + kWave < nb && (v1 >> 31) != a.epoch;
+            if (need0) v0 = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (need1) v1 = __hip_atomic_load(slots + lane + kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool miss = (lane < nb && (v0 >> 31) != a.epoch) || (lane + kWave < nb && (v1 >> 31) != a.epoch);
+            if (!__ballot(miss)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1L << 22)) {                      // ~1 s: give up loudly, never hang
+                if (lane == 0) __hip_atomic_store(a.error, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
+        int part = 0;
+        if (lane < nb) part += (int)(v0 & 0x7fffffffULL);
+        if (lane + kWave < nb) part += (int)(v1 & 0x7fffffffULL);
+        for (int k = lane + 2 * kWave; k < nb; k += kWave) {      // more than 128 workgroups before this one
+            unsigned long long v = 0;
+            long sp2 = 0;
+            while (((v = __hip_atomic_load(slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 31) != a.epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++sp2 > (1L << 22)) {
+                    __hip_atomic_store(a.error, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            part += (int)(v & 0x7fffffffULL);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) wbase = part;
     }
     __syncthreads();
-    __threadfence();
-    // ---- rows before this workgroup's first row: all 256 threads sum the published counts -----------
-    const int first = blockIdx.x * 4;
-    int part = 0;
-    for (int k = threadIdx.x; k < first; k += 256)
-        part += __hip_atomic_load(counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-    if (lane == 0) wsum[wave] = part;
-    __syncthreads();
-    int w = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int w = wbase;
     for (int k = 0; k < wave; ++k) w += wcnt[k];
     if (!live) return;
     int32_t *sub_rowptr = a.p.sub_rowptr[which], *sub_col = a.p.sub_col[which];
@@ -373,7 +406,7 @@ __global__ __launch_bounds__(256) void extract_parts_kernel(PartsArgs a) {
         int64_t wp = w;
         for (int base = beg; base < end; base += kWave) {
             const int e = base + lane;
-            const int r = e < end ? new_id(e) : -1;
+            const int r = new_id(e, e < end);
             const unsigned long long m = __ballot(r >= 0);
             if (r >= 0) {
                 const int64_t pos = wp + __popcll(m & ((1ULL << lane) - 1ULL));
@@ -668,54 +701,46 @@ extern "C" int gist_extract_batch_drop(const int32_t *g_rowptr, const int32_t *g
 
 // ---- one-launch extraction for batches that are unions of parts (see extract_parts_kernel) ------------
 extern "C" int64_t gist_extract_parts_scratch_bytes(int64_t n_max) {
-    return n_max <= 0 ? 0 : 16 + 8 * n_max;
+    return n_max <= 0 ? 0 : 16 + 16 * ceil_div(n_max, kPartsWaves);
 }
 
-// 1 if a batch buffer set sized for n_max rows may use gist_extract_parts_batch on the current device
+// 1 if gist_extract_parts_batch takes a buffer set sized for n_max rows
 extern "C" int gist_extract_parts_supported(int64_t n_max) {
-    if (n_max <= 0) return 0;
-    static std::atomic<int> cus{0};
-    int c = cus.load(std::memory_order_relaxed);
-    if (c == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-        cus.store(c, std::memory_order_relaxed);
-    }
-    // barrier workgroups (2 * ceil(n_max / 4), 256 threads, 4 KiB of LDS) must all be resident: a CU holds
-    // 8 such workgroups; use at most half of the slots
-    return 2 * ceil_div(n_max, 4) <= (int64_t)c * 4 ? 1 : 0;
+    return n_max > 0 && n_max < (1LL << 31) - 64 ? 1 : 0;
 }
 
 extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *g_col,
                                         const int32_t *g_t_rowptr, const int32_t *g_t_col,
                                         const int32_t *ids, int64_t n, int64_t n_max,
-                                        const int32_t *part_of, const int32_t *pos_in_part,
-                                        const int32_t *part_batch, const int32_t *part_row0, int32_t batch,
+                                        const int32_t *node_part, const int32_t *part_slot, int32_t batch,
                                         int32_t *rowptr, int32_t *col, int32_t *t_rowptr, int32_t *t_col,
                                         int64_t col_capacity, float *norm, const float *feat, int64_t ld_feat,
                                         int64_t n_feat, float *z0, int64_t ldz0, const int32_t *labels_all,
                                         int32_t *labels, float *x0, int64_t ldx0, float p, uint64_t seed,
                                         uint64_t offset, int64_t mask_ld, void *scratch, gist_stream_t stream) {
     GIST_REQUIRE(n > 0 && n <= n_max && n_max < (1LL << 31) - 8, "gist_extract_parts_batch: bad n");
-    GIST_REQUIRE(g_rowptr && g_col && g_t_rowptr && g_t_col && ids && part_of && pos_in_part && part_batch &&
-                     part_row0 && rowptr && col && t_rowptr && t_col && norm && feat && z0 && scratch,
+    GIST_REQUIRE(g_rowptr && g_col && g_t_rowptr && g_t_col && ids && node_part && part_slot && rowptr && col &&
+                     t_rowptr && t_col && norm && feat && z0 && scratch,
                  "gist_extract_parts_batch: null pointer");
+    GIST_REQUIRE(aligned8(node_part) && aligned8(part_slot), "gist_extract_parts_batch: tables must be 8-byte aligned");
     GIST_REQUIRE(n_feat > 0 && ld_feat >= n_feat && ldz0 >= n_feat && n_feat < (1LL << 31),
                  "gist_extract_parts_batch: bad feature shape");
     GIST_REQUIRE(col_capacity >= 0 && batch >= 0, "gist_extract_parts_batch: bad capacity / batch index");
     GIST_REQUIRE(aligned8(scratch), "gist_extract_parts_batch: scratch must be 8-byte aligned");
-    GIST_REQUIRE(gist_extract_parts_supported(n_max) == 1,
-                 "gist_extract_parts_batch: n_max too large for a one-launch extraction on this device");
+    GIST_REQUIRE(gist_extract_parts_supported(n_max) == 1, "gist_extract_parts_batch: bad n_max");
+    // launch epochs: process-wide, never 0 (a zeroed scratch matches no launch), never reused
+    static std::atomic<unsigned long long> g_epoch{0};
+    const unsigned long long epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) + 1) & ((1ULL << 33) - 1);
+    GIST_REQUIRE(epoch != 0, "gist_extract_parts_batch: launch counter exhausted");
     PartsArgs a{};
     a.p.rowptr[0] = g_rowptr; a.p.col[0] = g_col; a.p.sub_rowptr[0] = rowptr; a.p.sub_col[0] = col;
     a.p.rowptr[1] = g_t_rowptr; a.p.col[1] = g_t_col; a.p.sub_rowptr[1] = t_rowptr; a.p.sub_col[1] = t_col;
     a.ids = ids; a.n = (int)n; a.n_max = (int)n_max;
-    a.part_of = part_of; a.pos_in_part = pos_in_part; a.part_batch = part_batch; a.part_row0 = part_row0;
+    a.node_part = node_part; a.part_slot = part_slot;
     a.batch = batch; a.capacity = col_capacity; a.norm = norm;
-    a.ticket = static_cast<unsigned long long *>(scratch);
-    a.counts = reinterpret_cast<int32_t *>(static_cast<char *>(scratch) + 16);
+    a.error = static_cast<unsigned long long *>(scratch) + 1;
+    a.slots = static_cast<unsigned long long *>(scratch) + 2;
+    a.epoch = epoch;
     a.feat = feat; a.ld_feat = ld_feat; a.d = (int)n_feat; a.z0 = z0; a.ldz0 = ldz0;
     a.labels_all = labels_all; a.labels = labels;
     a.drop = 0;
@@ -726,7 +751,7 @@ extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *
         a.gd.x0 = x0; a.gd.ldx0 = ldx0; a.gd.p = p; a.gd.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
         a.gd.sm = seed * 0x9E3779B97F4A7C15ULL; a.gd.offset = offset; a.gd.mask_ld = mask_ld;
     }
-    hipLaunchKernelGGL(extract_parts_kernel, dim3((unsigned)ceil_div(n_max, 4), 3), dim3(256), 0,
-                       as_stream(stream), a);
+    hipLaunchKernelGGL(extract_parts_kernel, dim3((unsigned)ceil_div(n, kPartsWaves), 3),
+                       dim3(64 * kPartsWaves), 0, as_stream(stream), a);
     return launch_status("gist_extract_parts_batch");
 }

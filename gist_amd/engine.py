@@ -89,7 +89,7 @@ class Batch(object):
         self.ready = True
         self.row_blocks = None      # int32 [n_blocks + 1]: row ranges of the batch's METIS parts
         self.batcher = None         # set on lazy batches: who extracts them
-        self.parts = None           # (part_of, pos_in_part, [part_batch; part_row0], batch index) -- sampler
+        self.parts = None           # (node_part [N, 2], part_slot [parts, 2], batch index) -- sampler
 
 
 class ClusterBatcher(object):
@@ -360,15 +360,14 @@ class SageEngine(object):
         # one-launch extraction when the batch comes with its part tables (gist_extract_parts_batch)
         P = self.plan
         if b.parts is not None and not b.ready and self.fuse and L.gist_extract_parts_supported(self.n_max):
-            part_of, pos, tab, j = b.parts
+            node_part, tab, j = b.parts
             if self._extract_scratch is None:
                 self._extract_scratch = torch.zeros(int(L.gist_extract_parts_scratch_bytes(self.n_max)) // 8 + 1,
                                                     dtype=torch.int64, device=self.device)
-            P.part_of, P.pos_in_part = part_of.data_ptr(), pos.data_ptr()
-            P.part_batch, P.part_row0 = tab[0].data_ptr(), tab[1].data_ptr()
+            P.node_part, P.part_slot = node_part.data_ptr(), tab.data_ptr()
             P.batch_index, P.extract_scratch = int(j), self._extract_scratch.data_ptr()
         else:
-            P.part_of = P.pos_in_part = P.part_batch = P.part_row0 = P.extract_scratch = None
+            P.node_part = P.part_slot = P.extract_scratch = None
             P.batch_index = -1
         rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
                               eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())

@@ -151,7 +151,7 @@ class EngineClusterIter(ClusterIter):
         self._offsets = None
         # One-launch extraction (gist_extract_parts_batch): every node's part and position in it.  Only
         # when the parts really partition the train graph (disjoint; the reference's METIS output is).
-        self._part_of = self._pos_in_part = None
+        self._node_part = None
         n_nodes = tg.number_of_nodes()
         total = sum(len(p) for p in self.par_li)
         if 0 < total <= n_nodes:
@@ -171,8 +171,7 @@ class EngineClusterIter(ClusterIter):
                 # epoch table maps to a batch
                 part_of[part_of < 0] = len(self.par_li)
                 self._part_of_host = part_of
-                self._part_of = torch.from_numpy(part_of).to(tg.device)
-                self._pos_in_part = torch.from_numpy(pos).to(tg.device)
+                self._node_part = torch.from_numpy(np.stack([part_of, pos], 1).copy()).to(tg.device)   # [N, 2]
         self._extract_scratch = None
 
     def bind(self, engine, native=True):
@@ -215,9 +214,9 @@ class EngineClusterIter(ClusterIter):
         self._block_offsets = boff
         # which batch of this epoch each part belongs to, and the batch row of its first node
         self._part_tables = None
-        if self._part_of is not None:
+        if self._node_part is not None:
             n_parts = len(self.par_li) + 1
-            tab = np.full((2, n_parts), -1, np.int32)
+            tab = np.full((n_parts, 2), -1, np.int32)
             row = 0
             for s_, p in enumerate(used):
                 j = s_ // self.batch_size
@@ -225,7 +224,7 @@ class EngineClusterIter(ClusterIter):
                     row = 0
                 if len(p):
                     pid = int(self._part_of_host[p[0]])
-                    tab[0, pid], tab[1, pid] = j, row
+                    tab[pid, 0], tab[pid, 1] = j, row
                 row += len(p)
             self._part_tables = torch.from_numpy(tab).to(self.g.device)
 
@@ -248,7 +247,7 @@ class EngineClusterIter(ClusterIter):
             batch.row_blocks = self._epoch_blocks[int(self._block_offsets[self.n]):
                                                   int(self._block_offsets[self.n + 1])]
             if self._part_tables is not None:
-                batch.parts = (self._part_of, self._pos_in_part, self._part_tables, self.n)
+                batch.parts = (self._node_part, self._part_tables, self.n)
             self.n += 1
             return batch
         random.shuffle(self.par_li)

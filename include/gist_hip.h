@@ -416,25 +416,23 @@ int gist_extract_batch_drop(const int32_t *g_rowptr, const int32_t *g_col,
                             int64_t mask_ld, gist_stream_t stream);
 
 /* The same extraction in ONE launch for batches that are unions of parts of a fixed partition -- what
- * ClusterIter yields (cluster_gcn/sampler.py:85-93): part_of[v] / pos_in_part[v] give node v's part and its
- * position in the part's id list (static), part_batch[p] / part_row0[p] the batch of the current epoch that
- * part p belongs to (-1: none) and the batch row of its first node (uploaded with the epoch's part order),
- * so membership needs no mark pass and ids[part_row0[p] + pos] must be the pos-th node of part p.  One
- * kernel counts, scans (a grid barrier over its own workgroups) and fills both CSRs while a third group of
- * workgroups gathers features and labels; x0 != NULL folds layer 0's dropout in as
+ * ClusterIter yields (cluster_gcn/sampler.py:85-93): node_part[v] = (v's part, v's position in the part's id
+ * list) (int32 pairs, static), part_slot[p] = (the batch of the current epoch that part p belongs to, -1:
+ * none; the batch row of its first node) (int32 pairs, uploaded with the epoch's part order), so membership
+ * needs no mark pass and ids[row0(p) + pos] must be the pos-th node of part p.  Both 8-byte aligned.  One
+ * kernel counts, scans (a look-back over its own workgroups' totals: no barrier) and fills both CSRs while
+ * a third group of workgroups gathers features and labels; x0 != NULL folds layer 0's dropout in as
  * gist_extract_batch_drop does.  Same result as gist_extract_batch, bit for bit.
- * scratch: gist_extract_parts_scratch_bytes(n_max) bytes, 8-byte aligned, ZEROED ONCE by the caller and
- * then used with the same n_max on every call (it carries the barrier's ticket counter; word [1] != 0
- * after a call = a workgroup gave up waiting, results invalid).  gist_extract_parts_supported(n_max):
- * 1 if the barrier workgroups of a buffer set of n_max rows are all resident on the current device
- * (otherwise GIST_EINVAL: use gist_extract_batch).  Host functions both. */
+ * scratch: gist_extract_parts_scratch_bytes(n_max) bytes, 8-byte aligned, ZEROED ONCE by the caller (it
+ * carries the workgroups' published totals, tagged with a per-launch number; word [1] != 0 after a call =
+ * a workgroup gave up waiting for a predecessor after ~1 s, results invalid).  Calls sharing a scratch must
+ * be stream-ordered.  gist_extract_parts_supported(n_max): 1 if n_max is in range.  Host functions both. */
 int64_t gist_extract_parts_scratch_bytes(int64_t n_max);
 int gist_extract_parts_supported(int64_t n_max);
 int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *g_col,
                              const int32_t *g_t_rowptr, const int32_t *g_t_col,
                              const int32_t *ids, int64_t n, int64_t n_max,
-                             const int32_t *part_of, const int32_t *pos_in_part,
-                             const int32_t *part_batch, const int32_t *part_row0, int32_t batch,
+                             const int32_t *node_part, const int32_t *part_slot, int32_t batch,
                              int32_t *rowptr, int32_t *col, int32_t *t_rowptr, int32_t *t_col,
                              int64_t col_capacity, float *norm,
                              const float *feat, int64_t ld_feat, int64_t n_feat,
@@ -574,10 +572,10 @@ typedef struct gist_step_plan {
     float *hsrc[GIST_MAX_LAYERS]; int64_t ld_hsrc[GIST_MAX_LAYERS];   /* ld % 4 == 0 and >= n_in + 2 keeps the 16-byte gathers */
     float *col_partials;
     void *fused_workspace; int64_t fused_workspace_bytes;
-    /* One-launch extraction (gist_extract_parts_batch) when the batch is a union of parts: static part_of /
-     * pos_in_part, the epoch's part_batch / part_row0, this batch's index in the epoch (set per call) and
-     * the zeroed scratch; any NULL = gist_extract_batch (5 launches). */
-    const int32_t *part_of, *pos_in_part, *part_batch, *part_row0;
+    /* One-launch extraction (gist_extract_parts_batch) when the batch is a union of parts: the static
+     * node_part, the epoch's part_slot, this batch's index in the epoch (set per call) and the zeroed
+     * scratch; any NULL = gist_extract_batch (5 launches). */
+    const int32_t *node_part, *part_slot;
     int32_t batch_index;
     void *extract_scratch;
 } gist_step_plan;

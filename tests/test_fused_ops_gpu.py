@@ -317,7 +317,7 @@ def test_one_launch_extraction_equals_five_launches(hip, n_feats, with_drop):
     ld = n_feats + (2 if n_feats % 4 else 0)
     for epoch in range(2):
         it.__iter__()
-        part_of, pos, tab = it._part_of, it._pos_in_part, it._part_tables
+        node_part, tab = it._node_part, it._part_tables
         assert tab is not None
         for j in range(len(it)):
             a, b = int(it._offsets[j]), int(it._offsets[j + 1])
@@ -332,8 +332,7 @@ def test_one_launch_extraction_equals_five_launches(hip, n_feats, with_drop):
             fp, ldf = bt.feat.data_ptr(), bt.feat.stride(0)
             rc = L.gist_extract_parts_batch(
                 g.rowptr.data_ptr(), g.col.data_ptr(), g.t_rowptr.data_ptr(), g.t_col.data_ptr(),
-                ids.data_ptr(), n, n_max, part_of.data_ptr(), pos.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(),
-                j, rp2.data_ptr(), cl2.data_ptr(), trp2.data_ptr(), tcl2.data_ptr(), cl2.numel(),
+                ids.data_ptr(), n, n_max, node_part.data_ptr(), tab.data_ptr(), j, rp2.data_ptr(), cl2.data_ptr(), trp2.data_ptr(), tcl2.data_ptr(), cl2.numel(),
                 norm2.data_ptr(), fp, ldf, n_feats, z_new.data_ptr(), 2 * n_feats, bt.labels.data_ptr(),
                 lab2.data_ptr(), x_new.data_ptr() if with_drop else None, ld, 0.3, 11, 1000 * j, 2 * n_feats,
                 scratch.data_ptr(), hip._stream())
@@ -348,12 +347,46 @@ def test_one_launch_extraction_equals_five_launches(hip, n_feats, with_drop):
     assert int(scratch[1].item()) == 0           # no workgroup ever gave up at the barrier
 
 
-def test_one_launch_extraction_rejects_oversized_buffers(hip):
+def test_one_launch_extraction_large_batch(hip):
+    """More than 128 workgroups per CSR (n > 2048 rows: the look-back's third and later slots per lane)
+    and a hub row with more kept neighbours than the LDS stash holds."""
     from gist_amd import _lib
     L = _lib.load()
-    assert L.gist_extract_parts_supported(2048) == 1
-    assert L.gist_extract_parts_supported(1 << 20) == 0
-    assert L.gist_extract_parts_supported(0) == 0
+    from gist_amd import datasets
+    from gist_amd.sampler import EngineClusterIter
+    ds = datasets.make_block_dataset('hubs', 6000, 12, 16, 6, intra_deg=8, inter_deg=2, seed=3, hub_frac=0.002,
+                                     hub_mult=60)
+    random.seed(4)
+    it = EngineClusterIter('hubs', ds.g, len(ds.par_li), 6, np.arange(6000, dtype=np.int64),
+                           par_li=[p.copy() for p in ds.par_li], device=torch.device(DEV))
+    bt = it.batcher
+    n_max = it.n_max
+    assert n_max > 2500 and L.gist_extract_parts_supported(n_max) == 1
+    scratch = torch.zeros(int(L.gist_extract_parts_scratch_bytes(n_max)) // 8 + 1, dtype=torch.int64, device=DEV)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    rp2, trp2 = torch.zeros(n_max + 1, **i32), torch.zeros(n_max + 1, **i32)
+    cl2, tcl2 = torch.zeros(bt.col.numel(), **i32), torch.zeros(bt.col.numel(), **i32)
+    norm2, lab2 = torch.zeros(n_max, device=DEV), torch.zeros(n_max, **i32)
+    g = bt.g
+    it.__iter__()
+    for j in range(len(it)):
+        a, b = int(it._offsets[j]), int(it._offsets[j + 1])
+        ids, n = it._epoch_ids[a:b], b - a
+        z_ref, z_new = torch.zeros(n, 32, device=DEV), torch.zeros(n, 32, device=DEV)
+        ref = bt.extract(ids, z_ref[:, :16])
+        _lib.check(L.gist_extract_parts_batch(
+            g.rowptr.data_ptr(), g.col.data_ptr(), g.t_rowptr.data_ptr(), g.t_col.data_ptr(), ids.data_ptr(), n,
+            n_max, it._node_part.data_ptr(), it._part_tables.data_ptr(), j, rp2.data_ptr(), cl2.data_ptr(),
+            trp2.data_ptr(), tcl2.data_ptr(), cl2.numel(), norm2.data_ptr(), bt.feat.data_ptr(), bt.feat.stride(0),
+            16, z_new.data_ptr(), 32, bt.labels.data_ptr(), lab2.data_ptr(), None, 0, 0.0, 0, 0, 0,
+            scratch.data_ptr(), hip._stream()), 'gist_extract_parts_batch')
+        nnz = int(ref.rowptr[n].item())
+        assert int((ref.rowptr[1:n + 1] - ref.rowptr[:n]).max().item()) > 256      # a row beyond the stash
+        assert torch.equal(rp2[:n + 1], ref.rowptr[:n + 1]) and torch.equal(cl2[:nnz], ref.col[:nnz])
+        assert torch.equal(trp2[:n + 1], ref.t_rowptr[:n + 1])
+        assert torch.equal(tcl2[:int(trp2[n].item())], ref.t_col[:int(trp2[n].item())])
+        assert torch.equal(z_new, z_ref) and torch.equal(norm2[:n], ref.norm[:n])
+    assert int(scratch[1].item()) == 0
 
 
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
@@ -383,6 +416,7 @@ def test_native_step_fused_equals_unfused(hip, monkeypatch, p_drop):
                 if j == 3:
                     break
             eng.check_extract()
+            assert (eng._extract_scratch is not None) == (fuse == '1')      # the one-launch extraction ran
             res.append((eng.arena.params.clone(), torch.stack(losses), eng.arena.grads.clone()))
         assert (res[0][1] - res[1][1]).abs().max().item() < 1e-6
         assert (res[0][2] - res[1][2]).abs().max().item() < 1e-5 * max(1.0, res[0][2].abs().max().item())
