@@ -462,7 +462,8 @@ def test_config5_ultra_wide_H32768_S8():
     assert abs(float(loss.item()) - float(ref_loss)) < TOL
     assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max())
     errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in zip(m0.sub.export(), params)])
-    assert float(errs.mean()) < 1e-5 and float((errs > TOL).mean()) < 2e-2
+    stats = (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
+    _parity_ok('config5_sub_step_vs_oracle', 'bf16x3', 4096, stats)
     m0.sub.params.copy_(saved)
     m0.sub.reset_optimizer()
     del saved, params, errs
@@ -574,6 +575,39 @@ def _steps_vs_oracle(ds, batch_parts, n_hidden, n_layers, n_steps, p_seed):
                        max=float(errs.max()))
 
 
+# Post-Adam parameters against the reference at the metric's widths.  Bars = 2x the values measured on
+# MI355X for each case (profiles/r03_parity_stats.txt: mean |diff|, fraction of weights above 1e-4;
+# GIST_PARITY_STATS=<file> appends the statistics of a run).  Round 2 used one bar for all: 1e-5 / 2e-2.
+PARITY_BARS = {
+    ('metric_config_vs_oracle', 'f32', 4096): (6.8e-6, 1.02e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 4096): (6.7e-6, 1.0e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 2048): (1.12e-5, 1.74e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 1024): (5.7e-6, 6.6e-3),
+    ('metric_config_vs_oracle', 'bf16x3', 512): (7.5e-7, 1.07e-3),
+    ('metric_config_vs_oracle', 'f16x3', 4096): (4.3e-6, 5.7e-3),
+    ('metric_config_vs_oracle', 'f16x3', 2048): (1.12e-5, 1.74e-2),
+    ('metric_config_vs_oracle', 'f16x3', 1024): (7.0e-6, 7.7e-3),
+    ('config5_sub_step_vs_oracle', 'bf16x3', 4096): (4.0e-6, 1.1e-3),
+    ('kept_vs_per_call_splits', 'f16x3', 4096): (2.0e-8, 2.2e-5),
+    ('kept_vs_per_call_splits', 'bf16x3', 4096): (1.5e-9, 1.0e-6),
+    ('wide_class_layer_split_vs_f32', 'f16x3', 2048): (6.5e-7, 4.3e-4),
+    ('wide_class_layer_split_vs_f32', 'bf16x3', 2048): (4.9e-7, 3.5e-4),
+}
+
+
+def _parity_ok(test, mode, hidden, stats):
+    _record_parity(test, mode, hidden, stats)
+    mean_bar, frac_bar = PARITY_BARS[(test, mode, hidden)]
+    assert stats[0] < mean_bar and stats[1] < frac_bar, (test, mode, hidden, stats, (mean_bar, frac_bar))
+
+
+def _record_parity(test, mode, hidden, stats):
+    path = os.environ.get('GIST_PARITY_STATS')
+    if path:
+        with open(path, 'a') as f:
+            f.write('%s mode=%s hidden=%d mean=%.3e frac_over_1e-4=%.3e max=%.3e\n' % ((test, mode, hidden) + stats))
+
+
 def _check(loss_err, pstats):
     """Outputs (losses) are held to 1e-4.  Parameters AFTER Adam steps are checked in
     distribution: Adam divides the first moment by sqrt(second moment), so where a gradient is
@@ -634,6 +668,7 @@ def _metric_config_engine(mode, hidden=4096):
 
 
 @pytest.mark.parametrize('mode,hidden', [('f32', 4096), ('bf16x3', 4096), ('bf16x3', 2048),
+                                         ('bf16x3', 1024), ('bf16x3', 512),     # (both: every GEMM on the fp32 MFMA)
                                          ('f16x3', 4096), ('f16x3', 2048), ('f16x3', 1024)])
 def test_metric_config_hidden4096_vs_oracle(mode, hidden):
     """Metric configuration (and the per-rank widths of the 2- and 4-GPU points), 2 full training
@@ -649,8 +684,8 @@ def test_metric_config_hidden4096_vs_oracle(mode, hidden):
     try:
         ds, it, eng, dims, params = _metric_config_engine(mode, hidden)
         it.bind(eng)
-        if mode != 'f32':         # layer 1 (and 0) keep their split operands
-            assert eng.plan.h3_workspace is not None
+        if mode != 'f32' and hidden >= 1024:         # layer 1 (and 0) keep their split operands
+            assert eng.plan.h3_workspace is not None    # (width 512: no projection reaches a split path)
         g = ds.g
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
                            g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
@@ -668,8 +703,8 @@ def test_metric_config_hidden4096_vs_oracle(mode, hidden):
                 break
         errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in
                                zip(eng.arena.export(), params)])
-        assert float(errs.mean()) < 1e-5 and float((errs > TOL).mean()) < 2e-2, \
-            (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
+        stats = (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
+        _parity_ok('metric_config_vs_oracle', mode, hidden, stats)
     finally:
         hip.gemm_mode(prev)
 
@@ -770,8 +805,8 @@ def test_step_kept_split_operands_equal_per_call_splits(monkeypatch, mode):
         assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
         assert la[0] > 3.0 and abs(la[0] - la[2]) > 1e-3          # it did train, with dropout
         d = (runs['per_call'][1] - runs['kept'][1]).abs()
-        assert d.mean().item() < 1e-5 and (d > TOL).float().mean().item() < 2e-2, \
-            (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+        stats = (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+        _parity_ok('kept_vs_per_call_splits', mode, 4096, stats)
     finally:
         hip.gemm_mode(prev)
 
@@ -818,8 +853,8 @@ def test_wide_class_layer_stays_off_the_kept_split_path():
             assert all(np.isfinite(lb)) and torch.isfinite(runs[split][1]).all()
             assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (split, la, lb)
             d = (runs['f32'][1] - runs[split][1]).abs()
-            assert d.mean().item() < 1e-5 and (d > TOL).float().mean().item() < 2e-2, \
-                (split, d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+            stats = (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())
+            _parity_ok('wide_class_layer_split_vs_f32', split, 2048, stats)
     finally:
         hip.gemm_mode(prev)
 

@@ -102,3 +102,32 @@ def test_bench_two_ranks_on_the_split_projection_path():
     assert out['roofline_spmm']['kernel'].startswith('gist::spmm_csr_mfma_kernel')
     assert math.isfinite(out['loss_first']) and math.isfinite(out['loss_last'])
     assert out['weight_sync']['syncs_inside_timed_region'] >= 2
+
+
+@pytest.mark.parametrize('n_hidden,per_rank', [(4096, 1024), (2048, 512)])
+def test_bench_four_ranks_per_rank_widths_with_redispatch(n_hidden, per_rank):
+    """Four rank processes (the pool allows at most six processes on one card, so the 8-rank point is
+    rehearsed by its per-rank WIDTH instead: 2048 / 4 = 512 = 4096 / 8) through 78 iterations with a weight
+    exchange every 20: the run crosses into epoch 1, so the sub-GCNs are RE-DISPATCHED under new partitions
+    (cluster_gcn_ist_distrib.py:400-403) and trained on; the fused step at the per-rank widths of the N = 4
+    and N = 8 points (fp32 MFMA projections, one-launch extraction, deferred reductions).  Shared-GPU
+    validation mode: a first SCALE run must not die on a width-specific path."""
+    env = dict(os.environ, GIST_BENCH_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '78', '--warmup', '2',
+           '--n-hidden', str(n_hidden), '--iter-per-site', '20', '--timing-every', '16']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert out['n_gpus'] == 4 and out['config']['num_subnet'] == 4 and out['rccl_ranks'] == 4
+    assert out['dtype'] == 'f32'                           # every projection of this width on the fp32 MFMA
+    assert out['epochs_per_sec_per_rank'] > 0 and 'SUM over the 4 ranks' in out['scaling_note']
+    assert abs(out['value'] - 4 * out['epochs_per_sec_per_rank']) < 1e-3 * out['value']
+    assert len(out['per_rank_ms_per_step']) == 4
+    assert math.isfinite(out['loss_first']) and math.isfinite(out['loss_last'])
+    ws = out['weight_sync']
+    assert ws['syncs_inside_timed_region'] == 4             # iterations 20, 40, 60, 80
+    assert ws['all_gather_bytes_total'] == 4 * ws['all_gather_bytes_per_rank']
+    assert out['config']['workload'].endswith('(cluster_gcn_ist_distrib.py path)')
+    assert 'width %d' % per_rank in out['config']['workload']
