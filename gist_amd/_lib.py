@@ -76,6 +76,7 @@ SIGNATURES = {
     'gist_timer_count': (_i64, [_p]),
     'gist_timer_read': (_int, [_p, _i64, _p, _p, _p, _p, _p]),
     'gist_step_h3_workspace_bytes': (_i64, [_p]),
+    'gist_step_h3_workspace_bytes_mode': (_i64, [_p, _int]),
     'gist_step_fused_workspace_bytes': (_i64, [_p]),
     'gist_step_col_partials_floats': (_i64, [_p]),
     'gist_step_fused_slab_bytes': (_i64, [_p, _i32]),

@@ -75,6 +75,7 @@ int h3_gemm_presplit(const char *name, const uint32_t *sa, const float *inv_a, c
 // gemm_b3.hip: the bf16x3 split projection path (all 24 operand bits, no scales).  Split operand =
 // [rows][b3_kpad(k)] elements of 6 bytes (three bf16 pieces per element, 16-byte chunks per 8 k).
 int h3_mode();                        // 0 fp32 MFMA, 1 f16x3, 2 bf16x3 (gist_gemm_set_mode)
+void h3_mode_override(int mode);      // >= 0: h3_mode() of THIS thread returns it (sizing queries); -1: off
 int64_t b3_kpad(int64_t k);
 bool b3_eligible(int64_t m, int64_t n, int64_t k);
 bool b3_eligible_kept(int64_t m, int64_t n, int64_t k);

@@ -496,6 +496,10 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
         }
         once.done(dev);
     }
+    if (ldc * B3_TM * 4 >= (1LL << 31)) {      // the store epilogue's 32-bit byte offsets: 256 rows x ldc
+        set_error("%s: leading dimension of the output >= 2^21 elements on the bf16x3 path", name);
+        return GIST_EINVAL;
+    }
     B3Args g;
     const int64_t kpad = b3_kpad(k);
     g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.bias = bias; g.c = c; g.ldc = ldc;
@@ -524,6 +528,7 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
             int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
             void *ws, int64_t ws_bytes, hipStream_t st) {
     if (!b3_eligible(m, n, k)) return 0;
+    if (ldc * B3_TM * 4 >= (1LL << 31)) return 0;      // the store epilogue's 32-bit byte offsets: 256 rows x ldc
     if (ws == nullptr || !aligned16(ws) || ws_bytes < b3_workspace_bytes(m, n, k)) return 0;
     const int64_t kpad = b3_kpad(k);
     uint16_t *sa = static_cast<uint16_t *>(ws);

@@ -557,20 +557,29 @@ template __global__ void gemm_h3_kernel<128>(H3Args);
 template __global__ void gemm_h3_kernel<64>(H3Args);
 
 // ---- host side ----------------------------------------------------------------------------
-static int g_h3_mode = -1;      // -1: read GIST_GEMM_MODE on first use
+static std::atomic<int> g_h3_mode{-1};      // -1: read GIST_GEMM_MODE on first use
+// A sizing query "as if the mode were m" (gist_step_h3_workspace_bytes_mode) sets this for the calling
+// thread only: launches of other threads keep seeing the process-wide mode.
+thread_local int tl_mode_override = -1;
 
 int h3_mode() {
-    if (g_h3_mode < 0) {
+    if (tl_mode_override >= 0) return tl_mode_override;
+    int m = g_h3_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
         const char *e = getenv("GIST_GEMM_MODE");
         // default: large projections as three bf16 pieces per operand (all 24 bits, six cross terms:
         // error at the fp32-MFMA kernel's level, gemm_b3.hip), everything else fp32 MFMA
-        g_h3_mode = 2;
-        if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) g_h3_mode = 0;
-        else if (e && (!strcmp(e, "f16x3") || !strcmp(e, "1"))) g_h3_mode = 1;
-        else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "2"))) g_h3_mode = 2;
+        m = 2;
+        if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) m = 0;
+        else if (e && (!strcmp(e, "f16x3") || !strcmp(e, "1"))) m = 1;
+        else if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "2"))) m = 2;
+        int expected = -1;
+        g_h3_mode.compare_exchange_strong(expected, m, std::memory_order_relaxed);
+        m = g_h3_mode.load(std::memory_order_relaxed);
     }
-    return g_h3_mode;
+    return m;
 }
+void h3_mode_override(int mode) { tl_mode_override = mode; }
 
 int64_t h3_kpad(int64_t k) { return ceil_div(k, H3_BK) * H3_BK; }
 
@@ -711,7 +720,7 @@ int h3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
 extern "C" int gist_gemm_set_mode(int mode) {
     GIST_REQUIRE(mode >= 0 && mode <= 2,
                  "gist_gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (f16x3 split) or 2 (bf16x3 split)");
-    gist::g_h3_mode = mode;
+    gist::g_h3_mode.store(mode, std::memory_order_relaxed);
     return GIST_OK;
 }
 

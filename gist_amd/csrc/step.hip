@@ -210,7 +210,8 @@ B3Step b3_layout(const gist_step_plan *p, char *base) {
         const int64_t i2 = 2 * l.n_in, o = l.n_out;
         B3Layer &hl = h.layer[k];
         hl.on = b3_eligible_kept(n, o, i2) && b3_eligible_kept(o, i2, n) &&
-                (k == 0 || b3_eligible_kept(n, i2, o));
+                (k == 0 || b3_eligible_kept(n, i2, o)) &&
+                l.ldy < (1LL << 21) && i2 < (1LL << 21);      // 32-bit byte offsets of a 256-row C tile
         if (!hl.on) continue;
         h.any = true;
         hl.Zs = take(n * b3_kpad(i2) * 6);
@@ -221,8 +222,10 @@ B3Step b3_layout(const gist_step_plan *p, char *base) {
         // split-K slabs: the slice count depends on the batch rows through the tile count, and a batch
         // may have fewer rows than n_max (one 256-row tile less can double the slices): the largest
         // need over every row count up to n_max (the launcher uses one slice if the slab is too small)
+        // (sampled at every row count that changes a tile count AND at every row count that changes the
+        // number of 64-row k pairs of the dW projection: the slice count is not monotone in either)
         int64_t sb = 0;
-        for (int64_t rows = n; rows > 0; rows = (rows - 1) / 256 * 256) {
+        for (int64_t rows = n; rows > 0; rows = (rows - 1) / 64 * 64) {
             const int64_t need[3] = {b3_slab_bytes(rows, o, i2), b3_slab_bytes(o, i2, rows),
                                      k > 0 ? b3_slab_bytes(rows, i2, o) : 0};
             for (int q = 0; q < 3; ++q) sb = need[q] > sb ? need[q] : sb;
@@ -306,6 +309,16 @@ extern "C" int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan) {
     if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS) return 0;
     if (gist_gemm_get_mode() == 2) return b3_layout(plan, nullptr).bytes;
     return h3_layout(plan, nullptr).bytes;
+}
+
+// the same for a given GEMM mode, without touching the process-wide one (a caller that sizes for every
+// mode it may switch to must not change the arithmetic of launches other threads issue meanwhile)
+extern "C" int64_t gist_step_h3_workspace_bytes_mode(const gist_step_plan *plan, int mode) {
+    if (mode < 0 || mode > 2) return 0;
+    h3_mode_override(mode);
+    const int64_t need = gist_step_h3_workspace_bytes(plan);
+    h3_mode_override(-1);
+    return need;
 }
 
 // The step's aggregations: the blocked kernels when the batch comes with its locality blocks; with the

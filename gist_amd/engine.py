@@ -260,12 +260,8 @@ class SageEngine(object):
         L_ = _lib.load()
         cur = L_.gist_gemm_get_mode()
         need = 0
-        try:
-            for m_ in ((1, 2) if cur != 0 else ()):
-                _lib.check(L_.gist_gemm_set_mode(m_), 'gist_gemm_set_mode')
-                need = max(need, L_.gist_step_h3_workspace_bytes(ctypes.byref(P)))
-        finally:
-            _lib.check(L_.gist_gemm_set_mode(cur), 'gist_gemm_set_mode')
+        for m_ in ((1, 2) if cur != 0 else ()):      # (a query per mode: the process-wide mode is not touched)
+            need = max(need, L_.gist_step_h3_workspace_bytes_mode(ctypes.byref(P), m_))
         self._h3_ws = None
         if need > 0 and os.environ.get('GIST_STEP_H3', '1') != '0':
             self._h3_ws = torch.empty(need, dtype=torch.uint8, device=self.device)

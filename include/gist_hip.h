@@ -591,6 +591,9 @@ int64_t gist_step_fused_slab_bytes(const gist_step_plan *plan, int32_t k);
 /* Bytes of h3_workspace the plan's shapes need in the current GEMM mode (0: no layer qualifies, or
  * mode 0). Host function. */
 int64_t gist_step_h3_workspace_bytes(const gist_step_plan *plan);
+/* The same for GEMM mode `mode` (0, 1, 2) whatever the current one: size for every mode the steps may be
+ * switched to without changing the process-wide mode under other threads' launches. */
+int64_t gist_step_h3_workspace_bytes_mode(const gist_step_plan *plan, int mode);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream by the step
  * driver around every SpMM and GEMM call (what bench.py's `roofline` is computed from).

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for mode in bf16x3 f16x3; do

@@ -2,6 +2,7 @@
 # On the GPU box (gpurun): the measurements kept under profiles/ -- bench line, kernel stats of
 # the same command, PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy / active cycles: separate
 # runs, counters only), full-graph evaluation, per-rank widths of the N = 2/4/8 points.
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O

@@ -6,6 +6,7 @@
 # evaluation.  Probe libraries (built here beforehand, they travel with the snapshot):
 #   GIST_EXTRA_FLAGS=-DMF_PROBE GIST_LIB_OUT=$PWD/gist_amd/libgist_hip_MFP.so python gist_amd/build.py
 #   GIST_EXTRA_FLAGS=-DB3_CLOCK_PROBE GIST_LIB_OUT=$PWD/gist_amd/libgist_hip_CLK.so python gist_amd/build.py
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final_r2
 rm -rf $O; mkdir -p $O

@@ -1,3 +1,4 @@
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final_r2
 mkdir -p $O

@@ -1,5 +1,6 @@
 #!/bin/bash
 # on the GPU box: PMC counters of the split GEMM main kernels (MFMA busy cycles, active cycles)
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/pmc1

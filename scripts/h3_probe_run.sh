@@ -1,5 +1,6 @@
 #!/bin/bash
 # on the GPU box: kernel-trace each probe build on the big shapes, print gemm_h3_kernel durations
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in "" _NO_DMA _NO_MFMA $EXTRA_VARIANTS; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Dev tool: PMC counters of the LDS-staged SpMM (scripts/spmm_probe.py) -- run on the GPU box.
+: ${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_spmm
 mkdir -p $OUT
