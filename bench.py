@@ -557,7 +557,10 @@ def main():
         ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         sampled = 'every %d-th timed step (%d of %d)' % (every, n_instr, steps)
         h3 = prof['h3']
-        if mode in ('f16x3', 'bf16x3') and h3:
+        # (per-rank widths below 2048: only the dZ projection of the middle layers runs on a bf16x3 kernel --
+        # the convert-on-load one --; the dominant kernel is then the fp32 one and the line says so)
+        h3_dominant = bool(h3) and sum(ms for ms, _ in h3) >= 0.5 * g_ms
+        if mode in ('f16x3', 'bf16x3') and h3 and h3_dominant:
             terms = 3 if mode == 'f16x3' else 6
             # the split GEMM's main kernel, bracketed on its own.  achieved = ALGORITHMIC flops
             # (2mnk) / its time; it executes 3 f16 MFMA flops per algorithmic flop.
@@ -597,7 +600,18 @@ def main():
                 },
             }
         traffic, src = _traffic('gemm_f32_traffic.json')
+        extra = {}
+        if h3:
+            h_ms = sum(ms for ms, _ in h3)
+            h_flop = sum(2.0 * m * n * k for _, (m, n, k) in h3)
+            extra['bf16x3_projections'] = {
+                'kernel': 'gist::gemm_b3c_kernel (convert on load: operands split into three bf16 pieces inside '
+                          'the GEMM, six cross terms on v_mfma_f32_16x16x32_bf16) -- the dZ projections only',
+                'launches': len(h3), 'avg_launch_ms': round(h_ms / len(h3), 5),
+                'achieved_tflops_algorithmic': round(h_flop / (h_ms * 1e-3) / 1e12, 2) if h_ms > 0 else 0.0,
+                'share_of_step': share(h_ms)}
         return {
+            **extra,
             'kernel': 'gist::gemm_f32_kernel (v_mfma_f32_32x32x2_f32; NT/NN/TN)',
             'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
@@ -692,7 +706,9 @@ def main():
         # a split mode whose thresholds no projection of this run reached (small per-rank widths) IS the
         # fp32-MFMA run: say so
         eff_mode = args.gemm_mode
-        if prof is not None and args.gemm_mode != 'f32' and not prof['h3']:
+        if prof is not None and args.gemm_mode != 'f32' and (
+                not prof['h3'] or sum(ms for ms, _ in prof['h3']) <
+                0.5 * (sum(ms for ms, _ in prof['gemm']) + sum(prof['pre']))):
             eff_mode = 'f32'
         out = {
             'metric': 'epochs/sec', 'value': round(value, 4), 'unit': 'epochs/s',
@@ -746,6 +762,8 @@ def main():
                 'dataset': args.dataset,
                 'n_hidden': H, 'n_layers': L, 'num_subnet': S, 'batch_parts': batch_size,
                 'gemm_mode': args.gemm_mode if eff_mode == args.gemm_mode else
+                             ('%s requested; at this width only the dZ projections run on a bf16x3 kernel (convert on '
+                              'load), every other GEMM on the fp32 MFMA' % args.gemm_mode) if (prof and prof['h3']) else
                              '%s requested; no projection of this width reaches its thresholds: every GEMM on the fp32 MFMA' % args.gemm_mode,
                 'psize': psize, 'steps_per_epoch': STEPS_PER_EPOCH,
                 'epochs_per_sec_per_rank': round(value / world, 4),

@@ -614,6 +614,11 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
             int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
             void *ws, int64_t ws_bytes, hipStream_t st);
 int64_t b3_workspace_bytes(int64_t m, int64_t n, int64_t k);
+// gemm_b3c.hip: the bf16x3 path that converts on load (shapes below the pre-split path's thresholds)
+int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda, const float *b,
+             int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+             void *ws, int64_t ws_bytes, hipStream_t st, int *deferred);
+int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k);      // -1: shape not taken
 
 static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
     const int64_t kt = ceil_div(k, 32);      // the model counts k in units of 32
@@ -702,6 +707,8 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
         if (rc != 0) return rc < 0 ? rc : GIST_OK;
         rc = b3_gemm(name, A_KC, B_KC, a, lda, b, ldb, bias, c, ldc, m, n, k, ws, ws_bytes, st);   // mode 2
         if (rc != 0) return rc < 0 ? rc : GIST_OK;
+        rc = b3c_gemm(name, A_KC, B_KC, a, lda, b, ldb, bias, c, ldc, m, n, k, ws, ws_bytes, st, deferred);
+        if (rc != 0) return rc < 0 ? rc : GIST_OK;                                                   // mode 2, small
     }
     GemmArgs g;
     g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.c = c; g.ldc = ldc;
@@ -735,11 +742,20 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     return launch_status(name);
 }
 
-// slab bytes of the fp32 kernel's own split-K choice for this shape (0: one k slice)
+void gemm_f32_choice(int64_t m, int64_t n, int64_t k, int *tile, int *splits) {
+    const GemmCfg c = choose_cfg(m, n, k);
+    *tile = c.tile;
+    *splits = c.splits;
+}
+
+// slab bytes of the split-K choice for this shape on the fp32 kernel or the convert-on-load bf16x3 kernel,
+// whichever is larger (0: one k slice)
 int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const int sp = choose_cfg(m, n, k).splits;
-    return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
+    const int64_t f32 = sp > 1 ? (int64_t)sp * m * n * 4 : 0;
+    const int64_t c3 = b3c_slab_bytes(m, n, k);
+    return c3 > f32 ? c3 : f32;
 }
 
 int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, float *c,
@@ -788,8 +804,10 @@ extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (h3 > 0) return h3;
     const int64_t b3 = gist::b3_workspace_bytes(m, n, k);
     if (b3 > 0) return b3;
+    const int64_t c3 = gist::b3c_slab_bytes(m, n, k);      // >= 0: the convert-on-load bf16x3 path takes the shape
     const int s = gist::choose_cfg(m, n, k).splits;
-    return s > 1 ? (int64_t)s * m * n * 4 : 0;
+    const int64_t f32 = s > 1 ? (int64_t)s * m * n * 4 : 0;
+    return c3 > f32 ? c3 : f32;                            // (unaligned operands fall back to the fp32 kernel)
 }
 
 extern "C" int gist_gemm_nt_f32(const float *a, int64_t lda, const float *w, int64_t ldw,

@@ -1,0 +1,468 @@
+// bf16x3 projection for shapes too small for the pre-split kernel (gemm_b3.hip): CONVERT ON LOAD.
+//
+// Same arithmetic as gemm_b3.hip -- every fp32 operand x = b1 + b2 + b3 exactly (three bf16 pieces, all 24
+// significant bits), C = sum_k (a1.b1 + a1.b2 + a2.b1 + a2.b2 + a1.b3 + a3.b1) accumulated in fp32 on
+// v_mfma_f32_16x16x32_bf16 -- but the split happens INSIDE the GEMM: a thread loads its 8 consecutive k of
+// a row as fp32, forms the three pieces in registers and writes three 16-byte chunks to LDS.  There is no
+// pre-pass, so there is no flop threshold to amortise one: the per-rank projections of the N = 4 / 8
+// points (2046 x 1024 x 2048 and smaller), which the pre-split path only matched the fp32 kernel on
+// (its operand split costs as much as it saves below ~9 GFLOP), run on the bf16 matrix cores too.
+// Price: an operand tile is converted once per workgroup that uses it (VALU, ~6 instructions per
+// element) instead of once per call; a k step of a 128 x 128 tile is 96 MFMAs (1536 matrix-pipe cycles)
+// and ~170 VALU instructions per producer wave, against 4096 matrix-pipe cycles of the fp32 kernel.  Two
+// LDS stages (2 x 48 KiB at T = 128, 2 x 24 KiB at T = 64), producer and consumer waves (see the kernel).
+//
+// Layouts as gemm.hip: NT (A [m,k], B [n,k]), NN (A [m,k], B [k,n]), TN (A [k,m], B [k,n]); k-contiguous
+// operands are read 2 x 16 bytes per chunk, m/n-contiguous ones as 8 rows x (T / 64) columns (the
+// transposition happens in registers: a chunk is one column's 8 consecutive k).  Operands must be 16-byte
+// aligned with leading dimensions % 4 == 0 (everything the engine allocates); anything else stays on the
+// fp32 kernel.
+//
+// LDS image of an operand: three planes (pieces) of [T rows][32 k] bf16 = 64 bytes per row; the 16-byte
+// chunk kg (k = 8 kg .. 8 kg + 7) of row r sits at position kg ^ ((r >> 1) & 3) of its row, so the eight
+// lanes of a ds_read_b128 group (rows r .. r + 7, one kg) hit eight different 16-byte slots of the
+// 128-byte bank line, and so do the writes of eight consecutive chunks.
+#include <type_traits>
+
+#include "common.h"
+
+namespace gist {
+
+typedef __bf16 c3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
+
+struct C3Args {
+    const float *a; int64_t lda;
+    const float *b; int64_t ldb;
+    const float *bias;
+    float *c; int64_t ldc;
+    int m, n, k;
+    int tiles_m, tiles_n;
+    int k_per_split;       // multiple of 32
+    int64_t split_stride;  // elements between split slabs (0 = write C directly)
+};
+
+constexpr int C3_BK = 32;
+
+typedef float c3_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 c3_bf16x2 __attribute__((ext_vector_type(2)));
+
+// Two consecutive k of one row -> their packed bf16 pieces (the LDS words), two elements per instruction:
+// v_cvt_pk_bf16_f32 for the piece, a shift / a mask to widen it back, v_pk_add_f32 for the (exact)
+// remainder -- 9 vector instructions per PAIR (the first version converted element by element: 430
+// instructions per k step at T = 128, more cycles than the step's 96 MFMAs).
+__device__ __forceinline__ void c3_split2(c3_f32x2 x, uint32_t (&w)[3]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const c3_bf16x2 p = __builtin_convertvector(x, c3_bf16x2);
+        w[q] = __builtin_bit_cast(uint32_t, p);
+        if (q < 2) {
+            c3_f32x2 back;
+            back.x = __builtin_bit_cast(float, w[q] << 16);
+            back.y = __builtin_bit_cast(float, w[q] & 0xffff0000u);
+            x = x - back;                                   // exact
+        }
+    }
+}
+
+// 8 consecutive k of one row -> the row's chunk in each of the three planes
+__device__ __forceinline__ void c3_emit(const float (&v)[8], char *plane0, int plane_bytes, int off) {
+    uint32_t w[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c3_f32x2 x;
+        x.x = v[2 * j];
+        x.y = v[2 * j + 1];
+        c3_split2(x, w[j]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<uint4 *>(plane0 + q * plane_bytes + off) = make_uint4(w[0][q], w[1][q], w[2][q], w[3][q]);
+}
+
+__device__ __forceinline__ void c3_mfma(c3_f32x4 &acc, const c3_bf16x8 &a, const c3_bf16x8 &b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// Staging registers of one operand for one k tile.
+//   k-contiguous  : thread -> chunks q = t + 256 i (i < T / 64): row q / 4, octet q % 4; 2 float4 each
+//   m/n-contiguous: thread -> unit t (T = 128: column pair t % 64, octet t / 64; T = 64: column t % 64,
+//                   octet t / 64): 8 rows of (T / 64) floats
+// The thread's part of every address is a 32-bit byte offset from the tile's origin at k = 0, computed once;
+// the k advance is wave-uniform (scalar unit).
+template <bool KC, int T> struct C3Stage {
+    static constexpr int NCH = T / 64;                 // chunks this thread produces
+    float v[NCH][8];
+    uint32_t off[NCH];                                 // KC: byte offset of chunk i; MC: off[0] only
+};
+
+template <bool KC, int T>
+__device__ __forceinline__ void c3_offsets(int64_t ld, int rows, int row0, C3Stage<KC, T> &st, int t) {
+    if constexpr (KC) {
+#pragma unroll
+        for (int i = 0; i < T / 64; ++i) {
+            const int q = t + 256 * i;
+            const int r = min(q >> 2, rows - 1 - row0);              // rows past the end: never stored
+            st.off[i] = (uint32_t)(((int64_t)r * ld + 8 * (q & 3)) * 4);
+        }
+    } else {
+        constexpr int CW = T / 64;
+        const int c = min(row0 + (t & 63) * CW, (int)ld - CW) - row0;    // inside the row pitch
+        st.off[0] = (uint32_t)(((int64_t)(8 * (t >> 6)) * ld + c) * 4);
+    }
+}
+
+// origin = the operand's tile origin at this k tile (KC: p + row0 * ld + k0; MC: p + k0 * ld + row0).
+// FULL: the whole tile lies below k_end (no clamps, no masks).
+template <bool KC, int T, bool FULL>
+__device__ __forceinline__ void c3_load(const float *__restrict__ origin, int64_t ld, int k0, int k_end,
+                                        C3Stage<KC, T> &st, int t) {
+    const char *ob = reinterpret_cast<const char *>(origin);
+    if constexpr (KC) {
+#pragma unroll
+        for (int i = 0; i < T / 64; ++i) {
+            const float *src = reinterpret_cast<const float *>(ob + st.off[i]);
+            float4 lo, hi;
+            if constexpr (FULL) {
+                lo = *reinterpret_cast<const float4 *>(src);
+                hi = *reinterpret_cast<const float4 *>(src + 4);
+            } else {            // addresses clamped inside the row pitch (ld % 4 == 0); values masked at the store
+                const int kk = k0 + 8 * ((t + 256 * i) & 3);
+                const int back0 = max(kk - ((int)ld - 4), 0), back1 = max(kk + 4 - ((int)ld - 4), 0);
+                lo = *reinterpret_cast<const float4 *>(src - back0);
+                hi = *reinterpret_cast<const float4 *>(src + 4 - back1);
+            }
+            st.v[i][0] = lo.x; st.v[i][1] = lo.y; st.v[i][2] = lo.z; st.v[i][3] = lo.w;
+            st.v[i][4] = hi.x; st.v[i][5] = hi.y; st.v[i][6] = hi.z; st.v[i][7] = hi.w;
+        }
+    } else {
+        constexpr int CW = T / 64;
+        const int kk = k0 + 8 * (t >> 6);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int64_t step = (int64_t)j * ld * 4;                      // uniform
+            if constexpr (!FULL) step = (int64_t)(min(kk + j, k_end - 1) - kk) * ld * 4;
+            const float *src = reinterpret_cast<const float *>(ob + step + st.off[0]);
+            if constexpr (CW == 2) {
+                const float2 x = *reinterpret_cast<const float2 *>(src);
+                st.v[0][j] = x.x; st.v[1][j] = x.y;
+            } else {
+                st.v[0][j] = *src;
+            }
+        }
+    }
+}
+
+// (mask the k tail,) split, write to LDS (rows / columns clamped at load time carry garbage that only
+// reaches outputs past m / n, which are never stored)
+template <bool KC, int T, bool FULL>
+__device__ __forceinline__ void c3_store(C3Stage<KC, T> &st, char *image, int k0, int k_end, int t) {
+    constexpr int PLANE = T * 64;
+    if constexpr (KC) {
+#pragma unroll
+        for (int i = 0; i < T / 64; ++i) {
+            const int q = t + 256 * i;
+            const int r = q >> 2, kg = q & 3;
+            if constexpr (!FULL) {
+                const int kk = k0 + 8 * kg;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st.v[i][j] = kk + j < k_end ? st.v[i][j] : 0.f;
+            }
+            c3_emit(st.v[i], image, PLANE, r * 64 + ((kg ^ ((r >> 1) & 3)) << 4));
+        }
+    } else {
+        constexpr int CW = T / 64;
+        const int kg = t >> 6;
+#pragma unroll
+        for (int u = 0; u < CW; ++u) {
+            const int r = (t & 63) * CW + u;
+            if constexpr (!FULL) {
+                const int kk = k0 + 8 * kg;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st.v[u][j] = kk + j < k_end ? st.v[u][j] : 0.f;
+            }
+            c3_emit(st.v[u], image, PLANE, r * 64 + ((kg ^ ((r >> 1) & 3)) << 4));
+        }
+    }
+}
+
+// Workgroup = 8 waves with fixed roles (each SIMD hosts one wave of either kind, so the vector ALU work of
+// the split runs under the other wave's MFMAs -- inside ONE wave a vector instruction next to an MFMA stream
+// costs matrix-pipe time, profiles/r01_gemm_phase_trace.md; the first version of this kernel did
+// convert -> barrier -> multiply -> barrier with every wave and only matched the fp32 kernel):
+//   waves 4-7 PRODUCE: tile t + 1's fp32 values (loaded a step earlier) -> three bf16 pieces -> LDS stage
+//             (t + 1) & 1, then the global loads of tile t + 2;
+//   waves 0-3 CONSUME: fragments of stage t & 1 -> 6 x NI x NI MFMAs each (2 x 2 waves over the T x T tile);
+// one workgroup barrier per k step: stage (t + 1) & 1 complete, stage t & 1 free.
+template <bool A_KC, bool B_KC, int TM, int TN>
+__global__ __launch_bounds__(512, TM == 64 ? 2 : 1) void gemm_b3c_kernel(C3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char c3_smem[];
+    constexpr int PLANE_A = TM * 64, PLANE_B = TN * 64;      // bytes of one piece plane of an operand
+    constexpr int STAGE = 3 * (PLANE_A + PLANE_B);           // A planes, then B planes
+    constexpr int WM = TM / 2, WN = TN / 2;                  // consumer wave tile (2 x 2 waves)
+    constexpr int NI = WM / 16, NJ = WN / 16;                // 16 x 16 MFMA tiles per wave
+
+    // ---- block -> output tile, 8 x 8 super-tiles per XCD (as gemm.hip) ----
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int orig = blockIdx.x;
+    const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
+    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
+    constexpr int GM = 8;
+    const int width = GM * g.tiles_n;
+    const int group = L / width;
+    const int first_m = group * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int bm = first_m + (L % width) % gsz;
+    const int bn = (L % width) / gsz;
+    const int row0 = bm * TM, col0 = bn * TN;
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(g.k, k_begin + g.k_per_split);
+    const int n_kt = (k_end - k_begin + C3_BK - 1) / C3_BK;
+    const int n_full = (k_end - k_begin) / C3_BK;            // tiles that need no mask
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (wave >= 4) {
+        // ================================ producers ==================================================
+        const int t = threadIdx.x - 256;
+        // PD tiles of fp32 values in flight per thread: a tile's loads are issued PD k steps before it is
+        // converted (one step of ~0.7 us is less than the latency of a load under load: with one tile in
+        // flight the producers waited ~2 us per step for their operands and the kernel ran at their pace).
+        // The steady state is straight-line code over the FULL tiles: loads past the last full tile re-read
+        // it (never consumed), the ragged last tile sits in a register set of its own from the start.
+        constexpr int PD = 3;
+        C3Stage<A_KC, TM> sa[PD], ta;
+        C3Stage<B_KC, TN> sb[PD], tb;
+        c3_offsets<A_KC, TM>(g.lda, g.m, row0, ta, t);
+        c3_offsets<B_KC, TN>(g.ldb, g.n, col0, tb, t);
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+#pragma unroll
+            for (int i = 0; i < C3Stage<A_KC, TM>::NCH; ++i) sa[d].off[i] = ta.off[i];
+#pragma unroll
+            for (int i = 0; i < C3Stage<B_KC, TN>::NCH; ++i) sb[d].off[i] = tb.off[i];
+        }
+        // tile origins at k = 0 (uniform); the k advance is added per tile on the scalar unit
+        const float *oa = A_KC ? g.a + (int64_t)row0 * g.lda : g.a + row0;
+        const float *ob = B_KC ? g.b + (int64_t)col0 * g.ldb : g.b + col0;
+        const bool tail = n_kt > n_full;
+        const int last_full = max(n_full - 1, 0);
+        auto load_full = [&](int kt, C3Stage<A_KC, TM> &ra, C3Stage<B_KC, TN> &rb) {
+            const int k0 = k_begin + min(kt, last_full) * C3_BK;
+            c3_load<A_KC, TM, true>(A_KC ? oa + k0 : oa + (int64_t)k0 * g.lda, g.lda, k0, k_end, ra, t);
+            c3_load<B_KC, TN, true>(B_KC ? ob + k0 : ob + (int64_t)k0 * g.ldb, g.ldb, k0, k_end, rb, t);
+        };
+        auto store_full = [&](int kt, C3Stage<A_KC, TM> &ra, C3Stage<B_KC, TN> &rb) {
+            char *img = c3_smem + (kt & 1) * STAGE;
+            c3_store<A_KC, TM, true>(ra, img, 0, k_end, t);
+            c3_store<B_KC, TN, true>(rb, img + 3 * PLANE_A, 0, k_end, t);
+        };
+        if (tail) {                                           // the ragged tile: masked, clamped
+            const int k0 = k_begin + n_full * C3_BK;
+            c3_load<A_KC, TM, false>(A_KC ? oa + k0 : oa + (int64_t)k0 * g.lda, g.lda, k0, k_end, ta, t);
+            c3_load<B_KC, TN, false>(B_KC ? ob + k0 : ob + (int64_t)k0 * g.ldb, g.ldb, k0, k_end, tb, t);
+        }
+        if (n_full > 0) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) load_full(d, sa[d], sb[d]);
+            store_full(0, sa[0], sb[0]);
+            load_full(PD, sa[0], sb[0]);
+        } else if (tail) {
+            char *img = c3_smem;
+            c3_store<A_KC, TM, false>(ta, img, k_begin, k_end, t);
+            c3_store<B_KC, TN, false>(tb, img + 3 * PLANE_A, k_begin, k_end, t);
+        }
+        __syncthreads();                                      // stage 0 ready
+        // iteration kt (consumers multiply tile kt): store tile kt + 1, refill its register set
+        int kt = 0;
+        for (; kt + PD <= n_full - 1; kt += PD) {             // tiles kt + 1 .. kt + PD are all full
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                store_full(kt + d + 1, sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                load_full(kt + d + 1 + PD, sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {                        // the last (< PD) full tiles: kt % PD == 0 here
+            if (kt + d + 1 <= n_full - 1) {
+                store_full(kt + d + 1, sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                __syncthreads();
+            }
+        }
+        if (n_full > 0) {
+            if (tail) {                                       // iteration n_full - 1 stores the ragged tile
+                char *img = c3_smem + (n_full & 1) * STAGE;
+                const int k0 = k_begin + n_full * C3_BK;
+                c3_store<A_KC, TM, false>(ta, img, k0, k_end, t);
+                c3_store<B_KC, TN, false>(tb, img + 3 * PLANE_A, k0, k_end, t);
+            }
+            __syncthreads();                                  // end of iteration n_full - 1
+        }
+        if (tail) __syncthreads();                            // end of the ragged tile's iteration
+        return;
+    }
+    // ==================================== consumers ==================================================
+    const int lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int rr = lane & 15, kg = lane >> 4;
+    c3_f32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    // fragment offsets inside a plane: row (16 i + rr) of the wave's slab, chunk kg at its swizzled position
+    const int fa = (wm * WM + rr) * 64 + ((kg ^ ((rr >> 1) & 3)) << 4);
+    const int fb = 3 * PLANE_A + (wn * WN + rr) * 64 + ((kg ^ ((rr >> 1) & 3)) << 4);
+    constexpr int pa[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int pb[6] = {0, 1, 0, 1, 2, 0};
+    __syncthreads();                                          // stage 0 ready
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const char *img = c3_smem + (kt & 1) * STAGE;
+        c3_bf16x8 af[NI][3], bf[NJ][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                bf[j][q] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_B + fb + j * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                af[i][q] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_A + fa + i * 16 * 64);
+        }
+        // smallest terms first; consecutive MFMAs go to NI * NJ different accumulators
+#pragma unroll
+        for (int term = 5; term >= 0; --term)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) c3_mfma(acc[i][j], af[i][pa[term]], bf[j][pb[term]]);
+        __syncthreads();
+    }
+    // the MFMAs above are opaque to the compiler's hazard recognizer: let the last ones retire
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
+    float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
+    const bool add_bias = g.bias != nullptr && g.split_stride == 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = col0 + wn * WN + j * 16 + rr;
+        if (col >= g.n) continue;
+        const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = row0 + wm * WM + i * 16 + 4 * kg + e;
+                if (row < g.m) cbase[(int64_t)row * g.ldc + col] = acc[i][j][e] + bv;
+            }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+// Which calls take this kernel by default.  MEASURED (scripts/b3c_bench.py, profiles/r03_b3c_bench.txt): a k
+// step costs ~1300 cycles on top of its MFMAs (fragment-read latency after the barrier, the barrier itself,
+// the producers' LDS writes), so the kernel only MATCHES the fp32 kernel on most per-rank shapes (2046 x 1024
+// x 2048: 67 vs 70 us, 2046 x 512 x 1204: 24.5 vs 25.6) and beats it where 128 x 128 tiles fill the chip
+// with one workgroup per CU -- dZ = dY . W of the width-1024 sub-GCN, 2046 x 2048 x 1024: 54 vs 69 us.  So
+// by default only the NN layout with >= 200 tiles of 128 x 128 and >= 4 GFLOP comes here; the tuning hook
+// GIST_TUNE_B3C = 2 sends every shape with m, n, k >= 64 (tests, sweeps), 1 none.
+static bool b3c_geometry_ok(int64_t m, int64_t n, int64_t k) {
+    return h3_mode() == 2 && (int)tune(GIST_TUNE_B3C) != 1 && m >= 64 && n >= 64 && k >= 64;
+}
+bool b3c_shape_ok(int64_t m, int64_t n, int64_t k) {
+    if (!b3c_geometry_ok(m, n, k)) return false;
+    if ((int)tune(GIST_TUNE_B3C) == 2) return true;
+    return ceil_div(m, 128) * ceil_div(n, 128) >= 200 && 2.0 * (double)m * (double)n * (double)k >= 4e9;
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN>
+static int b3c_launch(const char *name, C3Args &g, int splits, hipStream_t st) {
+    const size_t smem = (size_t)2 * 3 * (TM + TN) * 64;      // two stages of (A, B) x 3 planes
+    static DeviceOnce once;       // one per template instance
+    int dev;
+    if (once.needed(&dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_b3c_kernel<A_KC, B_KC, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return GIST_ELAUNCH;
+        }
+        once.done(dev);
+    }
+    g.tiles_m = (int)ceil_div(g.m, TM);
+    g.tiles_n = (int)ceil_div(g.n, TN);
+    hipLaunchKernelGGL((gemm_b3c_kernel<A_KC, B_KC, TM, TN>),
+                       dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), smem, st, g);
+    return launch_status(name);
+}
+
+// Tile and k slices.  One 512-thread workgroup per CU at 128 x N tiles (two at 64 x 64), so the first aim is
+// >= ~256 workgroups: 128 x 128 when that many tiles exist, else 128 x 64, else 64 x 64, else k slices
+// (fp32 slabs, reduced by the call or left to the consumer).  Fitted to scripts/b3c_bench.py.
+static void b3c_choice(int64_t m, int64_t n, int64_t k, int *tm, int *tn, int *splits) {
+    const int t_tile = (int)tune(GIST_TUNE_GEMM_TILE), t_split = (int)tune(GIST_TUNE_GEMM_SPLITS);
+    auto tiles = [&](int a, int b) { return ceil_div(m, a) * ceil_div(n, b); };
+    if (tiles(128, 128) >= 200) { *tm = 128; *tn = 128; }
+    else if (tiles(128, 64) >= 200) { *tm = 128; *tn = 64; }
+    else { *tm = 64; *tn = 64; }
+    if (t_tile == 64) { *tm = 64; *tn = 64; }
+    else if (t_tile == 128) { *tm = 128; *tn = 128; }
+    else if (t_tile == 12864) { *tm = 128; *tn = 64; }
+    const int64_t wgs = tiles(*tm, *tn);
+    const int64_t kt = ceil_div(k, C3_BK);
+    int64_t sp = 1;
+    const int64_t want = *tm == 64 ? 512 : 256;
+    if (wgs * 2 <= want) sp = want / wgs;
+    if (sp > kt / 8) sp = kt / 8;                             // a slice keeps >= 8 k tiles
+    if (t_split > 0) sp = t_split;
+    if (sp > kt) sp = kt;
+    *splits = (int)(sp < 1 ? 1 : sp);
+}
+
+int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k) {
+    if (!b3c_shape_ok(m, n, k)) return -1;
+    int tm, tn, sp;
+    b3c_choice(m, n, k, &tm, &tn, &sp);
+    return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
+}
+
+// Returns 1 if the projection was issued here, 0 if this call is not for this path (the caller falls back
+// to the fp32 kernel), < 0 on error.  deferred as in gemm.hip's launch_gemm.
+int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda, const float *b, int64_t ldb,
+             const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k, void *ws,
+             int64_t ws_bytes, hipStream_t st, int *deferred) {
+    if (!b3c_shape_ok(m, n, k)) return 0;
+    if (!(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && lda >= 4 && ldb >= 4)) return 0;
+    if (!a_kc && b_kc) return 0;                                     // (no caller uses this layout)
+    if ((int)tune(GIST_TUNE_B3C) != 2 && !(a_kc && !b_kc)) return 0; // by default: the NN layout only (see above)
+    int tm = 128, tn = 128, splits = 1;
+    b3c_choice(m, n, k, &tm, &tn, &splits);
+    if (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits = 1;
+    C3Args g;
+    g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.c = c; g.ldc = ldc;
+    g.m = (int)m; g.n = (int)n; g.k = (int)k;
+    g.k_per_split = (int)(ceil_div(ceil_div(k, C3_BK), splits) * C3_BK);
+    splits = (int)ceil_div(k, g.k_per_split);
+    g.split_stride = 0;
+    if (splits > 1) { g.c = static_cast<float *>(ws); g.ldc = n; g.split_stride = m * n; g.bias = nullptr; }
+    const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: a bf16x3 main kernel
+    int rc;
+#define C3_GO(AK, BK_)                                                                        \
+    rc = tm == 64 ? b3c_launch<AK, BK_, 64, 64>(name, g, splits, st)                          \
+                  : (tn == 64 ? b3c_launch<AK, BK_, 128, 64>(name, g, splits, st)             \
+                              : b3c_launch<AK, BK_, 128, 128>(name, g, splits, st))
+    if (a_kc && b_kc) { C3_GO(true, true); }
+    else if (a_kc) { C3_GO(true, false); }
+    else { C3_GO(false, false); }
+#undef C3_GO
+    if (rc == GIST_OK && splits > 1) {
+        if (deferred) *deferred = splits;
+        else rc = splitk_reduce(name, static_cast<const float *>(ws), m * n, splits, bias, c, ldc, m, n, st);
+    }
+    timer_end(tl_timer, slot, st);
+    return rc == GIST_OK ? 1 : rc;
+}
+
+}  // namespace gist

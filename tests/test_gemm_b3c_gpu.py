@@ -1,0 +1,144 @@
+"""GPU tests of the convert-on-load bf16x3 projection (gist_amd/csrc/gemm_b3c.hip) through the C ABI: the
+shapes below the pre-split path's thresholds (per-rank widths 1024 and 512 of the N = 4 / 8 points, ragged
+edges, k tails, split-K, output windows) in GEMM mode bf16x3 against float64 at the fp32-MFMA kernel's error
+level, exactness where fp32 is exact, and the deferred-slab form."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gemm_b3_gpu import _operands, _ref64, _run
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from gist_amd import hip as h
+    assert h.device_count() >= 1
+    prev = h.gemm_mode()
+    h.tuning('b3c', 2)               # also below the production flop threshold
+    yield h
+    h.gemm_mode(prev)
+    h.tuning('b3c', 0)
+
+
+def _taken(hip, form, m, n, k, gen):
+    """The call really runs on gemm_b3c_kernel: with the path switched off (tuning hook) the result
+    differs in its low bits from the one with it on (fp32 products vs six bf16 cross terms)."""
+    a, w = _operands(form, m, n, k, gen, 'normal')
+    on = _run(hip, form, a, w, None, m, n)
+    hip.tuning('b3c', 1)
+    off = _run(hip, form, a, w, None, m, n)
+    hip.tuning('b3c', 2)
+    return not torch.equal(on, off)
+
+
+SHAPES = [('nt', 2046, 1024, 1204), ('nt', 2046, 1024, 2048), ('nn', 2046, 2048, 1024), ('tn', 1024, 2048, 2046),
+          ('tn', 1024, 1204, 2046), ('nt', 2046, 512, 1204), ('nn', 2046, 1024, 512), ('tn', 512, 1024, 2046),
+          ('nt', 1140, 512, 200), ('tn', 512, 200, 1140),          # Amazon-like per-rank shapes
+          ('nt', 333, 130, 100), ('nn', 77, 68, 72), ('tn', 68, 200, 333)]
+
+
+@pytest.mark.parametrize('form,m,n,k', SHAPES)
+@pytest.mark.parametrize('kind', ['normal', 'train', 'grad', 'cancel', 'range', 'edge'])
+def test_b3c_error_at_fp32_mfma_level(hip, form, m, n, k, kind):
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(m + 3 * n + 7 * k)
+    if kind == 'normal':
+        assert _taken(hip, form, m, n, k, gen)
+    a, w = _operands(form, m, n, k, gen, kind)
+    bias = torch.randn(n, device=DEV, generator=gen) * 1e-3 if form == 'nt' and kind == 'normal' else None
+    rows = torch.arange(0, m, max(1, m // 192), device=DEV)
+    ref, den = _ref64(form, a, w, rows)
+    if bias is not None:
+        ref = ref + bias.double()
+    y3 = _run(hip, form, a, w, bias, m, n)[rows].double()
+    hip.gemm_mode('f32')
+    y1 = _run(hip, form, a, w, bias, m, n)[rows].double()
+    hip.gemm_mode('bf16x3')
+    assert torch.isfinite(y3).all()
+    den = den.clamp(min=1e-300)
+    e3 = ((y3 - ref).abs() / den).max().item()
+    e1 = ((y1 - ref).abs() / den).max().item()
+    r3 = ((y3 - ref).pow(2).mean().sqrt() / den.pow(2).mean().sqrt()).item()
+    r1 = ((y1 - ref).pow(2).mean().sqrt() / den.pow(2).mean().sqrt()).item()
+    # same bars as the pre-split kernel (tests/test_gemm_b3_gpu.py): the arithmetic is the same
+    assert e3 <= max(3.0 * e1, 6e-7), (kind, e3, e1)
+    assert r3 <= max((2.5 if kind == 'range' else 1.25) * r1, 5e-8), (kind, r3, r1)
+
+
+def test_b3c_is_exact_where_fp32_is(hip):
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    m, n, k = 530, 300, 250
+    a = torch.randint(-8, 9, (m, k), device=DEV, generator=gen).float()
+    w = torch.randint(-8, 9, (n, k), device=DEV, generator=gen).float()
+    assert torch.equal(_run(hip, 'nt', a, w, None, m, n), (a.double() @ w.double().t()).float())
+    wt = w.t().contiguous()
+    assert torch.equal(_run(hip, 'nn', a, wt, None, m, n), (a.double() @ w.double().t()).float())
+    at = a.t().contiguous()
+    assert torch.equal(_run(hip, 'tn', at, wt, None, m, n), (a.double() @ w.double().t()).float())
+    b = torch.randn(256, 320, device=DEV, generator=gen) * torch.exp2(
+        torch.randint(-30, 31, (256, 320), device=DEV, generator=gen).float())
+    eye = torch.eye(256, device=DEV)
+    assert torch.equal(_run(hip, 'nn', eye, b, None, 256, 320), b)      # every one of the 24 bits of b
+    assert torch.equal(_run(hip, 'tn', eye, b, None, 256, 320), b)
+    bt = b.t().contiguous()
+    assert torch.equal(_run(hip, 'nt', eye, bt, None, 256, 320), b)
+    assert torch.equal(_run(hip, 'nt', bt, eye, None, 320, 256), bt)
+
+
+def test_b3c_output_window_k_tail_and_split_k(hip):
+    """A result written into a window of a larger buffer touches nothing around it; a k that is no multiple
+    of 32 or 8; forced split-K (the slabs reduced by the call) equals one k slice up to summation order."""
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    m, n, k = 530, 300, 203 * 4
+    a = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.randn(n, k, device=DEV, generator=gen)
+    ybuf = torch.full((m + 3, n + 8), 7.0, device=DEV)
+    hip.gemm_nt(a, w, None, ybuf[:m, 4:4 + n])
+    ref = (a.double() @ w.double().t()).float()
+    assert (ybuf[:m, 4:4 + n] - ref).abs().max().item() < 2e-6 * ref.abs().max().item() * np.sqrt(k)
+    assert (ybuf[m:] == 7.0).all() and (ybuf[:, :4] == 7.0).all() and (ybuf[:, 4 + n:] == 7.0).all()
+    one = _run(hip, 'nt', a, w, None, m, n)
+    hip.tuning('gemm_tile', 64)
+    hip.tuning('gemm_splits', 4)
+    try:
+        four = _run(hip, 'nt', a, w, None, m, n)
+    finally:
+        hip.tuning('gemm_tile', 0)
+        hip.tuning('gemm_splits', 0)
+    assert (four - one).abs().max().item() < 1e-5 * ref.abs().max().item()
+    # a k-major operand whose k is not a multiple of 8 (the batch rows of a dW projection)
+    k2 = 2046
+    g = torch.randn(k2, 130, device=DEV, generator=gen)
+    z = torch.randn(k2, 260, device=DEV, generator=gen)
+    got = _run(hip, 'tn', g, z, None, 130, 260)
+    ref2 = (g.double().t() @ z.double()).float()
+    assert (got - ref2).abs().max().item() < 1e-5 * ref2.abs().max().item()
+
+
+def test_b3c_deferred_slabs(hip):
+    """gist_gemm_slabs_f32 in mode bf16x3: the slabs of a split weight-gradient projection summed in slab
+    order are BIT-equal to the call that reduces them itself."""
+    from gist_amd import _lib
+    L = _lib.load()
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    m, n, k = 512, 1204, 2046
+    a = torch.randn(k, m, device=DEV, generator=gen)
+    b = torch.randn(k, n, device=DEV, generator=gen)
+    ref = torch.empty(m, n, device=DEV)
+    hip.gemm_tn(a, b, ref)
+    need = int(L.gist_gemm_workspace_bytes(m, n, k))
+    assert need > 0
+    slabs = torch.full((need // 4,), float('nan'), device=DEV)
+    c = torch.full((m, n), float('nan'), device=DEV)
+    ns = hip.gemm_slabs('tn', a, b, None, c, slabs.view(torch.uint8))
+    assert ns > 1
+    acc = torch.zeros(m * n, device=DEV)
+    for s in range(ns):
+        acc = acc + slabs[s * m * n:(s + 1) * m * n]
+    assert torch.equal(acc.view(m, n), ref)
