@@ -34,10 +34,19 @@ class FullGraphEvaluator(object):
     evaluated block of rows by block of rows (aggregate the block's rows over the full graph,
     project, normalise), never materialising [N, 2*in].  The narrowing class layer aggregates
     its C-wide projection instead of the H-wide activations ([h | A^h] W^T = h W1^T + A^(h W2^T)).
-    Reddit at H = 32768: 2 x 30.5 GB + 4 GB instead of ~250 GB."""
+    Reddit at H = 32768: 2 x 30.5 GB + 4 GB instead of ~250 GB.
+
+    node_blocks (int boundaries [0, b1, ..., N], blocks of at most 128 consecutive node ids -- the parts of a
+    partition the graph's ids are ordered by): the aggregation is split once into A = A_diag + A_rest.
+    A_diag, the edges inside a block, is a block-diagonal matrix whose blocks are DENSE on a clustered
+    graph (Reddit-like: 246 of a row's 450 neighbours among its block's 102 rows), so its product runs as
+    counts x features on the matrix cores (gist_spmm_csr_prepared_f32, exact fp32 as in training) instead of
+    246 gathered rows per node; A_rest is gathered by the row kernel with accumulate, column tile by column
+    tile so that the gathered slab of X stays in the Infinity Cache.  Row blocks are then cut at block
+    boundaries.  None = one gather pass over A (any graph)."""
 
     def __init__(self, g, dims, use_layernorm, arena, device, row_block=None,
-                 block_bytes=4 << 30):
+                 block_bytes=4 << 30, node_blocks=None):
         self.g = g if g.device == device else g.to(device)
         self.dims = [(int(i), int(o)) for i, o in dims]
         self.use_layernorm = bool(use_layernorm)
@@ -60,10 +69,15 @@ class FullGraphEvaluator(object):
         if row_block is None:
             row_block = max(4096, int(block_bytes // (8 * max_in)))
         self.row_block = int(min(max(row_block, 1), n))
+        self.split = None
+        self.rest_tile = 512        # floats per column tile of the remainder's gather passes
+        self.row_cuts = list(range(0, n, self.row_block)) + [n]
         hidden = max([o for (i, o) in self.dims[:-1]] + [1])
         self.h = [torch.empty(n, hidden, **f32) for _ in range(2 if L1 > 2 else 1)] if L1 > 1 else []
         self.zb = torch.empty(self.row_block, 2 * max_in, **f32) if blocked else None
         self.yb = torch.empty(self.row_block, max_out, **f32) if blocked else None
+        if node_blocks is not None and blocked:
+            self._split_graph(np.asarray(node_blocks, np.int64))
         self.logits = torch.empty(n, self.ldc, **f32)
         self.pbuf = torch.empty(n, self.ldc, **f32) if self.project_first else None
         self.correct = torch.zeros(1, dtype=torch.int32, device=device)
@@ -91,11 +105,24 @@ class FullGraphEvaluator(object):
                 hip.spmm(g.rowptr, g.col, p, out, out_scale=self.norm, accumulate=True)
                 break
             dst = self.logits if last else self.h[k % len(self.h)]
-            for r0 in range(0, n, self.row_block):
-                r1 = min(r0 + self.row_block, n)
+            for bi, (r0, r1) in enumerate(zip(self.row_cuts[:-1], self.row_cuts[1:])):
                 z = self.zb[:r1 - r0, :2 * i]
                 hip.block_gather(cur[r0:r1, :i], None, None, z[:, :i])
-                hip.spmm(g.rowptr[r0:r1 + 1], g.col, cur[:, :i], z[:, i:], out_scale=self.norm[r0:r1])
+                if self.split is not None and self._dense_ok(cur[r0:r1, :i], z[:, i:]):
+                    sp = self.split
+                    # inside the blocks: counts x features on the matrix cores (sources = this row block)
+                    hip.spmm(sp['rowptr_d'][r0:r1 + 1], sp['col_d'], cur[r0:r1, :i], z[:, i:],
+                             out_scale=self.norm[r0:r1], row_blocks=sp['blocks'][bi], prepared=sp['prepared'][bi])
+                    # everything else: gathered, accumulated -- one column tile at a time, so that the slab of
+                    # X a pass gathers from (N x rest_tile floats: 238 MB at Reddit's size) stays in the
+                    # Infinity Cache instead of every gather going to HBM
+                    ct = self.rest_tile
+                    for c0 in range(0, i, ct):
+                        c1 = min(c0 + ct, i)
+                        hip.spmm(sp['rowptr_r'][r0:r1 + 1], sp['col_r'], cur[:, c0:c1], z[:, i + c0:i + c1],
+                                 out_scale=self.norm[r0:r1], accumulate=True)
+                else:
+                    hip.spmm(g.rowptr[r0:r1 + 1], g.col, cur[:, :i], z[:, i:], out_scale=self.norm[r0:r1])
                 if last:
                     hip.gemm_nt(z, W, b, dst[r0:r1, :o])
                 else:
@@ -104,6 +131,68 @@ class FullGraphEvaluator(object):
                     hip.ln_relu_fwd(y, dst[r0:r1, :o], None, self.use_layernorm, True)
             cur = dst
         return self.logits[:, :self.n_classes]
+
+    @staticmethod
+    def _dense_ok(x, y):
+        """The block-dense product takes 16-byte rows of a multiple of 4 floats, at least 128 wide."""
+        d = x.shape[1]
+        return (d >= 128 and d % 4 == 0 and x.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and
+                x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0)
+
+    def _split_graph(self, bounds):
+        """A = A_diag + A_rest for the node blocks `bounds`, once, on the device; row blocks cut at block
+        boundaries; the block structure of every row block prepared for the matrix-core kernel."""
+        g, n, dev = self.g, self.n, self.device
+        if bounds[0] != 0 or bounds[-1] != n or (np.diff(bounds) <= 0).any() or (np.diff(bounds) > 128).any():
+            raise ValueError('gist_amd: node_blocks must be increasing boundaries 0..N of blocks of 1..128 nodes')
+        # row blocks: the last block boundary at or below r0 + row_block
+        cuts = [0]
+        while cuts[-1] < n:
+            j = int(np.searchsorted(bounds, cuts[-1] + self.row_block, side='right')) - 1
+            nxt = int(bounds[j])
+            if nxt <= cuts[-1]:
+                nxt = int(bounds[int(np.searchsorted(bounds, cuts[-1], side='right'))])
+            cuts.append(nxt)
+        self.row_cuts = cuts
+        longest = max(b - a for a, b in zip(cuts[:-1], cuts[1:]))
+        if longest > self.zb.shape[0]:
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.zb = torch.empty(longest, self.zb.shape[1], **f32)
+            self.yb = torch.empty(longest, self.yb.shape[1], **f32)
+        bd = torch.from_numpy(bounds).to(dev)
+        rowptr = g.rowptr.to(torch.int64)
+        deg = rowptr[1:] - rowptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+        col = g.col.to(torch.int64)
+        blk_of = torch.bucketize(torch.arange(n, device=dev), bd, right=True) - 1
+        inside = blk_of[rows] == blk_of[col]
+        del blk_of
+        cut_t = torch.tensor(cuts, dtype=torch.int64, device=dev)
+        rb_of_row = torch.bucketize(torch.arange(n, device=dev), cut_t, right=True) - 1
+
+        def csr(mask, local):
+            r = rows[mask]
+            c = col[mask]
+            if local:                                   # sources relative to the row block's first row
+                c = c - cut_t[rb_of_row[r]]
+            cnt = torch.bincount(r, minlength=n)
+            rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(cnt, 0, out=rp[1:])
+            return rp.to(torch.int32), c.to(torch.int32).contiguous()
+
+        rp_d, col_d = csr(inside, True)
+        rp_r, col_r = csr(~inside, False)
+        del rows, col, inside
+        blocks, prepared = [], []
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            lo = int(np.searchsorted(bounds, r0))
+            hi = int(np.searchsorted(bounds, r1))
+            rb = torch.from_numpy((bounds[lo:hi + 1] - r0).astype(np.int32)).to(dev)
+            blocks.append(rb)
+            # (row pointers of a row block are absolute offsets into col_d: prepare on the slice)
+            prepared.append(hip.spmm_prepare(rp_d[r0:r1 + 1], col_d, rb))
+        self.split = dict(rowptr_d=rp_d, col_d=col_d, rowptr_r=rp_r, col_r=col_r, blocks=blocks,
+                          prepared=prepared, diag_edges=int(col_d.numel()), rest_edges=int(col_r.numel()))
 
     def accuracy(self, mask_name):
         if mask_name not in self.masks:

@@ -46,11 +46,15 @@ for form, m, n, k in SH:
     hip.gemm_mode('bf16x3')
     out = []
     for tile, sp in cfgs:
+        # tile/splits given: every shape forced onto gemm_b3c_kernel with them (tuning hook b3c = 2);
+        # 0 0 = the library's default dispatch (most layouts stay on the fp32 kernel)
+        hip.tuning('b3c', 2 if (tile or sp) else 0)
         hip.tuning('gemm_tile', tile)
         hip.tuning('gemm_splits', sp)
-        out.append('%s/%s: %6.1f' % (tile or 'auto', sp or 'auto', t(form, a, b, c)))
+        out.append('%s/%s: %6.1f' % (tile or 'default', sp or 'default', t(form, a, b, c)))
     hip.tuning('gemm_tile', 0)
     hip.tuning('gemm_splits', 0)
+    hip.tuning('b3c', 0)
     gf = 2.0 * m * n * k / 1e9
     print('%s %5d %5d %5d  %5.2f GF  f32 %6.1f us (%5.1f TF) | b3c %s' % (form, m, n, k, gf, f32, gf / f32 * 1e3,
                                                                      '  '.join(out)), flush=True)

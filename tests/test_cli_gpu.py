@@ -181,3 +181,39 @@ def test_evaluator_row_blocks_agree():
         assert ev.row_block == rb
         assert (ev.forward() - ref).abs().max().item() < 1e-5
         assert abs(ev.accuracy('val_mask') - whole.accuracy('val_mask')) < 1e-9
+
+
+@pytest.mark.parametrize('hidden', [256, 2048])
+def test_evaluator_block_diagonal_split_agrees(hidden):
+    """FullGraphEvaluator(node_blocks=...): A = A_diag + A_rest (inside the blocks on the blocked kernels --
+    the LDS gather at width 256, counts x features on the matrix cores at 2048 -- the remainder gathered and
+    accumulated, column tile by column tile) gives the logits of the one-pass aggregation, for row blocks that
+    end at block boundaries; blocks of unequal sizes up to 128 nodes, a graph whose ids are ordered by block."""
+    from gist_amd import datasets
+    from gist_amd.engine import ParamArena, dims_for
+    from gist_amd.trainer import FullGraphEvaluator
+    dev = torch.device('cuda', 0)
+    ds = datasets.make_block_dataset('blocks', 5000, 47, 64, 5, intra_deg=20, inter_deg=6, seed=4, hub_frac=0.01,
+                                     hub_mult=8, train_frac=0.7)
+    g = ds.g
+    sizes = np.array([len(b) for b in np.array_split(np.arange(5000), 47)])
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    assert sizes.max() <= 128
+    dims = dims_for(64, hidden, 5, 3)
+    arena = ParamArena(dims, dev, with_grads=False)
+    gen = torch.Generator().manual_seed(2)
+    arena.load([((torch.rand(o, 2 * i, generator=gen) - 0.5) * (2.0 / np.sqrt(2 * i)),
+                 (torch.rand(o, generator=gen) - 0.5) * 0.1) for (i, o) in dims])
+    whole = FullGraphEvaluator(g, dims, True, arena, dev)
+    ref = whole.forward().clone()
+    for rb in (5000, 1300):
+        ev = FullGraphEvaluator(g, dims, True, arena, dev, row_block=rb, node_blocks=bounds)
+        assert ev.split is not None and ev.split['diag_edges'] + ev.split['rest_edges'] == g.number_of_edges()
+        assert ev.split['diag_edges'] > ev.split['rest_edges']
+        assert all(c in set(bounds.tolist()) for c in ev.row_cuts) and ev.row_cuts[-1] == 5000
+        if rb == 1300:
+            assert len(ev.row_cuts) > 3
+        assert (ev.forward() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+        assert abs(ev.accuracy('val_mask') - whole.accuracy('val_mask')) < 1e-9
+    with pytest.raises(ValueError):
+        FullGraphEvaluator(g, dims, True, arena, dev, node_blocks=np.array([0, 200, 5000]))      # blocks > 128
