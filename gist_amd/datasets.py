@@ -54,6 +54,10 @@ def make_block_dataset(name, n, n_blocks, n_feats, n_classes, intra_deg, inter_d
     ClusterIter.g, sampler.py:34,50)."""
     src, dst, blocks = sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed)
     g = Graph.from_edges(src, dst, n)
+    # the node ids are ordered by block: boundaries for the evaluator's block-diagonal split
+    # (trainer.FullGraphEvaluator node_blocks; blocks of at most 128 nodes only)
+    if max(len(b) for b in blocks) <= 128:
+        g.node_blocks = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.int64)
     gen = torch.Generator().manual_seed(seed)
     g.ndata['feat'] = torch.randn(n, n_feats, generator=gen)            # post-StandardScaler stats
     g.ndata['label'] = torch.randint(0, n_classes, (n,), generator=gen)

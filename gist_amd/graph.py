@@ -112,6 +112,8 @@ class Graph(object):
             g = Graph(self.rowptr.to(device), self.col.to(device), self.t_rowptr.to(device),
                       self.t_col.to(device), self._n, self._idtype)
             g._nnz = self._nnz
+            if getattr(self, 'node_blocks', None) is not None:
+                g.node_blocks = self.node_blocks      # (host boundaries of the id-ordered parts, if known)
         g.ndata = NData({k: v.to(device) for k, v in self.ndata.items()})
         return g
 

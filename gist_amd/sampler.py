@@ -173,6 +173,31 @@ class EngineClusterIter(ClusterIter):
                 self._part_of_host = part_of
                 self._node_part = torch.from_numpy(np.stack([part_of, pos], 1).copy()).to(tg.device)   # [N, 2]
         self._extract_scratch = None
+        # Are the parts LOCALITY blocks?  The blocked aggregation kernels (a part's feature tile staged in
+        # LDS, or its diagonal block as a dense counts x features product) pay only when most neighbours of a
+        # batch row lie in the row's own part: on a batch without locality the matrix-core kernel gathers
+        # every row in full and runs 1.6x SLOWER than the row-split kernel (profiles/r02_spmm_kernels_bench.txt).
+        # Measured once on the device: the share of the train graph's edges inside a part, and the expected
+        # number of a row's neighbours that fall in the OTHER parts of its batch (the dense kernel keeps at
+        # most 8 of those per row).  Without locality the batches carry no row blocks and every aggregation
+        # runs on gist_spmm_csr_f32.
+        self.locality = None
+        self.locality_stats = None
+        if self._node_part is not None and tg.number_of_edges() > 0:
+            rp = tg.rowptr.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(n_nodes, device=tg.device), rp[1:] - rp[:-1])
+            po = self._node_part[:, 0]
+            intra = int((po[rows] == po[tg.col.to(torch.int64)]).sum().item())
+            del rows
+            nnz = tg.number_of_edges()
+            inside = intra / float(nnz)
+            n_parts = max(len(self.par_li), 2)
+            outside_in_batch = (nnz - intra) / float(n_nodes) * (min(batch_size, n_parts) - 1) / (n_parts - 1)
+            self.locality_stats = dict(edges_inside_parts=round(inside, 4),
+                                       outside_neighbours_per_batch_row=round(outside_in_batch, 3))
+            self.locality = inside >= 0.5 and outside_in_batch <= 4.0
+            if os.environ.get('GIST_SPMM_LOCALITY') in ('0', '1'):      # dev override
+                self.locality = os.environ['GIST_SPMM_LOCALITY'] == '1'
 
     def bind(self, engine, native=True):
         """Feed `engine`.  native=True attaches the C++ step driver: batches are then only
@@ -244,8 +269,9 @@ class EngineClusterIter(ClusterIter):
                 batch = self.batcher.lazy(ids)
             else:
                 batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
-            batch.row_blocks = self._epoch_blocks[int(self._block_offsets[self.n]):
-                                                  int(self._block_offsets[self.n + 1])]
+            if self.locality is not False:       # (None: parts of unknown quality, e.g. overlapping: as before)
+                batch.row_blocks = self._epoch_blocks[int(self._block_offsets[self.n]):
+                                                      int(self._block_offsets[self.n + 1])]
             if self._part_tables is not None:
                 batch.parts = (self._node_part, self._part_tables, self.n)
             self.n += 1

@@ -6,6 +6,7 @@
 Timing follows the reference: `total_time` sums the epoch loops -- batch construction
 included, evaluation excluded (cluster_gcn.py:91,106-111).
 """
+import os
 import time
 
 import numpy as np
@@ -43,7 +44,8 @@ class FullGraphEvaluator(object):
     counts x features on the matrix cores (gist_spmm_csr_prepared_f32, exact fp32 as in training) instead of
     246 gathered rows per node; A_rest is gathered by the row kernel with accumulate, column tile by column
     tile so that the gathered slab of X stays in the Infinity Cache.  Row blocks are then cut at block
-    boundaries.  None = one gather pass over A (any graph)."""
+    boundaries.  None = the graph's own `node_blocks` attribute if it has one (the synthetic block
+    datasets do), else one gather pass over A (any graph); False = one gather pass."""
 
     def __init__(self, g, dims, use_layernorm, arena, device, row_block=None,
                  block_bytes=4 << 30, node_blocks=None):
@@ -76,7 +78,11 @@ class FullGraphEvaluator(object):
         self.h = [torch.empty(n, hidden, **f32) for _ in range(2 if L1 > 2 else 1)] if L1 > 1 else []
         self.zb = torch.empty(self.row_block, 2 * max_in, **f32) if blocked else None
         self.yb = torch.empty(self.row_block, max_out, **f32) if blocked else None
-        if node_blocks is not None and blocked:
+        if node_blocks is None:
+            node_blocks = getattr(g, 'node_blocks', None)      # a dataset whose ids are ordered by part says so
+        if node_blocks is False:
+            node_blocks = None                                  # explicit opt-out: one gather pass
+        if node_blocks is not None and blocked and os.environ.get('GIST_EVAL_SPLIT', '1') != '0':
             self._split_graph(np.asarray(node_blocks, np.int64))
         self.logits = torch.empty(n, self.ldc, **f32)
         self.pbuf = torch.empty(n, self.ldc, **f32) if self.project_first else None

@@ -204,8 +204,10 @@ def test_evaluator_block_diagonal_split_agrees(hidden):
     gen = torch.Generator().manual_seed(2)
     arena.load([((torch.rand(o, 2 * i, generator=gen) - 0.5) * (2.0 / np.sqrt(2 * i)),
                  (torch.rand(o, generator=gen) - 0.5) * 0.1) for (i, o) in dims])
-    whole = FullGraphEvaluator(g, dims, True, arena, dev)
+    whole = FullGraphEvaluator(g, dims, True, arena, dev, node_blocks=False)
+    assert whole.split is None
     ref = whole.forward().clone()
+    assert FullGraphEvaluator(g, dims, True, arena, dev).split is not None      # the dataset's own boundaries
     for rb in (5000, 1300):
         ev = FullGraphEvaluator(g, dims, True, arena, dev, row_block=rb, node_blocks=bounds)
         assert ev.split is not None and ev.split['diag_edges'] + ev.split['rest_edges'] == g.number_of_edges()
