@@ -80,8 +80,13 @@ __device__ __forceinline__ void c3_emit(const float (&v)[8], char *plane0, int p
         *reinterpret_cast<uint4 *>(plane0 + q * plane_bytes + off) = make_uint4(w[0][q], w[1][q], w[2][q], w[3][q]);
 }
 
+// (The builtin, not inline asm: the compiler must KNOW these are MFMAs.  As opaque asm statements it reused
+// a fragment register for an accumulator's zero-initialisation one instruction after the MFMA that still
+// read it as SrcA, and copied accumulators right behind the MFMA that wrote them -- both hazards the
+// backend's recognizer covers for real MFMA instructions.  Found as a one-time error of 1e-4 in ONE
+// accumulator per wave.)
 __device__ __forceinline__ void c3_mfma(c3_f32x4 &acc, const c3_bf16x8 &a, const c3_bf16x8 &b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
 
 // Staging registers of one operand for one k tile.
@@ -190,15 +195,17 @@ __device__ __forceinline__ void c3_store(C3Stage<KC, T> &st, char *image, int k0
 // the split runs under the other wave's MFMAs -- inside ONE wave a vector instruction next to an MFMA stream
 // costs matrix-pipe time, profiles/r01_gemm_phase_trace.md; the first version of this kernel did
 // convert -> barrier -> multiply -> barrier with every wave and only matched the fp32 kernel):
-//   waves 4-7 PRODUCE: tile t + 1's fp32 values (loaded a step earlier) -> three bf16 pieces -> LDS stage
-//             (t + 1) & 1, then the global loads of tile t + 2;
-//   waves 0-3 CONSUME: fragments of stage t & 1 -> 6 x NI x NI MFMAs each (2 x 2 waves over the T x T tile);
-// one workgroup barrier per k step: stage (t + 1) & 1 complete, stage t & 1 free.
+//   waves 4-7 PRODUCE: tile j's fp32 values (loaded three steps earlier) -> three bf16 pieces -> LDS stage
+//             j % 3, then the global loads of tile j + 3;
+//   waves 0-3 CONSUME: fragments of tile j -> registers while the 6 x NI x NJ MFMAs of tile j - 1 run
+//             (2 x 2 waves over the TM x TN tile, two fragment register sets);
+// one workgroup barrier per k step (P_j: tile j is in LDS).
 template <bool A_KC, bool B_KC, int TM, int TN>
-__global__ __launch_bounds__(512, TM == 64 ? 2 : 1) void gemm_b3c_kernel(C3Args g) {
+__global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     extern __shared__ __attribute__((aligned(16))) char c3_smem[];
     constexpr int PLANE_A = TM * 64, PLANE_B = TN * 64;      // bytes of one piece plane of an operand
     constexpr int STAGE = 3 * (PLANE_A + PLANE_B);           // A planes, then B planes
+    constexpr int NSTAGE = 3;
     constexpr int WM = TM / 2, WN = TN / 2;                  // consumer wave tile (2 x 2 waves)
     constexpr int NI = WM / 16, NJ = WN / 16;                // 16 x 16 MFMA tiles per wave
 
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(512, TM == 64 ? 2 : 1) void gemm_b3c_kernel(C3Args 
             c3_load<B_KC, TN, true>(B_KC ? ob + k0 : ob + (int64_t)k0 * g.ldb, g.ldb, k0, k_end, rb, t);
         };
         auto store_full = [&](int kt, C3Stage<A_KC, TM> &ra, C3Stage<B_KC, TN> &rb) {
-            char *img = c3_smem + (kt & 1) * STAGE;
+            char *img = c3_smem + (kt % NSTAGE) * STAGE;
             c3_store<A_KC, TM, true>(ra, img, 0, k_end, t);
             c3_store<B_KC, TN, true>(rb, img + 3 * PLANE_A, 0, k_end, t);
         };
@@ -264,41 +271,34 @@ __global__ __launch_bounds__(512, TM == 64 ? 2 : 1) void gemm_b3c_kernel(C3Args 
         if (n_full > 0) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) load_full(d, sa[d], sb[d]);
-            store_full(0, sa[0], sb[0]);
-            load_full(PD, sa[0], sb[0]);
-        } else if (tail) {
-            char *img = c3_smem;
-            c3_store<A_KC, TM, false>(ta, img, k_begin, k_end, t);
-            c3_store<B_KC, TN, false>(tb, img + 3 * PLANE_A, k_begin, k_end, t);
         }
-        __syncthreads();                                      // stage 0 ready
-        // iteration kt (consumers multiply tile kt): store tile kt + 1, refill its register set
+        // tile j: store (stage j % NSTAGE, register set j % PD), refill the set with tile j + PD, barrier P_j
         int kt = 0;
-        for (; kt + PD <= n_full - 1; kt += PD) {             // tiles kt + 1 .. kt + PD are all full
+        for (; kt + PD <= n_full; kt += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
-                store_full(kt + d + 1, sa[(d + 1) % PD], sb[(d + 1) % PD]);
-                load_full(kt + d + 1 + PD, sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                store_full(kt + d, sa[d], sb[d]);
+                load_full(kt + d + PD, sa[d], sb[d]);
                 __syncthreads();
+                // (left alone the scheduler hoists the conversions of the next two tiles above this barrier
+                // and waits for ALL loads in flight at the top of the unrolled body: vmcnt(0) every 3 steps)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int d = 0; d < PD; ++d) {                        // the last (< PD) full tiles: kt % PD == 0 here
-            if (kt + d + 1 <= n_full - 1) {
-                store_full(kt + d + 1, sa[(d + 1) % PD], sb[(d + 1) % PD]);
+            if (kt + d < n_full) {
+                store_full(kt + d, sa[d], sb[d]);
                 __syncthreads();
             }
         }
-        if (n_full > 0) {
-            if (tail) {                                       // iteration n_full - 1 stores the ragged tile
-                char *img = c3_smem + (n_full & 1) * STAGE;
-                const int k0 = k_begin + n_full * C3_BK;
-                c3_store<A_KC, TM, false>(ta, img, k0, k_end, t);
-                c3_store<B_KC, TN, false>(tb, img + 3 * PLANE_A, k0, k_end, t);
-            }
-            __syncthreads();                                  // end of iteration n_full - 1
+        if (tail) {
+            char *img = c3_smem + (n_full % NSTAGE) * STAGE;
+            const int k0 = k_begin + n_full * C3_BK;
+            c3_store<A_KC, TM, false>(ta, img, k0, k_end, t);
+            c3_store<B_KC, TN, false>(tb, img + 3 * PLANE_A, k0, k_end, t);
+            __syncthreads();
         }
-        if (tail) __syncthreads();                            // end of the ragged tile's iteration
         return;
     }
     // ==================================== consumers ==================================================
@@ -317,30 +317,73 @@ __global__ __launch_bounds__(512, TM == 64 ? 2 : 1) void gemm_b3c_kernel(C3Args 
     const int fb = 3 * PLANE_A + (wn * WN + rr) * 64 + ((kg ^ ((rr >> 1) & 3)) << 4);
     constexpr int pa[6] = {0, 0, 1, 1, 0, 2};
     constexpr int pb[6] = {0, 1, 0, 1, 2, 0};
-    __syncthreads();                                          // stage 0 ready
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const char *img = c3_smem + (kt & 1) * STAGE;
-        c3_bf16x8 af[NI][3], bf[NJ][3];
+    // Barrier P_j: tile j is in LDS (stage j % NSTAGE).  After it the wave issues the fragment reads of tile j
+    // into one register set and, while they fly, the MFMAs of tile j - 1 from the other set: the matrix pipe
+    // never waits for an LDS round trip (with one set the reads of a tile sat between the barrier and its
+    // first MFMA: ~1300 cycles per k step on top of the MFMAs).  Three stages: tile j + NSTAGE overwrites
+    // tile j's stage after P_{j+2}, by when this wave has waited for its reads of tile j (before P_{j+1}).
+    c3_bf16x8 af[2][NI][3], bf[2][NJ][3];
+    auto read_frags = [&](int kt, auto set_c) {
+        constexpr int set = decltype(set_c)::value;
+        const char *img = c3_smem + (kt % NSTAGE) * STAGE;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                bf[j][q] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_B + fb + j * 16 * 64);
+                bf[set][j][q] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_B + fb + j * 16 * 64);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                af[i][q] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_A + fa + i * 16 * 64);
+                af[set][i][q] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_A + fa + i * 16 * 64);
         }
+    };
+    auto multiply = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
         // smallest terms first; consecutive MFMAs go to NI * NJ different accumulators
 #pragma unroll
         for (int term = 5; term >= 0; --term)
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) c3_mfma(acc[i][j], af[i][pa[term]], bf[j][pb[term]]);
+                for (int j = 0; j < NJ; ++j) c3_mfma(acc[i][j], af[set][i][pa[term]], bf[set][j][pb[term]]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    int kt = 0;
+#ifdef C3_NO_OVERLAP      // dev probe: fragments read and consumed in the same step
+    for (; kt < n_kt; ++kt) {
         __syncthreads();
+        read_frags(kt, S0{});
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        multiply(S0{});
     }
-    // the MFMAs above are opaque to the compiler's hazard recognizer: let the last ones retire
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    kt = n_kt + 1;
+#endif
+    for (; kt + 2 <= n_kt; kt += 2) {
+        __syncthreads();                                      // P_kt
+        read_frags(kt, S0{});
+        if (kt > 0) multiply(S1{});
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this tile's fragments are in
+        __syncthreads();                                      // P_{kt+1}
+        read_frags(kt + 1, S1{});
+        multiply(S0{});
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    auto settle = [&]() {};
+#ifdef C3_NO_OVERLAP
+    settle();
+#else
+    if (kt < n_kt) {                                          // odd tile count: one more
+        __syncthreads();
+        read_frags(kt, S0{});
+        if (kt > 0) multiply(S1{});
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        multiply(S0{});
+        settle();
+    } else if (n_kt > 0) {
+        multiply(S1{});
+        settle();
+    }
+#endif
 
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
@@ -361,25 +404,26 @@ __global__ __launch_bounds__(512, TM == 64 ? 2 : 1) void gemm_b3c_kernel(C3Args 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-// Which calls take this kernel by default.  MEASURED (scripts/b3c_bench.py, profiles/r03_b3c_bench.txt): a k
-// step costs ~1300 cycles on top of its MFMAs (fragment-read latency after the barrier, the barrier itself,
-// the producers' LDS writes), so the kernel only MATCHES the fp32 kernel on most per-rank shapes (2046 x 1024
-// x 2048: 67 vs 70 us, 2046 x 512 x 1204: 24.5 vs 25.6) and beats it where 128 x 128 tiles fill the chip
-// with one workgroup per CU -- dZ = dY . W of the width-1024 sub-GCN, 2046 x 2048 x 1024: 54 vs 69 us.  So
-// by default only the NN layout with >= 200 tiles of 128 x 128 and >= 4 GFLOP comes here; the tuning hook
-// GIST_TUNE_B3C = 2 sends every shape with m, n, k >= 64 (tests, sweeps), 1 none.
+// Which calls take this kernel by default.  MEASURED (scripts/b3c_bench.py, profiles/r03_b3c_bench.txt; us,
+// standalone calls, fp32 kernel -> this kernel with 64 x 64 tiles and one k slice): NT 2046 x 1024 x 2048
+// 76 -> 59, NT 2046 x 1024 x 1204 50 -> 43, NN 2046 x 2048 x 1024 73 -> 66, NT 2046 x 512 x 1204 24.9 -> 22.3;
+// TN (both operands k-major: 16 scalar row loads per thread and step) 1024 x 2048 x 2046 68.5 -> 64, but
+// 1024 x 1204 x 2046 54 -> 60 and 512 x 1024 x 2046 25 -> 43.  So by default the NT and NN layouts from
+// 2 GFLOP with at least 256 tiles of 64 x 64 come here and TN stays on the fp32 kernel; the tuning hook
+// GIST_TUNE_B3C = 2 sends every shape with m, n, k >= 64 (tests, sweeps), 1 none.  A k step still costs
+// several hundred cycles on top of its MFMAs; the matrix pipe is far from saturated.
 static bool b3c_geometry_ok(int64_t m, int64_t n, int64_t k) {
     return h3_mode() == 2 && (int)tune(GIST_TUNE_B3C) != 1 && m >= 64 && n >= 64 && k >= 64;
 }
 bool b3c_shape_ok(int64_t m, int64_t n, int64_t k) {
     if (!b3c_geometry_ok(m, n, k)) return false;
     if ((int)tune(GIST_TUNE_B3C) == 2) return true;
-    return ceil_div(m, 128) * ceil_div(n, 128) >= 200 && 2.0 * (double)m * (double)n * (double)k >= 4e9;
+    return ceil_div(m, 64) * ceil_div(n, 64) >= 256 && 2.0 * (double)m * (double)n * (double)k >= 2e9;
 }
 
 template <bool A_KC, bool B_KC, int TM, int TN>
 static int b3c_launch(const char *name, C3Args &g, int splits, hipStream_t st) {
-    const size_t smem = (size_t)2 * 3 * (TM + TN) * 64;      // two stages of (A, B) x 3 planes
+    const size_t smem = (size_t)3 * 3 * (TM + TN) * 64;      // three stages of (A, B) x 3 planes
     static DeviceOnce once;       // one per template instance
     int dev;
     if (once.needed(&dev)) {
@@ -398,23 +442,18 @@ static int b3c_launch(const char *name, C3Args &g, int splits, hipStream_t st) {
     return launch_status(name);
 }
 
-// Tile and k slices.  One 512-thread workgroup per CU at 128 x N tiles (two at 64 x 64), so the first aim is
-// >= ~256 workgroups: 128 x 128 when that many tiles exist, else 128 x 64, else 64 x 64, else k slices
-// (fp32 slabs, reduced by the call or left to the consumer).  Fitted to scripts/b3c_bench.py.
+// Tile and k slices (fp32 slabs, reduced by the call or left to the consumer).  Fitted to scripts/b3c_bench.py.
 static void b3c_choice(int64_t m, int64_t n, int64_t k, int *tm, int *tn, int *splits) {
     const int t_tile = (int)tune(GIST_TUNE_GEMM_TILE), t_split = (int)tune(GIST_TUNE_GEMM_SPLITS);
     auto tiles = [&](int a, int b) { return ceil_div(m, a) * ceil_div(n, b); };
-    if (tiles(128, 128) >= 200) { *tm = 128; *tn = 128; }
-    else if (tiles(128, 64) >= 200) { *tm = 128; *tn = 64; }
-    else { *tm = 64; *tn = 64; }
-    if (t_tile == 64) { *tm = 64; *tn = 64; }
-    else if (t_tile == 128) { *tm = 128; *tn = 128; }
-    else if (t_tile == 12864) { *tm = 128; *tn = 64; }
+    // (no 128 x 128: two fragment sets of a 64 x 64 wave tile do not fit the register file; 128 x 64 measured
+    // slower than 64 x 64 on every per-rank shape -- two workgroups per CU matter more than the tile)
+    *tm = 64; *tn = 64;
+    if (t_tile == 128 || t_tile == 12864) { *tm = 128; *tn = 64; }
     const int64_t wgs = tiles(*tm, *tn);
     const int64_t kt = ceil_div(k, C3_BK);
     int64_t sp = 1;
-    const int64_t want = *tm == 64 ? 512 : 256;
-    if (wgs * 2 <= want) sp = want / wgs;
+    if (wgs < 128) sp = 256 / wgs;                            // (only reachable through the tuning hook)
     if (sp > kt / 8) sp = kt / 8;                             // a slice keeps >= 8 k tiles
     if (t_split > 0) sp = t_split;
     if (sp > kt) sp = kt;
@@ -436,7 +475,7 @@ int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda
     if (!b3c_shape_ok(m, n, k)) return 0;
     if (!(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && lda >= 4 && ldb >= 4)) return 0;
     if (!a_kc && b_kc) return 0;                                     // (no caller uses this layout)
-    if ((int)tune(GIST_TUNE_B3C) != 2 && !(a_kc && !b_kc)) return 0; // by default: the NN layout only (see above)
+    if ((int)tune(GIST_TUNE_B3C) != 2 && !a_kc) return 0;            // by default: NT and NN only (see above)
     int tm = 128, tn = 128, splits = 1;
     b3c_choice(m, n, k, &tm, &tn, &splits);
     if (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits = 1;
@@ -451,8 +490,7 @@ int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda
     int rc;
 #define C3_GO(AK, BK_)                                                                        \
     rc = tm == 64 ? b3c_launch<AK, BK_, 64, 64>(name, g, splits, st)                          \
-                  : (tn == 64 ? b3c_launch<AK, BK_, 128, 64>(name, g, splits, st)             \
-                              : b3c_launch<AK, BK_, 128, 128>(name, g, splits, st))
+                  : b3c_launch<AK, BK_, 128, 64>(name, g, splits, st)
     if (a_kc && b_kc) { C3_GO(true, true); }
     else if (a_kc) { C3_GO(true, false); }
     else { C3_GO(false, false); }

@@ -181,10 +181,10 @@ int gist_gemm_slabs_f32(int layout, const float *a, int64_t lda, const float *b,
  * read once at first use; gist_gemm_set_mode overrides it; process-wide: set it before sizing
  * workspaces).  Inputs, outputs and accumulation are fp32 in every mode, and small or skinny shapes
  * always run on v_mfma_f32_32x32x2_f32.
- *   Mode 2, bf16x3 (the default): the same arithmetic in two kernels.  gist_gemm_nn_f32 calls of >= 4 GFLOP
- *     with >= 200 output tiles of 128 x 128 that do not reach the thresholds below split their operands
- *     INSIDE the GEMM (convert on load: no pre-pass, no workspace; the other layouts only match the fp32
- *     kernel there and stay on it -- tuning hook GIST_TUNE_B3C).  Shapes large enough to fill the chip (>= 128 workgroups of
+ *   Mode 2, bf16x3 (the default): the same arithmetic in two kernels.  gist_gemm_nt_f32 / gist_gemm_nn_f32
+ *     calls of >= 2 GFLOP with >= 256 output tiles of 64 x 64 that do not reach the thresholds below split
+ *     their operands INSIDE the GEMM (convert on load: no pre-pass, no workspace; 1.1-1.3x the fp32 kernel
+ *     there; gist_gemm_tn_f32 stays on the fp32 kernel -- tuning hook GIST_TUNE_B3C).  Shapes large enough to fill the chip (>= 128 workgroups of
  *     256 x 128 tiles x k slices, >= 16 GFLOP per call or >= 9 GFLOP inside gist_sage_step, workspace
  *     of gist_gemm_workspace_bytes) carry each fp32 operand as three bf16 pieces, x = b1 + b2 + b3
  *     EXACTLY (3 x 8 = all 24 significant bits, fp32's exponent range, no scales), and accumulate

@@ -131,13 +131,17 @@ def test_b3c_deferred_slabs(hip):
     a = torch.randn(k, m, device=DEV, generator=gen)
     b = torch.randn(k, n, device=DEV, generator=gen)
     ref = torch.empty(m, n, device=DEV)
-    hip.gemm_tn(a, b, ref)
-    need = int(L.gist_gemm_workspace_bytes(m, n, k))
-    assert need > 0
-    slabs = torch.full((need // 4,), float('nan'), device=DEV)
-    c = torch.full((m, n), float('nan'), device=DEV)
-    ns = hip.gemm_slabs('tn', a, b, None, c, slabs.view(torch.uint8))
-    assert ns > 1
+    hip.tuning('gemm_splits', 4)          # (the kernel's own choice for this shape is one k slice)
+    try:
+        hip.gemm_tn(a, b, ref)
+        need = int(L.gist_gemm_workspace_bytes(m, n, k))
+        assert need >= 4 * m * n * 4
+        slabs = torch.full((need // 4,), float('nan'), device=DEV)
+        c = torch.full((m, n), float('nan'), device=DEV)
+        ns = hip.gemm_slabs('tn', a, b, None, c, slabs.view(torch.uint8))
+    finally:
+        hip.tuning('gemm_splits', 0)
+    assert ns == 4
     acc = torch.zeros(m * n, device=DEV)
     for s in range(ns):
         acc = acc + slabs[s * m * n:(s + 1) * m * n]
