@@ -579,19 +579,26 @@ def _steps_vs_oracle(ds, batch_parts, n_hidden, n_layers, n_steps, p_seed):
 # MI355X for each case (profiles/r03_parity_stats.txt: mean |diff|, fraction of weights above 1e-4;
 # GIST_PARITY_STATS=<file> appends the statistics of a run).  Round 2 used one bar for all: 1e-5 / 2e-2.
 PARITY_BARS = {
-    ('metric_config_vs_oracle', 'f32', 4096): (6.8e-6, 1.02e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 4096): (6.7e-6, 1.0e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 2048): (1.12e-5, 1.74e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 1024): (5.7e-6, 6.6e-3),
-    ('metric_config_vs_oracle', 'bf16x3', 512): (7.5e-7, 1.07e-3),
-    ('metric_config_vs_oracle', 'f16x3', 4096): (4.3e-6, 5.7e-3),
-    ('metric_config_vs_oracle', 'f16x3', 2048): (1.12e-5, 1.74e-2),
-    ('metric_config_vs_oracle', 'f16x3', 1024): (7.0e-6, 7.7e-3),
-    ('config5_sub_step_vs_oracle', 'bf16x3', 4096): (4.0e-6, 1.1e-3),
+    # GPU step vs the CPU oracle after two Adam steps.  CHAOTIC: Adam's first update is lr * sign(g) for all
+    # but rounding-level gradients, and a handful of ReLU inputs within rounding of zero take different masks
+    # in any two fp32 implementations (the oracle sums in another order), which moves whole rows of the
+    # gradient by ~1e-3 of their norm.  Seed study at width 1024 (profiles/r03_parity_stats.txt): the SAME
+    # kernels give mean 4.9e-8 .. 2.5e-5, fraction 3.9e-5 .. 4.5e-2 over three seeds, fp32 kernel and bf16x3
+    # kernel trading places.  Bar = 2x the worst observed; the gradient parity proper is the float64 test.
+    ('metric_config_vs_oracle', 'f32', 4096): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 4096): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 2048): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 1024): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'bf16x3', 512): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'f16x3', 4096): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'f16x3', 2048): (5e-5, 9e-2),
+    ('metric_config_vs_oracle', 'f16x3', 1024): (5e-5, 9e-2),
+    ('config5_sub_step_vs_oracle', 'bf16x3', 4096): (5e-5, 9e-2),
+    # two GPU variants of the same step (same masks unless a projection's rounding differs): 2x measured
     ('kept_vs_per_call_splits', 'f16x3', 4096): (2.0e-8, 2.2e-5),
     ('kept_vs_per_call_splits', 'bf16x3', 4096): (1.5e-9, 1.0e-6),
     ('wide_class_layer_split_vs_f32', 'f16x3', 2048): (6.5e-7, 4.3e-4),
-    ('wide_class_layer_split_vs_f32', 'bf16x3', 2048): (4.9e-7, 3.5e-4),
+    ('wide_class_layer_split_vs_f32', 'bf16x3', 2048): (9.4e-7, 4.3e-4),
 }
 
 
@@ -696,8 +703,12 @@ def test_metric_config_hidden4096_vs_oracle(mode, hidden):
             b = tg.batch(it.batch_ids(j))
             ref_loss, ref_logits, _ = O.train_step(b[0], b[1], b[2], b[3], b[4], b[5], params, opt,
                                                    True, 0.01)
-            assert abs(float(loss.item()) - float(ref_loss)) < TOL, (j, float(loss.item()), ref_loss)
+            # (1e-4 of the loss: at width 1024 the random-init loss is ~13, and the second step's loss sits behind
+            # one Adam update, which turns rounding-level differences of near-zero gradients into +-lr)
+            assert abs(float(loss.item()) - float(ref_loss)) < TOL * max(1.0, abs(float(ref_loss))), \
+                (j, float(loss.item()), ref_loss)
             if j == 0:
+                assert abs(float(loss.item()) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
                 assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max())
             if j == 1:
                 break
@@ -737,17 +748,21 @@ def _float64_step(rowptr, col, feat, labels, params, masks):
     return loss.item(), y.detach(), [(W.grad, b.grad) for W, b in ps], yhats
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16x3'])
-def test_metric_config_hidden4096_vs_float64(mode):
-    """Metric configuration, one forward/backward against float64 autograd on the same batch.
-    Both GEMM modes must reproduce the float64 activations, logits, loss and every gradient to
-    fp32 rounding level; the handful of ReLU inputs within rounding of zero (their count is
-    bounded here) take the GPU's own mask in the reference."""
+@pytest.mark.parametrize('mode,hidden', [('f32', 4096), ('bf16x3', 4096), ('f16x3', 4096),
+                                         ('bf16x3', 1024), ('bf16x3', 512), ('f32', 1024)])
+def test_metric_config_hidden4096_vs_float64(mode, hidden):
+    """Metric configuration (and the per-rank widths 1024 / 512 of the N = 4 / 8 points, whose NT / NN
+    projections run on the convert-on-load bf16x3 kernel in the default mode), one forward/backward against
+    float64 autograd on the same batch.  Every GEMM mode must reproduce the float64 activations, logits, loss
+    and every gradient to fp32 rounding level; the handful of ReLU inputs within rounding of zero (their
+    count is bounded here) take the GPU's own mask in the reference -- THE parity statement for the
+    gradients: the post-Adam comparison with the oracle (test_metric_config_hidden4096_vs_oracle) is chaotic
+    in exactly those few masks (profiles/r03_parity_stats.txt)."""
     from gist_amd import hip
     from oracle import train_oracle as TO
     prev = hip.gemm_mode()
     try:
-        ds, it, eng, dims, params = _metric_config_engine(mode)
+        ds, it, eng, dims, params = _metric_config_engine(mode, hidden)
         it.bind(eng, native=False)
         g = ds.g
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
@@ -766,7 +781,7 @@ def test_metric_config_hidden4096_vs_float64(mode):
             flips = int(((yh[k] > 0) != (yh64[k] > 0)).sum().item())
             assert flips <= 40, (k, flips)              # of 8.4 M activations
         loss = eng.loss_and_backward(batch)
-        assert abs(loss.item() - l64) < 1e-5
+        assert abs(loss.item() - l64) < 1e-5 * max(1.0, abs(l64))
         assert (eng.logits(n).double() - y64).abs().max().item() < TOL * max(1.0, y64.abs().max().item())
         for k in range(len(dims)):
             for got, ref in ((eng.arena.dW[k], g64[k][0]), (eng.arena.db[k], g64[k][1])):
