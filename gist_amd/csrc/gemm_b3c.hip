@@ -9,8 +9,8 @@
 // (its operand split costs as much as it saves below ~9 GFLOP), run on the bf16 matrix cores too.
 // Price: an operand tile is converted once per workgroup that uses it (VALU, ~6 instructions per
 // element) instead of once per call; a k step of a 128 x 128 tile is 96 MFMAs (1536 matrix-pipe cycles)
-// and ~170 VALU instructions per producer wave, against 4096 matrix-pipe cycles of the fp32 kernel.  Two
-// LDS stages (2 x 48 KiB at T = 128, 2 x 24 KiB at T = 64), producer and consumer waves (see the kernel).
+// and ~176 VALU instructions per producer wave, against 4096 matrix-pipe cycles of the fp32 kernel.  Three
+// LDS stages (3 x 48 KiB at 128 x 128, 3 x 24 KiB at 64 x 64), producer and consumer waves (see the kernel).
 //
 // Layouts as gemm.hip: NT (A [m,k], B [n,k]), NN (A [m,k], B [k,n]), TN (A [k,m], B [k,n]); k-contiguous
 // operands are read 2 x 16 bytes per chunk, m/n-contiguous ones as 8 rows x (T / 64) columns (the
@@ -60,13 +60,17 @@ __device__ __forceinline__ void c3_split2(c3_f32x2 x, uint32_t (&w)[3]) {
             c3_f32x2 back;
             back.x = __builtin_bit_cast(float, w[q] << 16);
             back.y = __builtin_bit_cast(float, w[q] & 0xffff0000u);
-            x = x - back;                                   // exact
+            // exact; two plain subtractions, NOT one v_pk_add_f32: beside another wave's MFMA stream a packed
+            // f32 instruction costs ~13 cycles of the SIMD's vector issue on top of its slot (MI355X_MICROARCH.md,
+            // 'price of one filler beside MFMAs'), and plain C++ is re-packed by the SLP vectoriser
+            asm("v_sub_f32_e32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(back.x));
+            asm("v_sub_f32_e32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(back.y));
         }
     }
 }
 
-// 8 consecutive k of one row -> the row's chunk in each of the three planes
-__device__ __forceinline__ void c3_emit(const float (&v)[8], char *plane0, int plane_bytes, int off) {
+// 8 consecutive k of one row -> the row's 16-byte chunk for each of the three planes
+__device__ __forceinline__ void c3_split8(const float (&v)[8], uint4 (&out)[3]) {
     uint32_t w[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -76,8 +80,7 @@ __device__ __forceinline__ void c3_emit(const float (&v)[8], char *plane0, int p
         c3_split2(x, w[j]);
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-        *reinterpret_cast<uint4 *>(plane0 + q * plane_bytes + off) = make_uint4(w[0][q], w[1][q], w[2][q], w[3][q]);
+    for (int q = 0; q < 3; ++q) out[q] = make_uint4(w[0][q], w[1][q], w[2][q], w[3][q]);
 }
 
 // (The builtin, not inline asm: the compiler must KNOW these are MFMAs.  As opaque asm statements it reused
@@ -158,37 +161,41 @@ __device__ __forceinline__ void c3_load(const float *__restrict__ origin, int64_
     }
 }
 
-// (mask the k tail,) split, write to LDS (rows / columns clamped at load time carry garbage that only
-// reaches outputs past m / n, which are never stored)
-template <bool KC, int T, bool FULL>
-__device__ __forceinline__ void c3_store(C3Stage<KC, T> &st, char *image, int k0, int k_end, int t) {
-    constexpr int PLANE = T * 64;
-    if constexpr (KC) {
+// The converted chunks of one operand for one k tile, and where this thread's chunks go in an LDS image.
+template <int T> struct C3Out {
+    uint4 w[T / 64][3];
+};
+template <bool KC, int T> __device__ __forceinline__ void c3_lds_offsets(uint32_t (&off)[T / 64], int t) {
 #pragma unroll
-        for (int i = 0; i < T / 64; ++i) {
-            const int q = t + 256 * i;
-            const int r = q >> 2, kg = q & 3;
-            if constexpr (!FULL) {
-                const int kk = k0 + 8 * kg;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) st.v[i][j] = kk + j < k_end ? st.v[i][j] : 0.f;
-            }
-            c3_emit(st.v[i], image, PLANE, r * 64 + ((kg ^ ((r >> 1) & 3)) << 4));
-        }
-    } else {
-        constexpr int CW = T / 64;
-        const int kg = t >> 6;
-#pragma unroll
-        for (int u = 0; u < CW; ++u) {
-            const int r = (t & 63) * CW + u;
-            if constexpr (!FULL) {
-                const int kk = k0 + 8 * kg;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) st.v[u][j] = kk + j < k_end ? st.v[u][j] : 0.f;
-            }
-            c3_emit(st.v[u], image, PLANE, r * 64 + ((kg ^ ((r >> 1) & 3)) << 4));
-        }
+    for (int i = 0; i < T / 64; ++i) {
+        int r, kg;
+        if constexpr (KC) { const int q = t + 256 * i; r = q >> 2; kg = q & 3; }
+        else { r = (t & 63) * (T / 64) + i; kg = t >> 6; }
+        off[i] = (uint32_t)(r * 64 + ((kg ^ ((r >> 1) & 3)) << 4));
     }
+}
+
+// (mask the k tail,) split (rows / columns clamped at load time carry garbage that only reaches outputs past
+// m / n, which are never stored)
+template <bool KC, int T, bool FULL>
+__device__ __forceinline__ void c3_convert(C3Stage<KC, T> &st, C3Out<T> &out, int k0, int k_end, int t) {
+#pragma unroll
+    for (int i = 0; i < T / 64; ++i) {
+        if constexpr (!FULL) {
+            const int kk = k0 + 8 * (KC ? ((t + 256 * i) & 3) : (t >> 6));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st.v[i][j] = kk + j < k_end ? st.v[i][j] : 0.f;
+        }
+        c3_split8(st.v[i], out.w[i]);
+    }
+}
+template <int T>
+__device__ __forceinline__ void c3_write(const C3Out<T> &out, char *image, const uint32_t (&off)[T / 64]) {
+    constexpr int PLANE = T * 64;
+#pragma unroll
+    for (int i = 0; i < T / 64; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4 *>(image + q * PLANE + off[i]) = out.w[i][q];
 }
 
 // Workgroup = 8 waves with fixed roles (each SIMD hosts one wave of either kind, so the vector ALU work of
@@ -200,6 +207,17 @@ __device__ __forceinline__ void c3_store(C3Stage<KC, T> &st, char *image, int k0
 //   waves 0-3 CONSUME: fragments of tile j -> registers while the 6 x NI x NJ MFMAs of tile j - 1 run
 //             (2 x 2 waves over the TM x TN tile, two fragment register sets);
 // one workgroup barrier per k step (P_j: tile j is in LDS).
+#ifdef C3_PROBE   // dev build (scripts/b3c_probe.py): where a k step's cycles go, per workgroup
+__device__ unsigned long long g_c3_probe[16 * 4096];
+__device__ __forceinline__ unsigned long long c3_stamp() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define C3_T() c3_stamp()
+#endif
+
 template <bool A_KC, bool B_KC, int TM, int TN>
 __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     extern __shared__ __attribute__((aligned(16))) char c3_smem[];
@@ -236,7 +254,10 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
         // flight the producers waited ~2 us per step for their operands and the kernel ran at their pace).
         // The steady state is straight-line code over the FULL tiles: loads past the last full tile re-read
         // it (never consumed), the ragged last tile sits in a register set of its own from the start.
-        constexpr int PD = 3;
+#ifndef C3_PD64
+#define C3_PD64 3
+#endif
+        constexpr int PD = TM + TN <= 128 ? C3_PD64 : 3;      // 16 values per operand and set at T = 64
         C3Stage<A_KC, TM> sa[PD], ta;
         C3Stage<B_KC, TN> sb[PD], tb;
         c3_offsets<A_KC, TM>(g.lda, g.m, row0, ta, t);
@@ -258,10 +279,19 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
             c3_load<A_KC, TM, true>(A_KC ? oa + k0 : oa + (int64_t)k0 * g.lda, g.lda, k0, k_end, ra, t);
             c3_load<B_KC, TN, true>(B_KC ? ob + k0 : ob + (int64_t)k0 * g.ldb, g.ldb, k0, k_end, rb, t);
         };
-        auto store_full = [&](int kt, C3Stage<A_KC, TM> &ra, C3Stage<B_KC, TN> &rb) {
+        C3Out<TM> wa;
+        C3Out<TN> wb;
+        uint32_t la[TM / 64], lb[TN / 64];
+        c3_lds_offsets<A_KC, TM>(la, t);
+        c3_lds_offsets<B_KC, TN>(lb, t);
+        auto convert_full = [&](C3Stage<A_KC, TM> &ra, C3Stage<B_KC, TN> &rb) {
+            c3_convert<A_KC, TM, true>(ra, wa, 0, k_end, t);
+            c3_convert<B_KC, TN, true>(rb, wb, 0, k_end, t);
+        };
+        auto write_tile = [&](int kt) {
             char *img = c3_smem + (kt % NSTAGE) * STAGE;
-            c3_store<A_KC, TM, true>(ra, img, 0, k_end, t);
-            c3_store<B_KC, TN, true>(rb, img + 3 * PLANE_A, 0, k_end, t);
+            c3_write<TM>(wa, img, la);
+            c3_write<TN>(wb, img + 3 * PLANE_A, lb);
         };
         if (tail) {                                           // the ragged tile: masked, clamped
             const int k0 = k_begin + n_full * C3_BK;
@@ -271,14 +301,43 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
         if (n_full > 0) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) load_full(d, sa[d], sb[d]);
+            convert_full(sa[0], sb[0]);
+            load_full(PD, sa[0], sb[0]);
         }
-        // tile j: store (stage j % NSTAGE, register set j % PD), refill the set with tile j + PD, barrier P_j
+        // Software pipeline.  Entering step j the converted chunks of tile j sit in (wa, wb): their LDS writes
+        // are issued first, then tile j + 1 (register set (j + 1) % PD, loaded PD steps ago) is converted WHILE
+        // those writes drain -- behind the consumers' fragment reads in the LDS queue: with convert -> write ->
+        // wait -> barrier the write latency was on every step's critical path -- the set is refilled with tile
+        // j + 1 + PD, and only then comes the wait for the writes and barrier P_j.
         int kt = 0;
-        for (; kt + PD <= n_full; kt += PD) {
+#ifdef C3_PROBE
+        unsigned long long pr_store = 0, pr_load = 0, pr_bar = 0, pr_cvt = 0, pr_ld = 0;
+        const unsigned long long pr_t0 = C3_T();
+#endif
+        for (; kt + PD < n_full; kt += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
-                store_full(kt + d, sa[d], sb[d]);
-                load_full(kt + d + PD, sa[d], sb[d]);
+#ifdef C3_PROBE
+                const unsigned long long p0 = C3_T();
+                write_tile(kt + d);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long p1 = C3_T();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * 2 * (TM + TN) / 64) : "memory");
+                const unsigned long long p1b = C3_T();
+                convert_full(sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                const unsigned long long p1c = C3_T();
+                load_full(kt + d + 1 + PD, sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                const unsigned long long p2 = C3_T();
+                __syncthreads();
+                const unsigned long long p3 = C3_T();
+                pr_store += p1 - p0; pr_load += p1b - p1; pr_bar += p3 - p2; pr_cvt += p1c - p1b; pr_ld += p2 - p1c;
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+#endif
+                write_tile(kt + d);
+                __builtin_amdgcn_sched_barrier(0);            // (the writes stay in front of the conversion)
+                convert_full(sa[(d + 1) % PD], sb[(d + 1) % PD]);
+                load_full(kt + d + 1 + PD, sa[(d + 1) % PD], sb[(d + 1) % PD]);
                 __syncthreads();
                 // (left alone the scheduler hoists the conversions of the next two tiles above this barrier
                 // and waits for ALL loads in flight at the top of the unrolled body: vmcnt(0) every 3 steps)
@@ -286,19 +345,28 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
             }
         }
 #pragma unroll
-        for (int d = 0; d < PD; ++d) {                        // the last (< PD) full tiles: kt % PD == 0 here
+        for (int d = 0; d < PD; ++d) {                        // the last (<= PD) full tiles: kt % PD == 0 here
             if (kt + d < n_full) {
-                store_full(kt + d, sa[d], sb[d]);
+                write_tile(kt + d);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + d + 1 < n_full) convert_full(sa[(d + 1) % PD], sb[(d + 1) % PD]);
                 __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (tail) {
-            char *img = c3_smem + (n_full % NSTAGE) * STAGE;
             const int k0 = k_begin + n_full * C3_BK;
-            c3_store<A_KC, TM, false>(ta, img, k0, k_end, t);
-            c3_store<B_KC, TN, false>(tb, img + 3 * PLANE_A, k0, k_end, t);
+            c3_convert<A_KC, TM, false>(ta, wa, k0, k_end, t);
+            c3_convert<B_KC, TN, false>(tb, wb, k0, k_end, t);
+            write_tile(n_full);
             __syncthreads();
         }
+#ifdef C3_PROBE
+        if (threadIdx.x == 256 && blockIdx.x < 4096 && blockIdx.z == 0) {
+            unsigned long long *o = g_c3_probe + 16 * blockIdx.x;
+            o[4] = C3_T() - pr_t0; o[5] = pr_store; o[6] = pr_load; o[7] = pr_bar; o[8] = pr_cvt; o[9] = pr_ld;
+        }
+#endif
         return;
     }
     // ==================================== consumers ==================================================
@@ -317,6 +385,98 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     const int fb = 3 * PLANE_A + (wn * WN + rr) * 64 + ((kg ^ ((rr >> 1) & 3)) << 4);
     constexpr int pa[6] = {0, 0, 1, 1, 0, 2};
     constexpr int pb[6] = {0, 1, 0, 1, 2, 0};
+    if constexpr (NI * NJ >= 16) {
+        // 64 x 64 wave tile (128 x 128 workgroup tile): 24 fragment reads feed 96 MFMAs (the 32 x 32 wave tile
+        // reads 12 for 24 and is bound by LDS traffic and by the vector issue the conversion takes next to the
+        // MFMAs: per MFMA it converts and reads twice as much).  Two fragment sets (192 registers) do not fit
+        // beside 64 accumulators, so there is ONE set, refilled piece by piece as the terms retire it: within
+        // step j (registers = tile j - 1, tile j in LDS) the terms run smallest first, as everywhere,
+        //   a3.b1 -> a3 <- tile j | a1.b3 -> b3 | a2.b2, a2.b1 -> a2 | a1.b2 -> b2 | a1.b1 column by column,
+        //   each b1 column refilled behind its four MFMAs -> a1
+        // so every read is issued at least 8 MFMAs before its first use.  The reads of tile j issued last are
+        // consumed during step j + 1, i.e. before this wave reaches P_{j+2} -- the barrier after which tile
+        // j + 3 overwrites the stage -- so the consumers' barrier carries NO wait (a bare s_barrier).
+        static_assert(NSTAGE == 3, "the late reads of a tile need its stage for one more step");
+        c3_bf16x8 af[3][NI], bf[3][NJ];
+        const char *img = c3_smem;
+        auto rd_a = [&](int q, int i) {
+            af[q][i] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_A + fa + i * 16 * 64);
+        };
+        auto rd_b = [&](int q, int j) {
+            bf[q][j] = *reinterpret_cast<const c3_bf16x8 *>(img + q * PLANE_B + fb + j * 16 * 64);
+        };
+        auto term = [&](int qa, int qb) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) c3_mfma(acc[i][j], af[qa][i], bf[qb][j]);
+        };
+        auto bare_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (n_kt > 0) {
+            bare_barrier();                                   // P_0
+#pragma unroll
+            for (int q = 2; q >= 0; --q) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) rd_a(q, i);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) rd_b(q, j);
+            }
+        }
+#ifdef C3_PROBE
+        unsigned long long co_bar = 0;
+        const unsigned long long co_t0 = C3_T();
+#endif
+        for (int kt = 1; kt < n_kt; ++kt) {
+#ifdef C3_PROBE
+            const unsigned long long c0 = C3_T();
+            bare_barrier();
+            co_bar += C3_T() - c0;
+#else
+            bare_barrier();                                   // P_kt
+#endif
+            img = c3_smem + (kt % NSTAGE) * STAGE;
+            term(2, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) rd_a(2, i);
+            __builtin_amdgcn_sched_barrier(0);
+            term(0, 2);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rd_b(2, j);
+            __builtin_amdgcn_sched_barrier(0);
+            term(1, 1);
+            term(1, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) rd_a(1, i);
+            __builtin_amdgcn_sched_barrier(0);
+            term(0, 1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rd_b(1, j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) c3_mfma(acc[i][j], af[0][i], bf[0][j]);
+                rd_b(0, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) rd_a(0, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef C3_PROBE
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.z == 0) {
+            unsigned long long *o = g_c3_probe + 16 * blockIdx.x;
+            o[0] = C3_T() - co_t0; o[1] = co_bar; o[2] = 0; o[3] = 0;
+        }
+#endif
+        if (n_kt > 0) {
+            term(2, 0); term(0, 2); term(1, 1); term(1, 0); term(0, 1); term(0, 0);
+        }
+    } else {
     // Barrier P_j: tile j is in LDS (stage j % NSTAGE).  After it the wave issues the fragment reads of tile j
     // into one register set and, while they fly, the MFMAs of tile j - 1 from the other set: the matrix pipe
     // never waits for an LDS round trip (with one set the reads of a tile sat between the barrier and its
@@ -358,6 +518,32 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     }
     kt = n_kt + 1;
 #endif
+#ifdef C3_PROBE
+    unsigned long long co_bar = 0, co_work = 0, co_wait = 0;
+    const unsigned long long co_t0 = C3_T();
+    for (; kt + 2 <= n_kt; kt += 2) {
+        const unsigned long long c0 = C3_T();
+        __syncthreads();
+        const unsigned long long c1 = C3_T();
+        read_frags(kt, S0{});
+        if (kt > 0) multiply(S1{});
+        const unsigned long long c2 = C3_T();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const unsigned long long c3 = C3_T();
+        __syncthreads();
+        const unsigned long long c4 = C3_T();
+        read_frags(kt + 1, S1{});
+        multiply(S0{});
+        const unsigned long long c5 = C3_T();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const unsigned long long c6 = C3_T();
+        co_bar += (c1 - c0) + (c4 - c3); co_work += (c2 - c1) + (c5 - c4); co_wait += (c3 - c2) + (c6 - c5);
+    }
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.z == 0) {
+        unsigned long long *o = g_c3_probe + 16 * blockIdx.x;
+        o[0] = C3_T() - co_t0; o[1] = co_bar; o[2] = co_work; o[3] = co_wait;
+    }
+#endif
     for (; kt + 2 <= n_kt; kt += 2) {
         __syncthreads();                                      // P_kt
         read_frags(kt, S0{});
@@ -385,6 +571,7 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     }
 #endif
 
+    }
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
     const bool add_bias = g.bias != nullptr && g.split_stride == 0;
@@ -446,10 +633,18 @@ static int b3c_launch(const char *name, C3Args &g, int splits, hipStream_t st) {
 static void b3c_choice(int64_t m, int64_t n, int64_t k, int *tm, int *tn, int *splits) {
     const int t_tile = (int)tune(GIST_TUNE_GEMM_TILE), t_split = (int)tune(GIST_TUNE_GEMM_SPLITS);
     auto tiles = [&](int a, int b) { return ceil_div(m, a) * ceil_div(n, b); };
-    // (no 128 x 128: two fragment sets of a 64 x 64 wave tile do not fit the register file; 128 x 64 measured
-    // slower than 64 x 64 on every per-rank shape -- two workgroups per CU matter more than the tile)
+    // 64 x 64 unless the output has 256 tiles of 128 x 128 (measured: NN 2046 x 2048 x 1024 62 -> 54 us; with fewer
+    // tiles the 128 x 128 grid leaves CUs idle or needs k slices and loses: NT 2046 x 1024 x 2048 59 vs 82 / 60 with
+    // 1 / 2 slices; 128 x 64 is slower than 64 x 64 on every per-rank shape).  A k step of the 128 x 128 tile takes
+    // ~2700 cycles for 1536 of MFMA, one of the 64 x 64 tile ~1200 for 384: the producers' step (176 / 88 vector
+    // instructions, 12 / 6 ds_write_b128 at ~13 issue cycles, 8 / 4 loads) sets the pace in both, and neither deeper
+    // load prefetch (PD 4-6), nor LDS writes issued before the conversion, nor cheaper instructions (v_perm for
+    // v_cvt_pk, v_sub for v_pk_add), nor half as many MFMA issues (32 x 32 x 16) moved it (scripts/b3c_probe.py).
     *tm = 64; *tn = 64;
+    if (tiles(128, 128) >= 256) { *tm = 128; *tn = 128; }
+    if (t_tile == 64) { *tm = 64; *tn = 64; }
     if (t_tile == 128 || t_tile == 12864) { *tm = 128; *tn = 64; }
+    if (t_tile == 128128) { *tm = 128; *tn = 128; }
     const int64_t wgs = tiles(*tm, *tn);
     const int64_t kt = ceil_div(k, C3_BK);
     int64_t sp = 1;
@@ -490,7 +685,8 @@ int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda
     int rc;
 #define C3_GO(AK, BK_)                                                                        \
     rc = tm == 64 ? b3c_launch<AK, BK_, 64, 64>(name, g, splits, st)                          \
-                  : b3c_launch<AK, BK_, 128, 64>(name, g, splits, st)
+         : tn == 64 ? b3c_launch<AK, BK_, 128, 64>(name, g, splits, st)                       \
+                    : b3c_launch<AK, BK_, 128, 128>(name, g, splits, st)
     if (a_kc && b_kc) { C3_GO(true, true); }
     else if (a_kc) { C3_GO(true, false); }
     else { C3_GO(false, false); }
@@ -504,3 +700,10 @@ int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda
 }
 
 }  // namespace gist
+
+#ifdef C3_PROBE
+extern "C" int gist_c3_probe_read(unsigned long long *out, int64_t n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gist::g_c3_probe), n_blocks * 16 * sizeof(unsigned long long)) ==
+                   hipSuccess ? 0 : -1;
+}
+#endif

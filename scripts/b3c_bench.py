@@ -8,7 +8,8 @@ from gist_amd import hip
 dev = 'cuda:0'
 SH = [('nt', 2046, 1024, 1204), ('nt', 2046, 1024, 2048), ('nn', 2046, 2048, 1024), ('tn', 1024, 2048, 2046),
       ('tn', 1024, 1204, 2046), ('nt', 2046, 512, 1204), ('nt', 2046, 512, 1024), ('nn', 2046, 1024, 512),
-      ('tn', 512, 1024, 2046), ('tn', 512, 1204, 2046)]
+      ('tn', 512, 1024, 2046), ('tn', 512, 1204, 2046), ('nt', 2046, 2048, 4096), ('nn', 2046, 4096, 2048),
+      ('nt', 2046, 4096, 8192)]
 
 
 def run(form, a, b, c):

@@ -146,3 +146,29 @@ def test_b3c_deferred_slabs(hip):
     for s in range(ns):
         acc = acc + slabs[s * m * n:(s + 1) * m * n]
     assert torch.equal(acc.view(m, n), ref)
+
+
+@pytest.mark.parametrize('form,m,n,k', [('nt', 2046, 1024, 2048), ('nn', 2046, 1024, 512), ('tn', 512, 1204, 2046),
+                                        ('nt', 333, 130, 100), ('nn', 77, 68, 72), ('tn', 68, 200, 333),
+                                        ('nt', 530, 300, 812), ('nt', 129, 257, 96)])
+@pytest.mark.parametrize('splits', [1, 3])
+def test_b3c_tiles_agree_bit_for_bit(hip, form, m, n, k, splits):
+    """The 128 x 128 tile (one fragment set refilled piece by piece, bare barriers), the 128 x 64 and the 64 x 64
+    tile (two fragment sets) give every output element the same MFMAs in the same order: equal bits, for one
+    k slice and for the same number of slices."""
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(11 * m + n + k)
+    a, w = _operands(form, m, n, k, gen, 'normal')
+    bias = torch.randn(n, device=DEV, generator=gen) if form == 'nt' else None
+    out = {}
+    hip.tuning('gemm_splits', splits)
+    try:
+        for tile in (64, 128, 128128):
+            hip.tuning('gemm_tile', tile)
+            out[tile] = _run(hip, form, a, w, bias, m, n)
+    finally:
+        hip.tuning('gemm_tile', 0)
+        hip.tuning('gemm_splits', 0)
+    assert torch.isfinite(out[64]).all()
+    assert torch.equal(out[64], out[128])
+    assert torch.equal(out[64], out[128128])
