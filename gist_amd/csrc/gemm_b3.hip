@@ -427,6 +427,18 @@ int b3_splits(int64_t m, int64_t n, int64_t k) {
     const int64_t n_kt = b3_kpad(k) / B3_BK;
     const int forced = (int)tune(GIST_TUNE_GEMM_SPLITS);
     int64_t s = forced > 0 ? forced : (tiles >= 192 ? 1 : 256 / tiles);
+    if (forced <= 0 && tiles > 128 && tiles < 192) {
+        // between half a chip and 3/4 of one (dW_0 of the H = 4096 step: 160 tiles) one slice runs a single
+        // under-full round; the slice count that minimises rounds x k tiles per slice wins even with the
+        // slab sum (4096 x 1204 x 2046: 3 slices = 2 rounds of 22 k tiles against 1 of 64; 165 -> 154 us
+        // per call with the sum in the call, scripts/b3_split_probe.py)
+        int64_t best = n_kt + 4;      // one slice: no slabs (the +4: a slab sum costs about 4 k tiles)
+        for (int64_t c = 2; c <= 4; ++c) {
+            const int64_t per = ceil_div(ceil_div(n_kt, c), 2) * 2;
+            const int64_t cost = ceil_div(tiles * c, 256) * per + 8;
+            if (per >= 8 && cost < best) { best = cost; s = c; }
+        }
+    }
     if (forced <= 0 && s > n_kt / 8) s = n_kt / 8;
     if (s > n_kt / 2) s = n_kt / 2;
     if (s < 1) s = 1;
@@ -484,7 +496,7 @@ int b3_dual_split(const B3Dual &d, hipStream_t st) {
 
 int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
                      int64_t ldc, int64_t m, int64_t n, int64_t k, float *slabs, int64_t slab_bytes,
-                     hipStream_t st) {
+                     hipStream_t st, int *deferred) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
@@ -517,7 +529,9 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
     hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits),
                        dim3(B3_THREADS), B3_STAGES * B3_BUF_BYTES, st, g);
     int rc = launch_status(name);
-    if (rc == GIST_OK && splits > 1) rc = splitk_reduce(name, slabs, m * n, splits, bias, c, ldc, m, n, st);
+    // deferred: the caller's consumer sums the slabs (slab s at slabs + s m n, in slab order); bias must be null
+    if (deferred) *deferred = splits;
+    else if (rc == GIST_OK && splits > 1) rc = splitk_reduce(name, slabs, m * n, splits, bias, c, ldc, m, n, st);
     timer_end(tl_timer, slot, st);
     return rc;
 }
@@ -545,7 +559,7 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
     if (rc != GIST_OK) return rc;
     rc = split(b_kc, b, ldb, n, sb);
     if (rc != GIST_OK) return rc;
-    rc = b3_gemm_presplit(name, sa, sb, bias, c, ldc, m, n, k, slabs, b3_slab_bytes(m, n, k), st);
+    rc = b3_gemm_presplit(name, sa, sb, bias, c, ldc, m, n, k, slabs, b3_slab_bytes(m, n, k), st, nullptr);
     return rc == GIST_OK ? 1 : rc;
 }
 

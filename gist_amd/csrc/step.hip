@@ -642,8 +642,17 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
             {
                 Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
+                // the step's LAST projection may leave its k slices to the optimiser (the slab scratch is not
+                // reused before it runs)
+                int ns = 1;
                 GIST_TRY(b3_gemm_presplit("gist_sage_step", b3.dYsT, hl.ZsT, nullptr, l.dW, 2 * l.n_in,
-                                          l.n_out, 2 * l.n_in, n, b3.slabs, b3.slab_bytes, st));
+                                          l.n_out, 2 * l.n_in, n, b3.slabs, b3.slab_bytes, st,
+                                          defer && k == 0 ? &ns : nullptr));
+                if (ns > 1) {
+                    gist_grad_segment &g = segs[n_segs++];
+                    g.begin = l.dW - p->grads; g.end = g.begin + l.n_out * 2 * l.n_in;
+                    g.src = b3.slabs; g.stride = l.n_out * 2 * l.n_in; g.n_src = ns;
+                }
             }
             if (k > 0) {
                 if (drop)
