@@ -347,15 +347,12 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
         bslot[ni] = ((n & 3) * 36 + (n >> 2)) * 16;
     }
     // the rows this wave finishes: pairs (one per half wave), row = wave + 16 (2 p + half)
+    // (their outside-neighbour counts and out scales are re-read from LDS in every tile's epilogue.  Kept as
+    // two 8-element arrays from the set-up on, the scale of a lane's row was `half ? rsc[2 p + 1] : rsc[2 p]`,
+    // which the compiler turned into an indexed load from a PRIVATE array: 40 B per lane stored to scratch at
+    // set-up and re-loaded from memory in every epilogue -- the 9.8 MB by which WRITE_SIZE exceeded the
+    // 33.5 MB output in the round-2 profile)
     constexpr int RW = MF_ROWS / MF_WAVES;
-    int rcnt[RW];
-    float rsc[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int r = wave + MF_WAVES * i;
-        rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
-        rsc[i] = r < nloc ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc[r]))) : 0.f;
-    }
     int mf_it = 0;
     for (; ct < a.n_col_tiles; ct += a.groups, ++mf_it) {
         MF_STAMP(8 + 8 * mf_it);
@@ -448,6 +445,19 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
         MF_STAMP(13 + 8 * mf_it);
 
         // ---- per row: + neighbours outside the block, x out_scale (+ y), store; two rows per pass ----
+        // (row offsets inside the block in 32 bits, launcher-checked: as 64-bit products hoisted out of the tile
+        // loop they were spilled to scratch)
+        float *yblk = a.y + (int64_t)r0 * a.ldy;
+        const int ldy32 = (int)a.ldy;
+        int rcnt[RW];
+        float rsc[RW / 2];                                 // this lane's rows: wave + 16 (2 p + half)
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int r = wave + MF_WAVES * i;
+            rcnt[i] = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
+        }
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp) rsc[pp] = sc[min(wave + MF_WAVES * (2 * pp + half), MF_ROWS - 1)];
         float4 v[RW / 2], yold[RW / 2];
 #pragma unroll
         for (int pp = 0; pp < RW / 2; ++pp) yold[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
 #pragma unroll
             for (int pp = 0; pp < RW / 2; ++pp)
                 yold[pp] = *reinterpret_cast<const float4 *>(
-                    a.y + (int64_t)(r0 + min(wave + MF_WAVES * (2 * pp + half), nloc - 1)) * a.ldy + (colok ? gc : 0));
+                    yblk + (uint32_t)(min(wave + MF_WAVES * (2 * pp + half), nloc - 1) * ldy32 + (colok ? gc : 0)));
         }
 #pragma unroll
         for (int pp = 0; pp < RW / 2; ++pp)
@@ -482,9 +492,9 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
                 }
             }
             const int r = wave + MF_WAVES * (2 * pp + half);
-            const float s = half ? rsc[2 * pp + 1] : rsc[2 * pp];
+            const float s = rsc[pp];
             if (colok && r < nloc)
-                *reinterpret_cast<float4 *>(a.y + (int64_t)(r0 + r) * a.ldy + gc) =
+                *reinterpret_cast<float4 *>(yblk + (uint32_t)(r * ldy32 + gc)) =
                     make_float4(fmaf(s, v[pp].x, yold[pp].x), fmaf(s, v[pp].y, yold[pp].y),
                                 fmaf(s, v[pp].z, yold[pp].z), fmaf(s, v[pp].w, yold[pp].w));
         }
@@ -573,6 +583,8 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
                      int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
                      int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
                      hipStream_t st) {
+    GIST_REQUIRE(ldy < (1LL << 22) && ldx < (1LL << 22) && d < (1LL << 22),
+                 "gist_spmm_csr_blocked_f32: row pitch of 2^22 floats or more");       // 32-bit offsets inside a block
     MfArgs a;
     a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
     a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
