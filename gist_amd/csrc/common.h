@@ -113,15 +113,44 @@ struct SpmmDrop {
 };
 int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y, int64_t ldy,
               int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale, int accumulate,
-              const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st);
+              const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st,
+              const void *prepared = nullptr);
 bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
                      const int32_t *row_blocks);
+#ifdef __HIPCC__
+// gist_dropout_f32's keep/scale factor of element idx, of VEC consecutive elements, of an aligned quad
+__device__ __forceinline__ float drop_keep(uint64_t idx, uint64_t sm, float p, float scale) {
+    const uint64_t h = splitmix64((idx >> 1) + sm);
+    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
+    return ((float)(w >> 8) * (1.0f / 16777216.0f) >= p) ? scale : 0.f;
+}
+template <int VEC>
+__device__ __forceinline__ void drop_vec(float (&v)[VEC], uint64_t idx0, const SpmmDrop &dr) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] *= drop_keep(idx0 + k, dr.sm, dr.p, dr.scale);
+}
+__device__ __forceinline__ void drop_f4(float4 &v, uint64_t idx0, const SpmmDrop &dr) {
+    const float inv = 1.0f / 16777216.0f;
+    if ((idx0 & 1) == 0) {                 // the usual case: two hashes cover the quad
+        const uint64_t pair = idx0 >> 1;
+        const uint64_t h0 = splitmix64(pair + dr.sm), h1 = splitmix64(pair + 1 + dr.sm);
+        v.x *= ((float)((uint32_t)h0 >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+        v.y *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+        v.z *= ((float)((uint32_t)h1 >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+        v.w *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv >= dr.p) ? dr.scale : 0.f;
+    } else {
+        v.x *= drop_keep(idx0, dr.sm, dr.p, dr.scale); v.y *= drop_keep(idx0 + 1, dr.sm, dr.p, dr.scale);
+        v.z *= drop_keep(idx0 + 2, dr.sm, dr.p, dr.scale); v.w *= drop_keep(idx0 + 3, dr.sm, dr.p, dr.scale);
+    }
+}
+
+#endif
 // spmm_mfma.hip: the block-dense aggregation kernel behind gist_spmm_csr_blocked_f32 / _prepared_f32
 // (prepared = NULL: every workgroup builds its block's counts itself)
 int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
                      int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
                      int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
-                     hipStream_t st);
+                     hipStream_t st, const SpmmDrop *dr = nullptr);
 int64_t spmm_blocks_bytes(int64_t n_blocks);
 bool spmm_prepared_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);   // spmm.hip
 int launch_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, const int32_t *rowptr2,

@@ -53,31 +53,7 @@ constexpr int kSpmmWavesPerBlock = 4;
 //   mode 1 (forward):  what the aggregation stores to y is multiplied by y's mask;
 //   mode 2 (backward): x is read through its mask (base = src_base) and the old y of the `y +=` through
 //                      y's -- the aggregation of a gradient whose dropout pass has not run.
-__device__ __forceinline__ float drop_keep(uint64_t idx, uint64_t sm, float p, float scale) {
-    const uint64_t h = splitmix64((idx >> 1) + sm);
-    const uint32_t w = (idx & 1) ? (uint32_t)(h >> 32) : (uint32_t)h;
-    return ((float)(w >> 8) * (1.0f / 16777216.0f) >= p) ? scale : 0.f;
-}
-template <int VEC>
-__device__ __forceinline__ void drop_vec(float (&v)[VEC], uint64_t idx0, const SpmmDrop &dr) {
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) v[k] *= drop_keep(idx0 + k, dr.sm, dr.p, dr.scale);
-}
-__device__ __forceinline__ void drop_f4(float4 &v, uint64_t idx0, const SpmmDrop &dr) {
-    const float inv = 1.0f / 16777216.0f;
-    if ((idx0 & 1) == 0) {                 // the usual case: two hashes cover the quad
-        const uint64_t pair = idx0 >> 1;
-        const uint64_t h0 = splitmix64(pair + dr.sm), h1 = splitmix64(pair + 1 + dr.sm);
-        v.x *= ((float)((uint32_t)h0 >> 8) * inv >= dr.p) ? dr.scale : 0.f;
-        v.y *= ((float)((uint32_t)(h0 >> 32) >> 8) * inv >= dr.p) ? dr.scale : 0.f;
-        v.z *= ((float)((uint32_t)h1 >> 8) * inv >= dr.p) ? dr.scale : 0.f;
-        v.w *= ((float)((uint32_t)(h1 >> 32) >> 8) * inv >= dr.p) ? dr.scale : 0.f;
-    } else {
-        v.x *= drop_keep(idx0, dr.sm, dr.p, dr.scale); v.y *= drop_keep(idx0 + 1, dr.sm, dr.p, dr.scale);
-        v.z *= drop_keep(idx0 + 2, dr.sm, dr.p, dr.scale); v.w *= drop_keep(idx0 + 3, dr.sm, dr.p, dr.scale);
-    }
-}
-
+// (drop_keep / drop_vec / drop_f4: common.h -- the matrix-core kernel of spmm_mfma.hip applies the same masks)
 template <int VEC, int LPR, bool DROP = false>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -842,21 +818,26 @@ static bool lds2_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, cons
     return d >= 128 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y);
 }
 
-// Which calls can carry the dropout mask themselves: forward (mode 1) every kernel but the matrix-core
-// one; backward (mode 2) the LDS-staged kernel only (it reads every source element once).
+// Which calls can carry the dropout mask themselves: forward (mode 1) every kernel; backward (mode 2) the
+// LDS-staged kernel only (it reads every source element of a block once; the row-split kernels would hash every
+// gathered element, and on the matrix-core kernel the hashes in the tile conversion cost more than the pass:
+// spmm_mfma.hip).
+static bool mfma_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
+                       const int32_t *row_blocks) {
+    const int forced = (int)tune(GIST_TUNE_SPMM_KERNEL);
+    return row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y) && forced != 1 && (d >= 1536 || forced == 2);
+}
 bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
                      const int32_t *row_blocks) {
-    const bool mfma = row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y) && d >= 1536 &&
-                      (int)tune(GIST_TUNE_SPMM_KERNEL) != 1;
-    if ((int)tune(GIST_TUNE_SPMM_KERNEL) == 2 && lds2_takes(d, ldx, ldy, x, y)) return false;
-    if (mode == 1) return !mfma;
-    if (mode == 2) return row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y) && !mfma;
+    if (mode == 1) return true;
+    if (mode == 2) return row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y) && !mfma_takes(d, ldx, ldy, x, y, row_blocks);
     return false;
 }
 
 int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y, int64_t ldy,
               int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale, int accumulate,
-              const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st) {
+              const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st,
+              const void *prepared) {
     GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_spmm_csr_drop_f32: negative size");
     if (n_rows == 0 || d == 0) return GIST_OK;
     GIST_REQUIRE(rowptr && x && y, "gist_spmm_csr_drop_f32: null pointer");
@@ -866,6 +847,9 @@ int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t
     GIST_REQUIRE(dr.p >= 0.f && dr.p < 1.f && dr.ld >= d, "gist_spmm_csr_drop_f32: bad mask description");
     GIST_REQUIRE(spmm_drop_takes(dr.mode, d, ldx, ldy, x, y, row_blocks),
                  "gist_spmm_csr_drop_f32: this shape cannot carry the mask (use gist_dropout_f32)");
+    if (mfma_takes(d, ldx, ldy, x, y, row_blocks))
+        return launch_spmm_mfma(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
+                                row_blocks, n_row_blocks, prepared, st, &dr);
     if (row_blocks != nullptr && lds2_takes(d, ldx, ldy, x, y))
         return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
                                 row_blocks, n_row_blocks, st, &dr);

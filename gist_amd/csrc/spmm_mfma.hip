@@ -84,6 +84,7 @@ struct MfArgs {
     const int32_t *row_blocks;
     int n_blocks, n_col_tiles, groups;
     const unsigned char *prep;       // prepared blocks (spmm_blocks_prepare_kernel) or NULL
+    SpmmDrop dr;                     // dropout masks folded in (kernel template DROP = dr.mode)
 };
 
 __device__ __forceinline__ uint32_t mf_pack(__bf16 lo, __bf16 hi) {
@@ -263,7 +264,12 @@ __device__ __forceinline__ void mf_build_block(const MfArgs &a, int r0, int nloc
     mf_barrier();
 }
 
-template <bool PREP>
+// DROP = 1 (gist_spmm_csr_drop_f32, forward form): what is stored is multiplied by y's dropout mask (+4 us per
+// D = 4096 launch for the 22-us pass it replaces).  The backward form (x read through its mask in the tile
+// conversion, the old y through y's) was built and measured on this kernel: bit-identical, 103 us against
+// 35 + 22 -- eight more 64-bit hashes per thread in the vector-bound conversion and 144 B per lane of spills at
+// 128 registers; it stays a separate pass in front of this kernel.
+template <bool PREP, int DROP = 0>
 __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
     MF_STAMP(0);
@@ -353,6 +359,9 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     // set-up and re-loaded from memory in every epilogue -- the 9.8 MB by which WRITE_SIZE exceeded the
     // 33.5 MB output in the round-2 profile)
     constexpr int RW = MF_ROWS / MF_WAVES;
+    // mask index of an element = a uniform 64-bit block base + a 32-bit in-block offset (DROP only)
+    const uint64_t dyb = a.dr.y_base + (uint64_t)r0 * (uint64_t)a.dr.ld;
+    const int dld = (int)a.dr.ld;
     int mf_it = 0;
     for (; ct < a.n_col_tiles; ct += a.groups, ++mf_it) {
         MF_STAMP(8 + 8 * mf_it);
@@ -493,10 +502,16 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
             }
             const int r = wave + MF_WAVES * (2 * pp + half);
             const float s = rsc[pp];
-            if (colok && r < nloc)
-                *reinterpret_cast<float4 *>(yblk + (uint32_t)(r * ldy32 + gc)) =
-                    make_float4(fmaf(s, v[pp].x, yold[pp].x), fmaf(s, v[pp].y, yold[pp].y),
-                                fmaf(s, v[pp].z, yold[pp].z), fmaf(s, v[pp].w, yold[pp].w));
+            if (colok && r < nloc) {
+                float4 o = make_float4(fmaf(s, v[pp].x, yold[pp].x), fmaf(s, v[pp].y, yold[pp].y),
+                                       fmaf(s, v[pp].z, yold[pp].z), fmaf(s, v[pp].w, yold[pp].w));
+                if constexpr (DROP == 1) {
+                    int rv_ = r;                       // (opaque: hoisted out of the tile loop, the four row
+                    asm volatile("" : "+v"(rv_));      // products r * dld were spilled to scratch)
+                    drop_f4(o, dyb + (uint32_t)(rv_ * dld + gc), a.dr);
+                }
+                *reinterpret_cast<float4 *>(yblk + (uint32_t)(r * ldy32 + gc)) = o;
+            }
         }
         // rows of an oversized block beyond the 128 staged ones: gathered in full, two rows per pass
         for (int rb = MF_ROWS + 2 * wave; rb < nrow; rb += 2 * MF_WAVES) {
@@ -509,11 +524,13 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
             const int r = rb + half;
             if (colok && r < nrow) {
                 float *yp = a.y + (int64_t)(r0 + r) * a.ldy + gc;
+                const uint64_t yi = a.dr.y_base + (uint64_t)(r0 + r) * (uint64_t)a.dr.ld + (uint64_t)gc;
                 float4 yo = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.accumulate) yo = *reinterpret_cast<const float4 *>(yp);
                 const float s = a.out_scale ? a.out_scale[r0 + r] : 1.f;
-                *reinterpret_cast<float4 *>(yp) = make_float4(fmaf(s, vo.x, yo.x), fmaf(s, vo.y, yo.y),
-                                                              fmaf(s, vo.z, yo.z), fmaf(s, vo.w, yo.w));
+                float4 o = make_float4(fmaf(s, vo.x, yo.x), fmaf(s, vo.y, yo.y), fmaf(s, vo.z, yo.z), fmaf(s, vo.w, yo.w));
+                if constexpr (DROP == 1) drop_f4(o, yi, a.dr);
+                *reinterpret_cast<float4 *>(yp) = o;
             }
         }
         MF_STAMP(15 + 8 * mf_it);
@@ -582,7 +599,7 @@ int launch_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, const 
 int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
                      int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
                      int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
-                     hipStream_t st) {
+                     hipStream_t st, const SpmmDrop *dr) {
     GIST_REQUIRE(ldy < (1LL << 22) && ldx < (1LL << 22) && d < (1LL << 22),
                  "gist_spmm_csr_blocked_f32: row pitch of 2^22 floats or more");       // 32-bit offsets inside a block
     MfArgs a;
@@ -590,6 +607,10 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
     a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
     a.accumulate = accumulate; a.row_blocks = row_blocks;
     a.prep = static_cast<const unsigned char *>(prepared);
+    a.dr = dr ? *dr : SpmmDrop{};
+    GIST_REQUIRE(a.dr.ld < (1LL << 22), "gist_spmm_csr_drop_f32: mask pitch of 2^22 elements or more");
+    const int mode = dr ? dr->mode : 0;
+    GIST_REQUIRE(mode == 0 || mode == 1, "gist_spmm_csr_drop_f32: the matrix-core kernel carries the forward mask only");
     const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, MF_ROWS);
     a.n_blocks = (int)nb;
     a.n_col_tiles = (int)ceil_div(d, MF_CT);
@@ -604,16 +625,24 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<false>), "gist_spmm_csr_blocked_f32");
-        if (rc == GIST_OK)
-            rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true>), "gist_spmm_csr_blocked_f32");
-        if (rc != GIST_OK) return rc;
+        const void *ks[4] = {reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<false, 0>),
+                             reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true, 0>),
+                             reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<false, 1>),
+                             reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true, 1>)};
+        for (const void *k : ks) {
+            const int rc = mf_set_lds(k, "gist_spmm_csr_blocked_f32");
+            if (rc != GIST_OK) return rc;
+        }
         once.done(dev);
     }
-    if (prepared)
-        hipLaunchKernelGGL(spmm_csr_mfma_kernel<true>, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-    else
-        hipLaunchKernelGGL(spmm_csr_mfma_kernel<false>, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+#define MF_GO(P, D)                                                                                             \
+    hipLaunchKernelGGL((spmm_csr_mfma_kernel<P, D>), dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a)
+    if (prepared) {
+        if (mode == 1) MF_GO(true, 1); else MF_GO(true, 0);
+    } else {
+        if (mode == 1) MF_GO(false, 1); else MF_GO(false, 0);
+    }
+#undef MF_GO
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 

@@ -396,6 +396,15 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     }
     const float keep = drop ? 1.0f / (1.0f - p->p_drop) : 1.f;
     const uint64_t sm = p->seed * 0x9E3779B97F4A7C15ULL;
+    // layers on split operands (their dZ comes from a split projection, unmasked): can the reverse aggregation
+    // carry dZ_k's mask instead of a dropout pass over dZ_k?
+    bool bwd_fold_split[GIST_MAX_LAYERS];
+    for (int k = 0; k < L1; ++k) {
+        const gist_layer_desc &l = p->layer[k];
+        bwd_fold_split[k] = fuse && drop && !plain[k] && k > 0 && k < L1 - 1 && (offs[k] & 1) == 0 &&
+                            spmm_drop_takes(2, l.n_in, 2 * l.n_in, 2 * l.n_in, p->dZ + l.n_in, p->dZ,
+                                            blocked ? p->row_blocks : nullptr);
+    }
 
     if (b3.any) {      // this step's weights, one read each
         Scope sc(p->timer, 3, 0, 0, 0, st);
@@ -491,7 +500,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                 dr.mode = 1; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
                 dr.y_base = offs[k] + (uint64_t)l.n_in; dr.src_base = 0; dr.ld = 2 * l.n_in;
                 GIST_TRY(spmm_drop(p->rowptr, p->col, p->hsrc[k], p->ld_hsrc[k], l.Z + l.n_in, l.ldz, n, l.n_in,
-                                   p->norm, nullptr, 0, blocked ? p->row_blocks : nullptr, p->n_row_blocks, dr, st));
+                                   p->norm, nullptr, 0, blocked ? p->row_blocks : nullptr, p->n_row_blocks, dr, st,
+                                   prep_fwd));
             } else {
                 GIST_TRY(step_spmm(p, p->rowptr, p->col, l.Z, l.ldz, l.Z + l.n_in, l.ldz, n, l.n_in,
                                    p->norm, nullptr, 0, prep_fwd, s));
@@ -613,12 +623,21 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                           nullptr, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in, n, st));
             }
             if (k > 0) {
-                if (drop)
-                    GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
-                                              offs[k], s));
-                Scope sc(p->timer, 0, n, n, l.n_in, st);
-                GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
+                if (bwd_fold_split[k]) {
+                    Scope sc(p->timer, 0, n, n, l.n_in, st);
+                    SpmmDrop dr{};
+                    dr.mode = 2; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
+                    dr.y_base = offs[k]; dr.src_base = offs[k] + (uint64_t)l.n_in; dr.ld = 2 * l.n_in;
+                    GIST_TRY(spmm_drop(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
+                                       l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st, prep_bwd));
+                } else {
+                    if (drop)
+                        GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
+                                                  offs[k], s));
+                    Scope sc(p->timer, 0, n, n, l.n_in, st);
+                    GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                       2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
+                }
             }
             continue;
         }
@@ -655,12 +674,21 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                 }
             }
             if (k > 0) {
-                if (drop)
-                    GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
-                                              offs[k], s));
-                Scope sc(p->timer, 0, n, n, l.n_in, st);
-                GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
-                                   2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
+                if (bwd_fold_split[k]) {
+                    Scope sc(p->timer, 0, n, n, l.n_in, st);
+                    SpmmDrop dr{};
+                    dr.mode = 2; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
+                    dr.y_base = offs[k]; dr.src_base = offs[k] + (uint64_t)l.n_in; dr.ld = 2 * l.n_in;
+                    GIST_TRY(spmm_drop(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
+                                       l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st, prep_bwd));
+                } else {
+                    if (drop)
+                        GIST_TRY(gist_dropout_f32(p->dZ, 2 * l.n_in, n, 2 * l.n_in, p->p_drop, p->seed,
+                                                  offs[k], s));
+                    Scope sc(p->timer, 0, n, n, l.n_in, st);
+                    GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
+                                       2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
+                }
             }
             continue;
         }
@@ -703,7 +731,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                 dr.mode = 2; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
                 dr.y_base = offs[k]; dr.src_base = offs[k] + (uint64_t)l.n_in; dr.ld = 2 * l.n_in;
                 GIST_TRY(spmm_drop(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
-                                   l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st));
+                                   l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st, prep_bwd));
             } else {
                 GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
                                    2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));

@@ -47,7 +47,8 @@ def block_graph(n, n_blocks, deg_in, deg_out, seed, hub=0):
 
 
 @pytest.mark.parametrize('n,d,blocks', [(700, 512, True), (700, 512, False), (300, 602, False), (300, 602, True),
-                                        (257, 100, True), (130, 41, False), (900, 1024, True), (200, 7, False)])
+                                        (257, 100, True), (130, 41, False), (900, 1024, True), (200, 7, False),
+                                        (700, 2048, True), (1100, 4096, True)])      # (the matrix-core kernel)
 def test_spmm_forward_mask_equals_dropout_after(hip, n, d, blocks):
     """mode 1: y = dropout(aggregate(x)) from the aggregation's own store == the plain aggregation
     followed by gist_dropout_f32 on y's columns of the wider tensor, on every kernel that takes it."""
