@@ -47,7 +47,7 @@ done
 echo config kstats done
 fi
 if [ $part = all ] || [ $part = c ]; then
-python3 $R/scripts/b3c_bench.py 0 0 64 1 64 2 128 1 128 2 > $O/b3c_bench.log 2>&1 || exit 1
+python3 $R/scripts/b3c_bench.py 0 0 64 1 64 2 128 1 128128 1 128128 2 > $O/b3c_bench.log 2>&1 || exit 1
 python3 $R/scripts/eval_bench.py > $O/eval.log 2>&1 || exit 1
 grep '^{' $O/eval.log | tail -1 | cut -c1-200
 for c in FETCH_SIZE WRITE_SIZE; do

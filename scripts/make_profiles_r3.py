@@ -19,13 +19,26 @@ def clean(path):
 
 
 # 1. bench lines: the default workload, the per-rank widths, one line per BASELINE config
+other = []
+for i in (1, 2):
+    f = os.path.join(F, 'bench_n1_box%d.log' % i)
+    if os.path.exists(f):
+        d = last_json(f)
+        other.append({k: d[k] for k in ('value', 'ms_per_step')} | {'gemm_b3_avg_launch_ms': d['roofline']['avg_launch_ms'],
+                                                                    'roofline_frac': d['roofline']['frac'],
+                                                                    'f32_mfma_ms_per_step': d['f32_mfma']['ms_per_step'],
+                                                                    'f16x3_split_ms_per_step': d['f16x3_split']['ms_per_step']})
 lines = {'bench_n1': last_json(os.path.join(F, 'bench_n1.log')),
+         'bench_n1_same_command_other_boxes': other,
          'per_rank_width_emulation': {('n_hidden_%d' % h): last_json(os.path.join(F, 'bench_h%d.log' % h))
                                       for h in (2048, 1024, 512)},
          'baseline_configs': {'config_2': last_json(os.path.join(F, 'bench_cfg2.log')),
                               'config_4_one_rank_of_8': last_json(os.path.join(F, 'bench_cfg4.log')),
                               'config_5_one_rank_of_8_plus_exchange': last_json(os.path.join(F, 'bench_cfg5.log'))},
-         'note': 'bench.py on 1x MI355X, round 3.  bench_n1 = the default invocation (BASELINE config 3 at N = 1: '
+         'note': 'bench.py on 1x MI355X, round 3, final code.  Every gpurun call lands on another box and the bf16-MFMA-bound kernels follow the '
+                 'box (power / clock): the default invocation measured 2.63-2.73 ms/step over six boxes this round; bench_n1 is the run the '
+                 'kernel statistics and PMC passes of profiles/r03_* were taken with (the slowest of them), bench_n1_same_command_other_boxes two '
+                 'more.  bench_n1 = the default invocation (BASELINE config 3 at N = 1: '
                  'Reddit-like, H = 4096, L = 2, GEMM mode bf16x3); `f32_mfma` / `f16x3_split` = the same workload '
                  're-timed in the other GEMM modes, same process.  per_rank_width_emulation: `bench.py --n-hidden H/N '
                  '--steps 300 --warmup 20` = the per-rank work of the N = 2/4/8 points of config 3 on one GPU (no '
@@ -150,10 +163,12 @@ for mode, sub in (('bf16x3', 'pmc_mfma_bf16x3'), ('f32', 'pmc_mfma_f32')):
 open(os.path.join(P, TAG + '_pmc_mfma.md'), 'w').write('\n'.join(md) + '\n')
 
 # 5. micro-benchmarks
-hdr = ('# scripts/b3c_bench.py 0 0 64 1 64 2 128 1 128 2 on MI355X: the convert-on-load bf16x3 GEMM (gemm_b3c.hip) vs the '
-       'fp32 kernel,\n# standalone calls (us; a call that splits k includes its reduce pass).  "default/default" = the '
-       'library\'s dispatch (NT / NN from 2 GFLOP\n# with >= 256 tiles on gemm_b3c_kernel 64 x 64, TN on the fp32 kernel); '
-       'tile/splits columns force gemm_b3c_kernel (tuning hook b3c = 2)\n# with that tile (128 = 128 x 64) and k-slice count.\n')
+hdr = ('# scripts/b3c_bench.py 0 0 64 1 64 2 128 1 128128 1 128128 2 on MI355X: the convert-on-load bf16x3 GEMM (gemm_b3c.hip) vs the\n'
+       '# fp32 kernel, standalone calls (us; a call that splits k includes its reduce pass).  "default/default" = the library\'s dispatch\n'
+       '# (NT / NN from 2 GFLOP with >= 256 tiles of 64 x 64 on gemm_b3c_kernel -- 128 x 128 tiles where the output has 256 of them --, TN on the\n'
+       '# fp32 kernel, >= 9-16 GFLOP on the pre-split kernel gemm_b3 incl. its per-call pre-pass); tile/splits columns force gemm_b3c_kernel (tuning\n'
+       '# hook b3c = 2) with that tile (64 = 64 x 64, 128 = 128 x 64, 128128 = 128 x 128) and k-slice count; the last three rows are above the\n'
+       '# pre-split threshold: every column is gemm_b3.\n')
 open(os.path.join(P, TAG + '_b3c_bench.txt'), 'w').write(hdr + clean(os.path.join(F, 'b3c_bench.log')))
 
 # 6. full-graph evaluation: timings + PMC traffic of the aggregation
