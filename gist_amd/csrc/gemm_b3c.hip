@@ -509,15 +509,6 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     int kt = 0;
-#ifdef C3_NO_OVERLAP      // dev probe: fragments read and consumed in the same step
-    for (; kt < n_kt; ++kt) {
-        __syncthreads();
-        read_frags(kt, S0{});
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        multiply(S0{});
-    }
-    kt = n_kt + 1;
-#endif
 #ifdef C3_PROBE
     unsigned long long co_bar = 0, co_work = 0, co_wait = 0;
     const unsigned long long co_t0 = C3_T();
@@ -554,24 +545,16 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
         multiply(S0{});
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
-    auto settle = [&]() {};
-#ifdef C3_NO_OVERLAP
-    settle();
-#else
     if (kt < n_kt) {                                          // odd tile count: one more
         __syncthreads();
         read_frags(kt, S0{});
         if (kt > 0) multiply(S1{});
         __builtin_amdgcn_s_waitcnt(0xc07f);
         multiply(S0{});
-        settle();
     } else if (n_kt > 0) {
         multiply(S1{});
-        settle();
     }
-#endif
-
-    }
+    }      // (the two-set consumer of the 32 x 32 / 64 x 32 wave tiles)
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
     const bool add_bias = g.bias != nullptr && g.split_stride == 0;
