@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GistLibraryError(RuntimeError):
@@ -86,6 +86,9 @@ SIGNATURES = {
     'gist_gemm_slabs_f32': (_int, [_int, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _p]),
     'gist_ln_relu_fwd_drop_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _f, _f, _u64,
                                          _u64, _i64, _p]),
+    'gist_ln_relu_fwd_slabs_f32': (_int, [_p, _i64, _p, _i64, _int, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int,
+                                          _f, _f, _u64, _u64, _i64, _p]),
+    'gist_gemm_splits_operands': (_int, [_i64, _i64, _i64]),
     'gist_row_chunks16': (_i64, [_i64]),
     'gist_ln_relu_bwd_colsum_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p, _p]),
     'gist_colsum_chunks_f32': (_int, [_p, _i64, _i64, _p, _p]),

@@ -620,7 +620,9 @@ int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda
              void *ws, int64_t ws_bytes, hipStream_t st, int *deferred);
 int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k);      // -1: shape not taken
 
-static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
+// deferred: the k slices are summed by the kernel that consumes the result (gist_gemm_slabs_f32) -- no reduce
+// launch, only the slabs' write and read.
+static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k, bool deferred = false) {
     const int64_t kt = ceil_div(k, 32);      // the model counts k in units of 32
     // explicit override for tuning sweeps (scripts/gemm_sweep.py) and tests; 0 = the model decides
     const int t_tile = (int)tune(GIST_TUNE_GEMM_TILE), t_split = (int)tune(GIST_TUNE_GEMM_SPLITS);
@@ -645,7 +647,9 @@ static GemmCfg choose_cfg(int64_t m, int64_t n, int64_t k) {
             const int conc = (int)(per_cu < cap ? per_cu : cap);
             const double eff = tile == 128 ? eff128[conc] : eff64[conc];
             double cost = (double)per_cu * unit * (double)(kt_per + 3) / eff;
-            if (sp > 1) cost += 12.0 + 6.5 * sp * mn;
+            // (deferred: no reduce launch, but the slabs are written by this kernel and read by the consumer; fitted to
+            // same-box A/B runs of the forward projections of BASELINE configs 2 and 4, scripts/ab_yslabs.sh)
+            if (sp > 1) cost += deferred ? 4.5 + 9.0 * sp * mn : 12.0 + 6.5 * sp * mn;
             if (cost < best_cost) { best_cost = cost; best = GemmCfg{tile, sp}; }
         }
     }
@@ -716,9 +720,13 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     const bool aligned = aligned16(a) && (lda % 4 == 0) && lda >= 4 && aligned16(b) &&
                          (ldb % 4 == 0) && ldb >= 4 && k > 0;
     g.setprio = 1;
-    GemmCfg cfg = choose_cfg(m, n, k);
+    GemmCfg cfg = choose_cfg(m, n, k, deferred != nullptr);
     int splits = cfg.splits;
-    if (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits = 1;
+    // a slab buffer too small for the model's slice count: the largest power of two that fits, not one slice
+    // (the class layer's 41 x 4096 x 2046 weight gradient fell from 8 slices to 1 for most batch sizes of the
+    // h = 2048 step -- 39 us instead of 13 -- because the count is not monotone in k and the step had sized its
+    // buffer from a few sampled batch sizes)
+    while (splits > 1 && (ws == nullptr || ws_bytes < (int64_t)splits * m * n * 4)) splits >>= 1;
     g.k_per_split = (int)(ceil_div(ceil_div(k, 64), splits) * 64);   // multiple of either BK
     splits = (int)ceil_div(k, g.k_per_split > 0 ? g.k_per_split : 1);
     if (splits < 1) splits = 1;
@@ -752,7 +760,7 @@ void gemm_f32_choice(int64_t m, int64_t n, int64_t k, int *tile, int *splits) {
 // whichever is larger (0: one k slice)
 int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const int sp = choose_cfg(m, n, k).splits;
+    const int sp = choose_cfg(m, n, k, true).splits;      // (sized for the deferred form: what these slabs are for)
     const int64_t f32 = sp > 1 ? (int64_t)sp * m * n * 4 : 0;
     const int64_t c3 = b3c_slab_bytes(m, n, k);
     return c3 > f32 ? c3 : f32;
@@ -798,6 +806,13 @@ extern "C" int gist_gemm_trace_read(unsigned long long *out, int64_t n_blocks) {
 }
 #endif
 
+/* 1 if a gist_gemm_* call of this shape splits its own operands in the current mode (f16x3 / bf16x3 pre-split
+ * kernels: it needs the large workspace of gist_gemm_workspace_bytes and reduces its k slices itself). */
+extern "C" int gist_gemm_splits_operands(int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    return (gist::h3_eligible(m, n, k) || gist::b3_eligible(m, n, k)) ? 1 : 0;
+}
+
 extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const int64_t h3 = gist::h3_workspace_bytes(m, n, k);
@@ -805,7 +820,8 @@ extern "C" int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     const int64_t b3 = gist::b3_workspace_bytes(m, n, k);
     if (b3 > 0) return b3;
     const int64_t c3 = gist::b3c_slab_bytes(m, n, k);      // >= 0: the convert-on-load bf16x3 path takes the shape
-    const int s = gist::choose_cfg(m, n, k).splits;
+    const int s0 = gist::choose_cfg(m, n, k).splits, s1 = gist::choose_cfg(m, n, k, true).splits;
+    const int s = s0 > s1 ? s0 : s1;                       // (the call that reduces itself / gist_gemm_slabs_f32)
     const int64_t f32 = s > 1 ? (int64_t)s * m * n * 4 : 0;
     return c3 > f32 ? c3 : f32;                            // (unaligned operands fall back to the fp32 kernel)
 }

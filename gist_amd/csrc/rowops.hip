@@ -71,6 +71,9 @@ struct DropOut {
     float p, scale;                 // p = 0: no mask (out = the plain value)
     uint64_t sm, offset;            // seed * golden ratio; counter base
     int64_t mask_ld;
+    // the pre-norm input still as split-K slabs of its projection (gist_ln_relu_fwd_slabs_f32): row r, column c =
+    // sum_s slabs[s * slab_stride + r * d + c] + bias[c], formed here in gist_gemm's own order (n_slabs = 0: y as is)
+    const float *slabs; int64_t slab_stride; int n_slabs; const float *bias;
 };
 
 // ---------------------------------------------------------------------------
@@ -115,6 +118,26 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float *__restrict__ y,
         }
         orow[c] = v;
     };
+    if (dr.n_slabs > 0 && live) {
+        // y <- the projection's result; every thread forms exactly the columns it reads back below
+        const float *sp = dr.slabs + (int64_t)row * d;
+        for (int c = t * VEC; c < d; c += TPR * VEC) {
+            if constexpr (VEC == 4) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < dr.n_slabs; ++k) {
+                    const float4 q = *reinterpret_cast<const float4 *>(sp + (int64_t)k * dr.slab_stride + c);
+                    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+                }
+                if (dr.bias) { a.x += dr.bias[c]; a.y += dr.bias[c + 1]; a.z += dr.bias[c + 2]; a.w += dr.bias[c + 3]; }
+                *reinterpret_cast<float4 *>(yr + c) = a;
+            } else {
+                float a = 0.f;
+                for (int k = 0; k < dr.n_slabs; ++k) a += sp[(int64_t)k * dr.slab_stride + c];
+                if (dr.bias) a += dr.bias[c];
+                yr[c] = a;
+            }
+        }
+    }
     float mean = 0.f, rstd = 1.f;
 #ifndef GIST_LN_STREAMING      // dev A/B build flag: always take the streaming path
     if constexpr (TPR == 256 && VEC == 4) {
@@ -936,8 +959,15 @@ static int ln_relu_fwd_ex(const char *name, float *y, int64_t ldy, float *out, i
     bool v4 = d % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out);
     DropOut dr{};
     const bool dropping = drop != nullptr && (drop->p > 0.f || drop->out2 != nullptr);
+    if (drop != nullptr && drop->n_slabs > 0) {
+        if (drop->slabs == nullptr || drop->slab_stride < n_rows * d) { set_error("%s: bad slabs", name); return GIST_EINVAL; }
+        dr.slabs = drop->slabs; dr.slab_stride = drop->slab_stride; dr.n_slabs = drop->n_slabs; dr.bias = drop->bias;
+        v4 = v4 && aligned16(drop->slabs) && drop->slab_stride % 4 == 0;
+    }
     if (dropping) {
+        const DropOut keep = dr;
         dr = *drop;
+        dr.slabs = keep.slabs; dr.slab_stride = keep.slab_stride; dr.n_slabs = keep.n_slabs; dr.bias = keep.bias;
         if (dr.out2 != nullptr) {
             if (dr.ldo2 < d) { set_error("%s: leading dimension < d", name); return GIST_EINVAL; }
             v4 = v4 && dr.ldo2 % 4 == 0 && aligned16(dr.out2);
@@ -978,6 +1008,23 @@ extern "C" int gist_ln_relu_fwd_drop_f32(float *y, int64_t ldy, float *out, int6
     dr.out2 = out2; dr.ldo2 = ldo2; dr.p = p; dr.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
     dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.offset = offset; dr.mask_ld = mask_ld;
     return gist::ln_relu_fwd_ex("gist_ln_relu_fwd_drop_f32", y, ldy, out, ldo, rstd, n_rows, d, use_lynorm,
+                                relu, eps, &dr, gist::as_stream(stream));
+}
+
+extern "C" int gist_ln_relu_fwd_slabs_f32(float *y, int64_t ldy, const float *slabs, int64_t slab_stride,
+                                          int32_t n_slabs, const float *bias, float *out, int64_t ldo, float *out2,
+                                          int64_t ldo2, float *rstd, int64_t n_rows, int64_t d, int use_lynorm,
+                                          int relu, float eps, float p, uint64_t seed, uint64_t offset,
+                                          int64_t mask_ld, gist_stream_t stream) {
+    GIST_REQUIRE(p >= 0.f && p < 1.f, "gist_ln_relu_fwd_slabs_f32: p must be in [0,1)");
+    GIST_REQUIRE(mask_ld >= d || p == 0.f, "gist_ln_relu_fwd_slabs_f32: mask_ld < d");
+    GIST_REQUIRE(n_slabs >= 0 && n_slabs < 4096, "gist_ln_relu_fwd_slabs_f32: bad n_slabs");
+    GIST_REQUIRE(n_slabs == 0 || slabs != nullptr, "gist_ln_relu_fwd_slabs_f32: null slabs");
+    gist::DropOut dr{};
+    dr.out2 = out2; dr.ldo2 = ldo2; dr.p = p; dr.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+    dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.offset = offset; dr.mask_ld = mask_ld;
+    dr.slabs = slabs; dr.slab_stride = slab_stride; dr.n_slabs = n_slabs; dr.bias = n_slabs > 0 ? bias : nullptr;
+    return gist::ln_relu_fwd_ex("gist_ln_relu_fwd_slabs_f32", y, ldy, out, ldo, rstd, n_rows, d, use_lynorm,
                                 relu, eps, &dr, gist::as_stream(stream));
 }
 

@@ -246,6 +246,7 @@ namespace {
 struct FusedLayout {
     float *dw_slabs[GIST_MAX_LAYERS]; int64_t dw_bytes[GIST_MAX_LAYERS];   // dW_k = dY_k^T . Z_k
     float *logit_slabs; int64_t logit_bytes;                               // class layer's Y = Z . W^T
+    float *y_slabs; int64_t y_bytes;      // a hidden layer's Y = Z . W^T until its LayerNorm has read it (one buffer)
     float *partials[GIST_MAX_LAYERS];                                      // [row_chunks16(n_max)][n_out_k]
     int64_t bytes, partial_floats;
 };
@@ -253,13 +254,23 @@ struct FusedLayout {
 // the largest slab need over the batch sizes a plan sees (the split count depends on the reduction
 // length); a batch that would need more falls back to one k slice inside the launcher
 int64_t slab_need(int64_t m, int64_t n, int64_t k_max, bool k_is_rows) {
+    // (called for every layer of every step: remembered per shape and GEMM mode)
+    struct Memo { int64_t m, n, k; int rows, mode; int64_t need; };
+    static thread_local Memo memo[32];
+    static thread_local int memo_n = 0;
+    const int mode = gist_gemm_get_mode();
+    for (int i = 0; i < memo_n; ++i)
+        if (memo[i].m == m && memo[i].n == n && memo[i].k == k_max && memo[i].rows == (int)k_is_rows && memo[i].mode == mode)
+            return memo[i].need;
     int64_t need = 0;
-    for (int q = 8; q >= 4; --q) {
-        const int64_t rows = k_max * q / 8;
-        if (rows <= 0) continue;
+    // every 32 rows down to half the largest batch (the model's slice count is not monotone in the reduction
+    // length: two neighbouring batch sizes can differ by a factor of two)
+    for (int64_t rows = k_max; rows > 0 && rows >= k_max / 2; rows -= 32) {
         const int64_t b = k_is_rows ? gemm_f32_slab_bytes(m, n, rows) : gemm_f32_slab_bytes(rows, n, m);
         need = b > need ? b : need;
     }
+    if (memo_n < 32 && tune(GIST_TUNE_GEMM_TILE) == 0.0 && tune(GIST_TUNE_GEMM_SPLITS) == 0.0 && tune(GIST_TUNE_B3C) == 0.0)
+        memo[memo_n++] = Memo{m, n, k_max, (int)k_is_rows, mode, need};      // (not under tuning overrides)
     return need;
 }
 
@@ -283,6 +294,12 @@ FusedLayout fused_layout(const gist_step_plan *p, char *base, float *partials) {
     const gist_layer_desc &last = p->layer[L1 - 1];
     f.logit_bytes = slab_need(2 * last.n_in, last.n_out, p->n_max, false);
     f.logit_slabs = f.logit_bytes > 0 ? take(f.logit_bytes) : nullptr;
+    f.y_bytes = 0;
+    for (int k = 0; k + 1 < L1; ++k) {
+        const int64_t b = slab_need(2 * p->layer[k].n_in, p->layer[k].n_out, p->n_max, false);
+        f.y_bytes = b > f.y_bytes ? b : f.y_bytes;
+    }
+    f.y_slabs = f.y_bytes > 0 ? take(f.y_bytes) : nullptr;
     f.bytes = off;
     f.partial_floats = poff;
     return f;
@@ -296,8 +313,9 @@ extern "C" int64_t gist_step_fused_workspace_bytes(const gist_step_plan *plan) {
 // bytes reserved for the slabs of layer k's weight gradient (k == n_layers: the class layer's logits)
 extern "C" int64_t gist_step_fused_slab_bytes(const gist_step_plan *plan, int32_t k) {
     if (!plan || plan->n_layers < 1 || plan->n_layers > GIST_MAX_LAYERS || plan->n_max <= 0) return 0;
-    if (k < 0 || k > plan->n_layers) return 0;
+    if (k < 0 || k > plan->n_layers + 1) return 0;
     const FusedLayout f = fused_layout(plan, nullptr, nullptr);
+    if (k == plan->n_layers + 1) return f.y_bytes;      // the hidden layers' forward projections (shared)
     return k == plan->n_layers ? f.logit_bytes : f.dw_bytes[k];
 }
 extern "C" int64_t gist_step_col_partials_floats(const gist_step_plan *plan) {
@@ -493,6 +511,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     int logit_slabs = 0;           // > 1: the class layer's logits are still split-K slabs
     for (int k = 0; k < L1; ++k) {
         const gist_layer_desc &l = p->layer[k];
+        int y_slabs_n = 1;                   // > 1: this layer's pre-norm output is still split-K slabs
+        const float *y_slabs = nullptr;
         {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
             if (fwd_fold[k]) {      // source = the undropped input, store = dropout(ah)
@@ -530,8 +550,16 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             d.dst_r = hl.Zs;
             d.dst_t = train ? hl.ZsT : nullptr;
             GIST_TRY(b3_dual_split(d, st));
+            // (a hidden layer's k slices stay slabs: its LayerNorm, the next launch, sums them as it reads)
+            // (with one slice the kernel adds the bias itself; slabs get it from the LayerNorm)
+#ifdef STEP_NO_YSLABS
+            const bool to_ln = false;
+#else
+            const bool to_ln = defer && k + 1 < L1;
+#endif
             GIST_TRY(b3_gemm_presplit("gist_sage_step", hl.Zs, hl.Ws, l.b, l.Y, l.ldy, n, l.n_out,
-                                      2 * l.n_in, b3.slabs, b3.slab_bytes, st));
+                                      2 * l.n_in, b3.slabs, b3.slab_bytes, st, to_ln ? &y_slabs_n : nullptr));
+            if (to_ln) y_slabs = b3.slabs;
         } else {
             if (drop && !fwd_fold[k])
                 GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, offs[k], s));
@@ -539,6 +567,14 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             if (defer && k == L1 - 1 && fl.logit_slabs != nullptr) {      // the loss kernel sums the slabs
                 GIST_TRY(gemm_slabs(0, l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out, 2 * l.n_in,
                                     fl.logit_slabs, fl.logit_bytes, &logit_slabs, st));
+#ifndef STEP_NO_YSLABS      // dev A/B build flag
+            } else if (defer && k + 1 < L1 && fl.y_slabs != nullptr && !h3_eligible(n, l.n_out, 2 * l.n_in) &&
+                       !b3_eligible(n, l.n_out, 2 * l.n_in)) {
+                // the LayerNorm sums the slabs (a projection the per-call split paths take keeps their workspace)
+                GIST_TRY(gemm_slabs(0, l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out, 2 * l.n_in,
+                                    fl.y_slabs, fl.y_bytes, &y_slabs_n, st));
+                y_slabs = fl.y_slabs;
+#endif
             } else {
                 GIST_TRY(gist_gemm_nt_f32(l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out,
                                           2 * l.n_in, p->workspace, p->workspace_bytes, s));
@@ -546,7 +582,15 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         }
         if (k + 1 < L1) {
             const gist_layer_desc &nx = p->layer[k + 1];
-            if (fwd_fold[k + 1])
+            if (y_slabs_n > 1)
+                GIST_TRY(gist_ln_relu_fwd_slabs_f32(l.Y, l.ldy, y_slabs, n * l.n_out, y_slabs_n, l.b, nx.Z, nx.ldz,
+                                                    fwd_fold[k + 1] ? p->hsrc[k + 1] : nullptr,
+                                                    fwd_fold[k + 1] ? p->ld_hsrc[k + 1] : 0,
+                                                    p->use_layernorm ? l.rstd : nullptr, n, l.n_out,
+                                                    p->use_layernorm, 1, 1e-5f, fwd_fold[k + 1] ? p->p_drop : 0.f,
+                                                    p->seed, fwd_fold[k + 1] ? offs[k + 1] : 0,
+                                                    fwd_fold[k + 1] ? 2 * nx.n_in : l.n_out, s));
+            else if (fwd_fold[k + 1])
                 GIST_TRY(gist_ln_relu_fwd_drop_f32(l.Y, l.ldy, nx.Z, nx.ldz, p->hsrc[k + 1], p->ld_hsrc[k + 1],
                                                    p->use_layernorm ? l.rstd : nullptr, n, l.n_out,
                                                    p->use_layernorm, 1, 1e-5f, p->p_drop, p->seed,

@@ -406,6 +406,8 @@ class SageEngine(object):
             fb['partials'].append(torch.zeros(max(chunks * o, 4), **f32))
         nb = int(L.gist_step_fused_slab_bytes(ctypes.byref(P), self.L1))
         fb['logits'] = torch.empty(nb, **u8) if nb > 0 else None
+        nb = int(L.gist_step_fused_slab_bytes(ctypes.byref(P), self.L1 + 1))
+        fb['y'] = torch.empty(nb, **u8) if nb > 0 else None          # a hidden layer's forward projection
         self._fused = fb
         return fb
 
@@ -476,9 +478,22 @@ class SageEngine(object):
                 hip.gemm_nt(z, A.W[k], A.b[k], self.Y[k][:n, :o])
             else:
                 y = self.Y[k][:n]
-                hip.gemm_nt(z, A.W[k], A.b[k], y)
                 i_next = self.dims[k + 1][0]
                 rstd = self.rstd[k][:n] if self.use_layernorm else None
+                if (self.fuse and training and _step and self._fused_buffers()['y'] is not None and
+                        not hip.gemm_splits_own_operands(n, o, 2 * i)):
+                    # the projection's k slices stay slabs; the LayerNorm sums them as it reads (gist_sage_step)
+                    ys = self._fused_buffers()['y']
+                    ns = hip.gemm_slabs('nt', z, A.W[k], A.b[k], y, ys)
+                    if ns > 1:
+                        hip.ln_relu_fwd_slabs(y, ys, ns, A.b[k], self.Z[k + 1][:n, :i_next],
+                                              self.H[k + 1][:n, :i_next] if fold[k + 1] else None, rstd,
+                                              self.use_layernorm, True, self.p_drop if fold[k + 1] else 0.0,
+                                              self.seed, offs[k + 1] if fold[k + 1] else 0,
+                                              2 * i_next if fold[k + 1] else o)
+                        continue
+                else:
+                    hip.gemm_nt(z, A.W[k], A.b[k], y)
                 if fold[k + 1]:
                     hip.ln_relu_fwd_drop(y, self.Z[k + 1][:n, :i_next], self.H[k + 1][:n, :i_next], rstd,
                                          self.use_layernorm, True, self.p_drop, self.seed, offs[k + 1],

@@ -207,6 +207,11 @@ def gemm_mode(mode=None):
     return ('f32', 'f16x3', 'bf16x3')[L.gist_gemm_get_mode()]
 
 
+def gemm_splits_own_operands(m, n, k):
+    """Does a projection of this shape take a pre-split kernel in the current GEMM mode (gist_gemm_splits_operands)?"""
+    return bool(_lib.load().gist_gemm_splits_operands(int(m), int(n), int(k)))
+
+
 def tuning(knob, value=None):
     """Get (and with a value, set) a tuning hook (include/gist_hip.h gist_tuning_set): explicit
     overrides of the launchers' choices for sweeps and tests; 0 = the launcher decides."""
@@ -542,6 +547,26 @@ def ln_relu_fwd_drop(y, out, out2, rstd, use_lynorm, relu, p, seed, offset, mask
     _lib.check(L.gist_ln_relu_fwd_drop_f32(yp, ldy, op, ldo, o2p, ldo2, _opt(rstd, 'rstd', torch.float32, n), n,
                                            d, int(bool(use_lynorm)), int(bool(relu)), eps, float(p), int(seed),
                                            int(offset), int(mask_ld), _stream()), 'gist_ln_relu_fwd_drop_f32')
+    return out
+
+
+def ln_relu_fwd_slabs(y, slabs, n_slabs, bias, out, out2, rstd, use_lynorm, relu, p=0.0, seed=0, offset=0, mask_ld=0,
+                      eps=LN_EPS):
+    """LayerNorm + ReLU of y = sum of the projection's n_slabs split-K slabs (dense [n, d] arrays at the start of
+    `slabs`, n * d floats apart) + bias, formed inside the kernel; out / out2 / dropout as ln_relu_fwd_drop."""
+    L = _lib.load()
+    yp, ldy = _mat(y, 'y')
+    op, ldo = _mat(out, 'out')
+    o2p, ldo2 = _mat(out2, 'out2') if out2 is not None else (None, 0)
+    n, d = y.shape
+    if n_slabs > 0:
+        if slabs is None or not slabs.is_cuda or slabs.numel() * slabs.element_size() < n_slabs * n * d * 4:
+            raise ValueError('gist_amd: slabs must be a device buffer of at least n_slabs * n * d floats')
+    _lib.check(L.gist_ln_relu_fwd_slabs_f32(yp, ldy, slabs.data_ptr() if n_slabs > 0 else None, n * d, int(n_slabs),
+                                            _opt(bias, 'bias', torch.float32, d), op, ldo, o2p, ldo2,
+                                            _opt(rstd, 'rstd', torch.float32, n), n, d, int(bool(use_lynorm)),
+                                            int(bool(relu)), eps, float(p), int(seed), int(offset), int(mask_ld),
+                                            _stream()), 'gist_ln_relu_fwd_slabs_f32')
     return out
 
 

@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 9 */
+int gist_abi_version(void);   /* currently 10 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -146,6 +146,9 @@ int gist_partition_graph(const int32_t *rowptr, const int32_t *col,
  * Bytes of workspace gist_gemm_* may need for the given output shape (split-K
  * partial sums); 0 is a valid answer.  Host function. */
 int64_t gist_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+/* 1 if a call of this shape splits its own operands in the current mode (the pre-split f16x3 / bf16x3 kernels:
+ * large workspace, reduces its own k slices -- gist_gemm_slabs_f32 then returns one slab); host function. */
+int gist_gemm_splits_operands(int64_t m, int64_t n, int64_t k);
 
 /* Y[m,n] = A[m,k] . W[n,k]^T + bias[n]          (bias may be NULL)
  * Replaces self.linear(h), cluster_gcn/modules.py:233 (nn.Linear: W is [out, 2*in]). */
@@ -246,6 +249,17 @@ int gist_ln_relu_fwd_drop_f32(float *y, int64_t ldy, float *out, int64_t ldo, fl
                               float *rstd, int64_t n_rows, int64_t d, int use_lynorm, int relu,
                               float eps, float p, uint64_t seed, uint64_t offset, int64_t mask_ld,
                               gist_stream_t stream);
+
+/* gist_ln_relu_fwd_drop_f32 whose pre-norm input is still the split-K slabs of its projection
+ * (gist_gemm_slabs_f32, layout NT: n_slabs dense [n_rows, d] arrays slab_stride floats apart): the kernel
+ * forms y = sum of the slabs in slab order + bias (gist_gemm_nt_f32's own order: same bits) as it reads the
+ * row, so self.linear(h) of modules.py:233 needs no reduce launch in front of :234-236.  n_slabs = 0: y is
+ * read as is (slabs, bias ignored); p = 0 and out2 = NULL: no dropout (gist_ln_relu_fwd_f32). */
+int gist_ln_relu_fwd_slabs_f32(float *y, int64_t ldy, const float *slabs, int64_t slab_stride,
+                               int32_t n_slabs, const float *bias, float *out, int64_t ldo, float *out2,
+                               int64_t ldo2, float *rstd, int64_t n_rows, int64_t d, int use_lynorm,
+                               int relu, float eps, float p, uint64_t seed, uint64_t offset,
+                               int64_t mask_ld, gist_stream_t stream);
 
 /* gist_ln_relu_bwd_f32 that also leaves the bias gradient of the layer in chunks:
  * col_partials[gist_row_chunks16(n_rows)][d] = column sums of dy per 16 consecutive rows.  The sum of the

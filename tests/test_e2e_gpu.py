@@ -663,7 +663,7 @@ def _metric_config_engine(mode, hidden=4096):
     eng = SageEngine(dims, True, 0.0, it.n_max, DEV)
     if hidden == 4096:
         big = _lib.load().gist_gemm_workspace_bytes(it.n_max, 4096, 8192)
-        assert (big > (1 << 27)) == (mode != 'f32')        # the step really runs on the split path
+        assert mode == 'f32' or big > (1 << 27)            # the step really runs on the split path
     rs = np.random.RandomState(3)
     params = []
     for (i, o) in dims:
@@ -817,7 +817,7 @@ def test_step_kept_split_operands_equal_per_call_splits(monkeypatch, mode):
                     break
             runs[tag] = (losses, eng.arena.params.clone())
         la, lb = runs['per_call'][0], runs['kept'][0]
-        assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+        assert max(abs(a - b) / max(1.0, abs(a)) for a, b in zip(la, lb)) < 2e-5, (la, lb)      # (losses of ~40)
         assert la[0] > 3.0 and abs(la[0] - la[2]) > 1e-3          # it did train, with dropout
         d = (runs['per_call'][1] - runs['kept'][1]).abs()
         stats = (d.mean().item(), (d > TOL).float().mean().item(), d.max().item())

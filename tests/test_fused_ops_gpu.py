@@ -116,6 +116,52 @@ def test_ln_relu_fwd_drop(hip, n, d, use_ln):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize('m,n,k,p', [(2046, 256, 512, 0.0), (1140, 512, 1024, 0.3), (700, 2048, 260, 0.2),
+                                     (333, 96, 1204, 0.0), (513, 4096, 192, 0.25)])
+def test_ln_from_projection_slabs(hip, m, n, k, p):
+    """gist_gemm_slabs_f32 (NT; the model's slice count, then 4 forced) + gist_ln_relu_fwd_slabs_f32 == the slabs
+    summed in slab order + bias (with the same slice count: gist_gemm_nt_f32's own result) followed by
+    gist_ln_relu_fwd_drop_f32, bit for bit: yhat, rstd, the dropped output and the undropped copy."""
+    prev = hip.gemm_mode()
+    hip.gemm_mode('f32')
+    gen = torch.Generator(device=DEV).manual_seed(m + n)
+    a = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.randn(n, k, device=DEV, generator=gen) / np.sqrt(k)
+    bias = torch.randn(n, device=DEV, generator=gen)
+    try:
+        for splits in (0, 4):
+            hip.tuning('gemm_tile', 64 if splits else 0)
+            hip.tuning('gemm_splits', splits)
+            y = torch.full((m, n), float('nan'), device=DEV)
+            slabs = torch.full((8 * m * n,), float('nan'), device=DEV)
+            ns = hip.gemm_slabs('nt', a, w, bias, y, slabs.view(torch.uint8))
+            assert (ns in (3, 4)) if splits else ns >= 1      # (k = 260: slices of 128 -> 3)
+            if ns > 1:       # the slabs in slab order, then the bias: gist_gemm's own reduce pass
+                y_ref = torch.zeros(m, n, device=DEV)
+                for q in range(ns):
+                    y_ref = y_ref + slabs[q * m * n:(q + 1) * m * n].view(m, n)
+                y_ref = y_ref + bias
+                if splits:   # ... which the self-reducing call with the same slice count reproduces
+                    y_call = torch.empty(m, n, device=DEV)
+                    hip.gemm_nt(a, w, bias, y_call)
+                    assert torch.equal(y_call, y_ref)
+            else:
+                y_ref = y.clone()
+            o_ref, o2_ref, r_ref = torch.zeros(m, 2 * n, device=DEV), torch.zeros(m, n, device=DEV), torch.zeros(m, device=DEV)
+            hip.ln_relu_fwd_drop(y_ref, o_ref[:, :n], o2_ref, r_ref, True, True, p, 9, 128, 2 * n)
+            o, o2, r = torch.zeros(m, 2 * n, device=DEV), torch.zeros(m, n, device=DEV), torch.zeros(m, device=DEV)
+            if ns > 1:
+                hip.ln_relu_fwd_slabs(y, slabs, ns, bias, o[:, :n], o2, r, True, True, p, 9, 128, 2 * n)
+            else:
+                hip.ln_relu_fwd_slabs(y, None, 0, None, o[:, :n], o2, r, True, True, p, 9, 128, 2 * n)
+            assert torch.equal(y, y_ref) and torch.equal(r, r_ref)
+            assert torch.equal(o, o_ref) and torch.equal(o2, o2_ref)
+    finally:
+        hip.tuning('gemm_tile', 0)
+        hip.tuning('gemm_splits', 0)
+        hip.gemm_mode(prev)
+
+
 @pytest.mark.parametrize('n,d,use_ln', [(2046, 512, True), (1000, 1024, True), (37, 96, True), (300, 256, False),
                                         (200, 2048, True), (65, 50, True)])
 def test_ln_relu_bwd_colsum(hip, n, d, use_ln):
@@ -393,8 +439,8 @@ def test_one_launch_extraction_large_batch(hip):
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
 def test_native_step_fused_equals_unfused(hip, monkeypatch, p_drop):
     """gist_sage_step with the fused sequence against the un-fused one (GIST_STEP_FUSE=0), GEMM mode f32,
-    4 steps: the dropout folds, slab deferrals and the one-launch extraction are exact rewrites, only the
-    bias gradients change their summation order -- losses within 1e-6, parameters within 1e-6."""
+    4 steps: the dropout folds, slab deferrals and the one-launch extraction are exact rewrites; the bias
+    gradients and the k slices of the deferred projections change their summation order."""
     from gist_amd.engine import SageEngine, dims_for
     prev = hip.gemm_mode()
     hip.gemm_mode('f32')
@@ -419,8 +465,11 @@ def test_native_step_fused_equals_unfused(hip, monkeypatch, p_drop):
             eng.check_extract()
             assert (eng._extract_scratch is not None) == (fuse == '1')      # the one-launch extraction ran
             res.append((eng.arena.params.clone(), torch.stack(losses), eng.arena.grads.clone()))
-        assert (res[0][1] - res[1][1]).abs().max().item() < 1e-6
-        assert (res[0][2] - res[1][2]).abs().max().item() < 1e-5 * max(1.0, res[0][2].abs().max().item())
+        # (the hidden layers' forward projections may run with another k-slice count when their slabs are left
+        # to the LayerNorm: fp32 sums in another order -- the first loss agrees to rounding, later ones at 1e-4)
+        dl = (res[0][1] - res[1][1]).abs()
+        assert dl[0].item() < 2e-6 * max(1.0, res[0][1][0].abs().item()) and dl.max().item() < 1e-4
+        assert (res[0][2] - res[1][2]).abs().max().item() < 1e-4 * max(1.0, res[0][2].abs().max().item())
         # Adam normalises by sqrt(v): a rounding-level difference of a tiny bias gradient may move its
         # parameter by a fraction of lr in the first steps; everything else must agree closely
         d = (res[0][0] - res[1][0]).abs()
