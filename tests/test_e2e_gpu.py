@@ -829,9 +829,9 @@ def test_step_kept_split_operands_equal_per_call_splits(monkeypatch, mode):
 @pytest.mark.parametrize('hidden', [4096, 2048])
 def test_metric_config_fused_step_equals_unfused_bf16x3(monkeypatch, hidden):
     """The metric's step (dropout 0.2, GEMM mode bf16x3, kept split operands) with the fused sequence against
-    the un-fused one after ONE iteration: same masks, same projections; the k slices of the last weight
-    gradient (dW_0: 3 slices at H = 4096) are summed by the optimiser instead of a reduce pass, in the same
-    order -- the hidden layers' weight gradients are BIT-equal; bias gradients change their summation order (chunk sums)."""
+    the un-fused one after ONE iteration: same masks, same projections; k slices are summed by their consumers
+    (LayerNorm, loss kernel, optimiser) instead of reduce passes, bias gradients as chunk sums -- every gradient
+    agrees to rounding."""
     from gist_amd import hip
     prev = hip.gemm_mode()
     try:
@@ -850,10 +850,11 @@ def test_metric_config_fused_step_equals_unfused_bf16x3(monkeypatch, hidden):
         assert abs(runs['0'][0] - runs['1'][0]) < 1e-6 * max(1.0, abs(runs['0'][0]))
         for k in range(len(dims)):
             gw = runs['0'][1][k]
-            if k < len(dims) - 1:      # the projections on kept split operands
-                assert torch.equal(gw, runs['1'][1][k]), k
-            else:                      # the class layer's k slices: another slice count when they are deferred
-                assert (gw - runs['1'][1][k]).abs().max().item() < 1e-5 * gw.abs().max().item()
+            # (k slices left to a consumer may be cut differently from slices the call sums itself -- the class
+            # layer's logits and weight gradient -- so everything downstream agrees to rounding, not bit for bit;
+            # the slab sums themselves are held bitwise in tests/test_fused_ops_gpu.py)
+            dgw = (gw - runs['1'][1][k]).abs()
+            assert dgw.max().item() < 1e-4 * gw.abs().max().item() and dgw.mean().item() < 1e-6 * gw.abs().max().item(), k
             gb = runs['0'][2][k]
             assert (gb - runs['1'][2][k]).abs().max().item() < 1e-5 * max(1e-3, gb.abs().max().item()), k
         d = (runs['0'][3] - runs['1'][3]).abs()
