@@ -117,7 +117,7 @@ def test_ln_relu_fwd_drop(hip, n, d, use_ln):
 
 
 @pytest.mark.parametrize('m,n,k,p', [(2046, 256, 512, 0.0), (1140, 512, 1024, 0.3), (700, 2048, 260, 0.2),
-                                     (333, 96, 1204, 0.0), (513, 4096, 192, 0.25)])
+                                     (333, 96, 1204, 0.0), (513, 4096, 192, 0.25), (130, 37, 300, 0.0)])      # (37: scalar path)
 def test_ln_from_projection_slabs(hip, m, n, k, p):
     """gist_gemm_slabs_f32 (NT; the model's slice count, then 4 forced) + gist_ln_relu_fwd_slabs_f32 == the slabs
     summed in slab order + bias (with the same slice count: gist_gemm_nt_f32's own result) followed by
