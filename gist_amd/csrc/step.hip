@@ -259,7 +259,9 @@ int64_t slab_need(int64_t m, int64_t n, int64_t k_max, bool k_is_rows) {
     static thread_local Memo memo[32];
     static thread_local int memo_n = 0;
     const int mode = gist_gemm_get_mode();
-    for (int i = 0; i < memo_n; ++i)
+    // (tuning overrides change tile and slice choices: neither read nor fill the memo while one is set)
+    const bool tuned = tune(GIST_TUNE_GEMM_TILE) != 0.0 || tune(GIST_TUNE_GEMM_SPLITS) != 0.0 || tune(GIST_TUNE_B3C) != 0.0;
+    for (int i = 0; i < memo_n && !tuned; ++i)
         if (memo[i].m == m && memo[i].n == n && memo[i].k == k_max && memo[i].rows == (int)k_is_rows && memo[i].mode == mode)
             return memo[i].need;
     int64_t need = 0;
@@ -269,8 +271,11 @@ int64_t slab_need(int64_t m, int64_t n, int64_t k_max, bool k_is_rows) {
         const int64_t b = k_is_rows ? gemm_f32_slab_bytes(m, n, rows) : gemm_f32_slab_bytes(rows, n, m);
         need = b > need ? b : need;
     }
-    if (memo_n < 32 && tune(GIST_TUNE_GEMM_TILE) == 0.0 && tune(GIST_TUNE_GEMM_SPLITS) == 0.0 && tune(GIST_TUNE_B3C) == 0.0)
-        memo[memo_n++] = Memo{m, n, k_max, (int)k_is_rows, mode, need};      // (not under tuning overrides)
+    if (!tuned) {      // a full table overwrites its oldest entry instead of recomputing every call
+        static thread_local int memo_next = 0;
+        if (memo_n < 32) memo[memo_n++] = Memo{m, n, k_max, (int)k_is_rows, mode, need};
+        else { memo[memo_next] = Memo{m, n, k_max, (int)k_is_rows, mode, need}; memo_next = (memo_next + 1) % 32; }
+    }
     return need;
 }
 

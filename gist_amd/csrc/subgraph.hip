@@ -262,6 +262,7 @@ struct PartsArgs {
     float *norm;
     unsigned long long *error;       // scratch word [1]: raised when a workgroup gave up waiting
     unsigned long long *slots;       // scratch: [2][gridDim.x] (launch epoch << 31 | kept-neighbour total)
+    unsigned long long *tickets;     // scratch: [2] chunk tickets of the two CSR passes (0 between launches)
     unsigned long long epoch;        // this launch's number (never 0, never reused with this scratch)
     // gather
     const float *feat; int64_t ld_feat; int d;
@@ -277,8 +278,25 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
     __shared__ int32_t stash[kPartsWaves][kStash];
     __shared__ int wcnt[kPartsWaves];
     __shared__ int wbase;
+    __shared__ int s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * kPartsWaves + wave;
+    // Which 16-row chunk this workgroup filters: for the two CSR passes (y = 0 / 1) a TICKET, not blockIdx.x --
+    // the look-back below waits for the chunks BEFORE this one, so chunk numbers must follow the order in which
+    // workgroups actually started, and HIP promises no dispatch order.  One returning atomic per workgroup; the
+    // workgroup that draws the last ticket puts the counter back to zero for the next (stream-ordered) launch.
+    int tile = (int)blockIdx.x;
+    if (blockIdx.y < 2) {
+        if (threadIdx.x == 0) {
+            unsigned long long *tk = a.tickets + blockIdx.y;
+            const unsigned long long t = __hip_atomic_fetch_add(tk, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == (unsigned long long)gridDim.x)
+                __hip_atomic_store(tk, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_tile = (int)t;
+        }
+        __syncthreads();
+        tile = s_tile;
+    }
+    const int i = tile * kPartsWaves + wave;
     if (blockIdx.y == 2) {                                   // ---- features + label of row i
         if (i >= a.n) return;
         const int v = a.ids[i];
@@ -353,8 +371,8 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
     // Each workgroup PUBLISHES (launch epoch << 31 | its kept-neighbour total) in its own slot with one
     // device-scope store and reads the slots of the workgroups BEFORE it (wave 0: up to 128 slots, two per
     // lane), re-reading the ones whose epoch is not this launch's yet.  A workgroup waits only for
-    // lower-numbered ones, which the hardware dispatched earlier and which wait for nobody above them, so
-    // the chain always drains -- no co-residency condition.  (Measured first: a grid barrier on ONE ticket
+    // lower-numbered ones, which STARTED earlier (chunk numbers are tickets drawn at start) and which wait for
+    // nobody above them, so the chain always drains -- no co-residency and no dispatch-order condition.  (Measured first: a grid barrier on ONE ticket
     // counter.  Device-scope read-modify-writes on one address complete at ~0.1-0.3 us each on this
     // multi-die part: 260 arrivals took 26 us, 1030 took 340; device-scope FENCES write back and
     // invalidate the XCD's whole L2, which the gather workgroups keep dirty: 206 us.)
@@ -364,11 +382,11 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
         int t = 0;
 #pragma unroll
         for (int k = 0; k < kPartsWaves; ++k) t += wcnt[k];
-        __hip_atomic_store(slots + blockIdx.x, (a.epoch << 31) | (unsigned long long)(unsigned)t, __ATOMIC_RELAXED,
+        __hip_atomic_store(slots + tile, (a.epoch << 31) | (unsigned long long)(unsigned)t, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     if (wave == 0) {
-        const int nb = (int)blockIdx.x;                      // slots to read: [0, nb)
+        const int nb = tile;                                 // slots to read: [0, nb)
         unsigned long long v0 = 0, v1 = 0;
         long spins = 0;
         for (;;) {
@@ -714,7 +732,7 @@ extern "C" int gist_extract_batch_drop(const int32_t *g_rowptr, const int32_t *g
 
 // ---- one-launch extraction for batches that are unions of parts (see extract_parts_kernel) ------------
 extern "C" int64_t gist_extract_parts_scratch_bytes(int64_t n_max) {
-    return n_max <= 0 ? 0 : 16 + 16 * ceil_div(n_max, kPartsWaves);
+    return n_max <= 0 ? 0 : 32 + 16 * ceil_div(n_max, kPartsWaves);
 }
 
 // 1 if gist_extract_parts_batch takes a buffer set sized for n_max rows
@@ -752,7 +770,8 @@ extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *
     a.node_part = node_part; a.part_slot = part_slot;
     a.batch = batch; a.capacity = col_capacity; a.norm = norm;
     a.error = static_cast<unsigned long long *>(scratch) + 1;
-    a.slots = static_cast<unsigned long long *>(scratch) + 2;
+    a.tickets = static_cast<unsigned long long *>(scratch) + 2;
+    a.slots = static_cast<unsigned long long *>(scratch) + 4;
     a.epoch = epoch;
     a.feat = feat; a.ld_feat = ld_feat; a.d = (int)n_feat; a.z0 = z0; a.ldz0 = ldz0;
     a.labels_all = labels_all; a.labels = labels;

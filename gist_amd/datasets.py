@@ -79,6 +79,47 @@ def make_block_dataset(name, n, n_blocks, n_feats, n_classes, intra_deg, inter_d
     return Dataset(num_classes=n_classes, g=g, par_li=par_li, name=name)
 
 
+def save_arrays(ds, directory):
+    """Dump a Dataset as plain .npy files (one per array; a directory in /dev/shm is a memcpy): how
+    bench.py hands ONE synthetic graph per node to all of its rank processes instead of letting every
+    rank regenerate it (the reference makes every rank load the full dataset)."""
+    import os
+    g = ds.g
+    np.save(os.path.join(directory, 'meta.npy'),
+            np.array([ds.num_classes, g.number_of_nodes(), len(ds.par_li)], np.int64))
+    for k in ('rowptr', 'col', 't_rowptr', 't_col'):
+        np.save(os.path.join(directory, k + '.npy'), getattr(g, k).numpy())
+    for k, v in g.ndata.items():
+        np.save(os.path.join(directory, 'ndata_' + k + '.npy'), v.numpy())
+    if getattr(g, 'node_blocks', None) is not None:
+        np.save(os.path.join(directory, 'node_blocks.npy'), g.node_blocks)
+    np.save(os.path.join(directory, 'par_sizes.npy'), np.array([len(p) for p in ds.par_li], np.int64))
+    np.save(os.path.join(directory, 'par_cat.npy'),
+            np.concatenate(ds.par_li) if ds.par_li else np.zeros(0, np.int64))
+    with open(os.path.join(directory, 'name.txt'), 'w') as f:
+        f.write(ds.name)
+
+
+def load_arrays(directory):
+    """Inverse of save_arrays: the same Dataset, bit for bit."""
+    import os
+    ld = lambda k: np.load(os.path.join(directory, k + '.npy'))
+    meta = ld('meta')
+    g = Graph(*[torch.from_numpy(ld(k)) for k in ('rowptr', 'col', 't_rowptr', 't_col')], int(meta[1]))
+    for fn in sorted(os.listdir(directory)):
+        if fn.startswith('ndata_'):
+            g.ndata[fn[len('ndata_'):-4]] = torch.from_numpy(np.load(os.path.join(directory, fn)))
+    if os.path.exists(os.path.join(directory, 'node_blocks.npy')):
+        g.node_blocks = ld('node_blocks')
+    sizes = ld('par_sizes')
+    cat = ld('par_cat')
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    par_li = [cat[offs[i]:offs[i + 1]].copy() for i in range(len(sizes))]
+    with open(os.path.join(directory, 'name.txt')) as f:
+        name = f.read()
+    return Dataset(num_classes=int(meta[0]), g=g, par_li=par_li, name=name)
+
+
 def reddit_synth(seed=0, n=153431, n_blocks=1500, train_frac=1.0):
     return make_block_dataset('reddit-synth', n, n_blocks, 602, 41, intra_deg=28, inter_deg=20,
                               seed=seed, train_frac=train_frac)

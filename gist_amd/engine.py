@@ -83,10 +83,15 @@ class ParamArena(object):
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
     __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
-                 'row_blocks', 'batcher', 'parts')
+                 'row_blocks', 'batcher', 'parts', 'z0_dropped')
 
     def __init__(self):
         self.ready = True
+        # CONTRACT: one training step per extraction.  When layer 0's dropout was folded into the extraction's
+        # feature gather, Z[0]'s left half holds dropout(features) afterwards, not the features: a second
+        # training step on the same Batch object would aggregate and drop the dropped values again.
+        # z0_dropped records that state and train_step refuses such a batch (re-extract it instead).
+        self.z0_dropped = False
         self.row_blocks = None      # int32 [n_blocks + 1]: row ranges of the batch's METIS parts
         self.batcher = None         # set on lazy batches: who extracts them
         self.parts = None           # (node_part [N, 2], part_slot [parts, 2], batch index) -- sampler
@@ -368,6 +373,8 @@ class SageEngine(object):
         rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
                               eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())
         _lib.check(rc, 'gist_sage_step')
+        if not b.ready and train and self.fuse and self.p_drop > 0.0 and self.H[0] is not None:
+            b.z0_dropped = True      # (layer 0's mask went into the feature gather: Batch contract)
         b.ready = True
         return self.loss
 
@@ -444,6 +451,7 @@ class SageEngine(object):
             dr = (self.H[0][:n, :i0], self.p_drop, self.seed, offs[0], 2 * i0) if fold[0] else None
             b.batcher.extract(b.ids, self.z0_left(n), drop=dr)
             b.ready = True
+            b.z0_dropped = dr is not None
         self._logit_slabs_n = 1
         for k, (i, o) in enumerate(self.dims):
             z = self.Z[k][:n]
@@ -595,6 +603,10 @@ class SageEngine(object):
         """One iteration of the reference loop (cluster_gcn_ist_distrib.py:408-417).
         Returns the device loss tensor; nothing synchronises with the host.  With a native
         plan attached (attach_batcher) and no mask this is a single gist_sage_step call."""
+        if b.ready and getattr(b, 'z0_dropped', False):
+            raise RuntimeError('gist_amd: this Batch was already stepped once with layer 0\'s dropout folded into '
+                               'its extraction (Z[0] holds dropped features); one training step per extraction -- '
+                               'take a fresh batch from the iterator')
         if self.plan is not None and mask is None and hip._prof is None:
             return self._native_step(b, lr, weight_decay, train=True)
         self.forward(b, training=True, _step=mask is None)

@@ -36,16 +36,15 @@ from .engine import ParamArena, SageEngine, dims_for
 
 def create_partition(num_subnet, size, rng=_pyrandom):
     """cluster_gcn_ist_distrib.py:51-65: shuffle range(size) with python's `random`, deal
-    round-robin to the sites; returns [(idx, full_idx)] as LongTensors."""
-    possible_indices = [x for x in range(size)]
-    rng.shuffle(possible_indices)
-    feats_idx_list = [[] for _ in range(num_subnet)]
-    for i in range(size):
-        feats_idx_list[i % num_subnet].append(possible_indices[i])
+    round-robin to the sites; returns [(idx, full_idx)] as LongTensors.  The consumption of
+    `random` (one shuffle of a `size`-long list) and the deal order are the parity surface."""
+    order = list(range(size))
+    rng.shuffle(order)
+    # site s takes order[s], order[s + S], order[s + 2S], ... (round-robin deal)
     out = []
-    for idx in feats_idx_list:
-        idx = torch.LongTensor(idx)
-        out.append((idx, torch.cat((idx, idx + size))))
+    for s in range(num_subnet):
+        own = torch.LongTensor(order[s::num_subnet])
+        out.append((own, torch.cat((own, own + size))))
     return out
 
 
@@ -87,24 +86,6 @@ class TorchDistComm(object):
 
     def barrier(self):
         dist.barrier(group=self.group)
-
-
-class HostStagedComm(TorchDistComm):
-    """VALIDATION ONLY: S ranks that share ONE GPU (a 1-GPU box; the reference's launcher does
-    the same with `--cuda-id 0`, script/reddit/run_ist_distrib.sh:16-18).  RCCL refuses two
-    ranks on one device, so the process group is `gloo` and the payloads are staged through the
-    host; everything around the collective -- HipBlocks gather/scatter, the replicated base, the
-    schedule -- is the product path.  Never used for a reported number."""
-
-    def all_gather_flat(self, out, inp):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
-        out.copy_(o)
-
-    def broadcast(self, t, src=0):
-        c = t.cpu()
-        dist.broadcast(c, src=src, group=self.group)
-        t.copy_(c)
 
 
 class LocalCommGroup(object):

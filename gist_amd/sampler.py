@@ -276,5 +276,7 @@ class EngineClusterIter(ClusterIter):
                 batch.parts = (self._node_part, self._part_tables, self.n)
             self.n += 1
             return batch
+        if self.engine is not None:          # every batch of the epoch that just ended was extracted completely
+            self.engine.check_extract()
         random.shuffle(self.par_li)
         raise StopIteration

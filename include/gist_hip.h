@@ -637,7 +637,12 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
  * (cluster_gcn_ist_distrib.py:410-417 / cluster_gcn/cluster_gcn.py:98-105).
  * `plan` is HOST memory; drop_offset is the dropout counter base for this step
  * (layer k uses drop_offset + sum_{j<k} round_up(n*2*n_in_j, 2)); adam_step is 1-based.
- * ~45 kernel launches, no host synchronisation. */
+ * No host synchronisation.
+ * CONTRACT -- one TRAIN step per extraction: with plan->fuse and dropout, a GIST_STEP_EXTRACT | GIST_STEP_TRAIN
+ * call folds layer 0's mask into the feature gather (layer[0].Z's left half then holds dropout(features), hsrc[0]
+ * the features).  A later GIST_STEP_TRAIN call WITHOUT GIST_STEP_EXTRACT on the same buffers would aggregate and
+ * drop those dropped values again: re-extract (pass GIST_STEP_EXTRACT) for every training step.  Forward-only calls
+ * (no GIST_STEP_TRAIN) on extracted buffers are fine. */
 int gist_sage_step(const gist_step_plan *plan, const int32_t *ids, int64_t n,
                    uint64_t drop_offset, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t adam_step, int flags, gist_stream_t stream);

@@ -5,7 +5,7 @@
 Every rank is its own process on cuda:0 (like the reference's launcher with `--cuda-id 0`,
 script/reddit/run_ist_distrib.sh:16-18) with the PRODUCT block movers (gist_amd.ist.HipBlocks:
 gist_block_gather/scatter_f32, gist_mean_rows_f32) and the product wrapper / train loop; the
-one collective is host-staged over gloo (gist_amd.ist.HostStagedComm) because RCCL refuses two
+one collective is host-staged over gloo (tests/host_staged_comm.py) because RCCL refuses two
 ranks on one device.  mode g4: dispatch / sync choreography against the reference's
 DistributedGNNWrapper run (tests/golden/G4_ist_*.npz).  mode g6: the whole train() loop against
 the reference's run (tests/golden/G6_e2e_ist_S*.npz).  Writes {"rank", "errors": [...]}.
@@ -20,6 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tests.host_staged_comm import HostStagedComm  # noqa: E402
 TOL = 1e-4
 
 
@@ -37,7 +38,7 @@ def run_g4(rank, S, d, errs):
                               use_layernorm=True)
     base_init = _params(d, 'base0_', L + 1) if rank == 0 else None
     w = ist.DistributedGNNWrapper(args, None, int(d['fin']), int(d['ncls']), dev,
-                                  base_init=base_init, comm=ist.HostStagedComm())
+                                  base_init=base_init, comm=HostStagedComm())
     assert isinstance(w.blocks, ist.HipBlocks)
 
     def same(a, b, what, tol=0.0):
@@ -101,7 +102,7 @@ def run_g6(rank, S, d, errs):
     model = ist.DistributedGNNWrapper(
         args, None, fin, ncls, dev,
         base_init=_params(d, 'r0_base_init_', L + 1) if rank == 0 else None,
-        comm=ist.HostStagedComm(), n_max=it.n_max)
+        comm=HostStagedComm(), n_max=it.n_max)
     assert isinstance(model.blocks, ist.HipBlocks)
     model.ini_sync_dispatch_model()
     for k in range(L + 1):

@@ -21,7 +21,9 @@ def test_launcher_propagates_rank_failure():
                         '--warmup', '1'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert 'rank process' in r.stderr and 'stopping the others' in r.stderr
-    assert not [l for l in r.stdout.split('\n') if l.startswith('{')]      # no result line
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{')]         # no result line: one error line, rank 0's
+    # (rank 0 prints the error line unless another rank's exit got it stopped first)
+    assert len(lines) <= 1 and all('"value": null' in l and 'device_count' in l for l in lines)
 
 
 def test_launcher_is_not_used_under_torchrun_env():
@@ -104,3 +106,73 @@ def test_launcher_deadline_stops_hung_ranks(tmp_path):
     assert 'deadline' in r.stderr
     pids = [int(open(os.path.join(str(tmp_path), f)).read()) for f in os.listdir(str(tmp_path)) if f.isdigit()]
     assert len(pids) == 2 and _ps_alive(pids) == []
+
+
+def test_launcher_exit_code_is_the_failing_ranks(tmp_path):
+    """rank 0 exits 3 while the others sleep -- the launcher stops them and exits with 3
+    itself, without a traceback (it used to crash in its own bookkeeping and exit 1)."""
+    cmd = ("import os, sys, time\n"
+           "open(os.environ['PIDDIR'] + '/' + os.environ['RANK'], 'w').write(str(os.getpid()))\n"
+           "sys.exit(3) if os.environ['RANK'] == '0' else time.sleep(600)\n")
+    env = _launcher_env(tmp_path)
+    env['GIST_BENCH_RANK_CMD'] = cmd
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3'], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert 'Traceback' not in r.stderr, r.stderr
+    assert 'rank process 0 exited with 3' in r.stderr
+    pids = [int(open(os.path.join(str(tmp_path), f)).read()) for f in os.listdir(str(tmp_path)) if f.isdigit()]
+    assert len(pids) == 3 and _ps_alive(pids) == []
+
+
+def _error_lines(stdout):
+    import json
+    out = []
+    for l in stdout.split('\n'):
+        if l.startswith('{'):
+            out.append(json.loads(l))
+    return out
+
+
+def test_rank_fails_fast_without_one_gpu_per_rank():
+    """First-contact hardening: a rank of a 2-rank run on a node that shows fewer than 2 GPUs prints ONE
+    JSON error line (value null) and exits 2 -- before any rendez-vous, dataset work or GPU call."""
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('two GPUs visible')
+    import time
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', LOCAL_WORLD_SIZE='2',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29871')
+    env.pop('GIST_BENCH_SHARED_GPU', None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr)
+    lines = _error_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]['value'] is None
+    assert 'device_count' in lines[0]['error'] and lines[0]['rank'] == 0
+    assert time.time() - t0 < 120
+
+
+def test_rank_rendezvous_times_out_with_an_error_line():
+    """A peer that never joins: init_process_group's time-out (or the watchdog behind it) ends the rank
+    with a JSON error line naming the rendez-vous and a non-zero exit code, instead of waiting forever.
+    Exercised through the shared-GPU validation mode, whose rendez-vous (gloo) precedes every GPU call."""
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', LOCAL_WORLD_SIZE='2',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GIST_BENCH_SHARED_GPU='1',
+               GIST_BENCH_RENDEZVOUS_TIMEOUT_S='4', GIST_BENCH_SHM=os.environ.get('TMPDIR', '/tmp'))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dataset', 'reddit-synth'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    import shutil
+    shutil.rmtree(os.path.join(env['GIST_BENCH_SHM'], 'gist_bench_reddit-synth_%d' % port), ignore_errors=True)
+    assert r.returncode in (3, 124), (r.returncode, r.stderr[-2000:])
+    lines = _error_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]['value'] is None and lines[0].get('phase') == 'rendezvous', lines
+    assert time.time() - t0 < 300

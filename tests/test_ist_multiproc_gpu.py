@@ -1,7 +1,7 @@
 """GPU, multi-process: GIST with one PROCESS per rank, all on the box's one GPU, with the product
 block movers (HipBlocks) and the product wrapper / train loop -- the gather -> all-gather ->
 scatter chain outside LocalCommGroup.  The collective is host-staged over gloo
-(gist_amd.ist.HostStagedComm; RCCL refuses two ranks on one device), everything around it is the
+(tests/host_staged_comm.py; RCCL refuses two ranks on one device), everything around it is the
 path the N-GPU run takes.  Checked against the reference's own runs: G4 (dispatch / sync under
 gloo) and G6 (whole train() loop).  Also: `python bench.py --gpus 2` starts its own rank
 processes (no torchrun) and prints one JSON line.
