@@ -463,7 +463,8 @@ def test_config5_ultra_wide_H32768_S8():
     assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max())
     errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in zip(m0.sub.export(), params)])
     stats = (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
-    _parity_ok('config5_sub_step_vs_oracle', 'bf16x3', 4096, stats)
+    _record_parity('config5_sub_step_vs_oracle', 'bf16x3', 4096, stats)
+    assert stats[2] <= 3 * 0.01
     m0.sub.params.copy_(saved)
     m0.sub.reset_optimizer()
     del saved, params, errs
@@ -575,25 +576,15 @@ def _steps_vs_oracle(ds, batch_parts, n_hidden, n_layers, n_steps, p_seed):
                        max=float(errs.max()))
 
 
-# Post-Adam parameters against the reference at the metric's widths.  Bars = 2x the values measured on
-# MI355X for each case (profiles/r03_parity_stats.txt: mean |diff|, fraction of weights above 1e-4;
-# GIST_PARITY_STATS=<file> appends the statistics of a run).  Round 2 used one bar for all: 1e-5 / 2e-2.
+# Parameter-level comparisons of two GPU variants of the same step: bars = 2x the values measured on MI355X
+# (mean |diff|, fraction of weights above 1e-4; GIST_PARITY_STATS=<file> appends the statistics of a run).
+# The FREE-RUNNING post-Adam comparison with the oracle that lived here (bars 5e-5 / 9e-2 after two steps) is gone:
+# it was chaotic by construction (Adam's first update is lr * sign(g); a ReLU input within rounding of zero flips in
+# any two fp32 implementations) and a bar at 2x the observation could not catch a regression.  Its place is taken by
+# tests/test_timed_step_parity_gpu.py: five TEACHER-FORCED steps of the timed configuration (dropout 0.2, fused
+# step, default GEMM mode) with the pre-Adam gradients at 2e-5 relative / 1e-4 max-norm and the post-step
+# parameters at 1e-4 max-norm; the statistics of the free-running runs are still recorded for the curious.
 PARITY_BARS = {
-    # GPU step vs the CPU oracle after two Adam steps.  CHAOTIC: Adam's first update is lr * sign(g) for all
-    # but rounding-level gradients, and a handful of ReLU inputs within rounding of zero take different masks
-    # in any two fp32 implementations (the oracle sums in another order), which moves whole rows of the
-    # gradient by ~1e-3 of their norm.  Seed study at width 1024 (profiles/r03_parity_stats.txt): the SAME
-    # kernels give mean 4.9e-8 .. 2.5e-5, fraction 3.9e-5 .. 4.5e-2 over three seeds, fp32 kernel and bf16x3
-    # kernel trading places.  Bar = 2x the worst observed; the gradient parity proper is the float64 test.
-    ('metric_config_vs_oracle', 'f32', 4096): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 4096): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 2048): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 1024): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'bf16x3', 512): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'f16x3', 4096): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'f16x3', 2048): (5e-5, 9e-2),
-    ('metric_config_vs_oracle', 'f16x3', 1024): (5e-5, 9e-2),
-    ('config5_sub_step_vs_oracle', 'bf16x3', 4096): (5e-5, 9e-2),
     # two GPU variants of the same step (same masks unless a projection's rounding differs): 2x measured
     ('kept_vs_per_call_splits', 'f16x3', 4096): (2.0e-8, 2.2e-5),
     ('kept_vs_per_call_splits', 'bf16x3', 4096): (6e-9, 6e-6),      # (dW_0: 3 k slices summed in Adam vs in the call's own order)
@@ -715,7 +706,8 @@ def test_metric_config_hidden4096_vs_oracle(mode, hidden):
         errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in
                                zip(eng.arena.export(), params)])
         stats = (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
-        _parity_ok('metric_config_vs_oracle', mode, hidden, stats)
+        _record_parity('metric_config_vs_oracle', mode, hidden, stats)
+        assert stats[2] <= 3 * 0.01          # never more than lr per step
     finally:
         hip.gemm_mode(prev)
 

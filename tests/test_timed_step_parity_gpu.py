@@ -1,0 +1,191 @@
+"""GPU: oracle parity of THE STEP THAT IS TIMED -- the fused native step (gist_sage_step, plan.fuse = 1), dropout 0.2,
+default GEMM mode (bf16x3), on the configurations bench.py reports -- and a chaos-free multi-step statement.
+
+Reference: cluster_gcn/cluster_gcn_ist_distrib.py:405-417 (zero_grad, forward with nn.Dropout on [h | ah]
+modules.py:227-231, CE, backward, Adam step).
+
+Teacher forcing: before EVERY step the oracle's parameters and Adam state (exp_avg, exp_avg_sq, step count) are
+copied into the engine's arena, so each of the 5 steps starts from identical state and a rounding-level difference
+of one step cannot grow into a different trajectory (Adam's first updates are +-lr whatever the gradient's size).
+The dropout masks are not stored anywhere on the GPU: the test rebuilds them on the host from the generator's
+definition (seed, layer offset, element index -> splitmix64) and hands them to the oracle as `drop_masks`.
+
+Per step, against O.train_step(..., drop_masks=..., drop_p=0.2):
+  * loss and logits at 1e-4 (relative to max(1, |ref|));
+  * the PRE-Adam gradients (Adam writes the summed split-K slabs / bias chunk sums back to the gradient arena):
+    every tensor within 2e-5 of the oracle's in relative L2 norm and within 1e-4 x max|g| in max-norm;
+  * the POST-step parameters in max-norm 1e-4 wherever Adam's update is a well-conditioned function of the gradient
+    (|g| >= 1e-6: with exp_avg_sq ~ g^2 the update g / (|g| + 1e-8) of a gradient at the 1e-8 level turns a 1e-9
+    difference into a different step of up to lr -- in ANY two fp32 implementations); those ill-conditioned
+    elements are counted (< 1 %) and bounded by 2 lr;
+  * the Adam kernel itself on ALL elements: float64 Adam applied on the host to the GPU's own gradient reproduces
+    the GPU's parameters to 2e-7.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+TOL = 1e-4
+P_DROP = 0.2
+LR = 0.01
+
+
+def _mask(n, d, p, seed, offset):
+    """The step's dropout mask of one layer (gist_dropout_f32's generator: one splitmix64 per element pair)."""
+    idx = np.arange(n * d, dtype=np.uint64) + np.uint64(offset)
+    with np.errstate(over='ignore'):
+        z = (idx >> np.uint64(1)) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    w = np.where(idx & np.uint64(1), z >> np.uint64(32), z & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(n, d).astype(np.float32)
+
+
+def _flat(pairs):
+    return np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for (W, b) in pairs]).astype(np.float32)
+
+
+def _teacher_force(eng, params, opt):
+    A = eng.arena
+    A.params.copy_(torch.from_numpy(_flat(params)))
+    A.exp_avg.copy_(torch.from_numpy(_flat(opt['m'])))
+    A.exp_avg_sq.copy_(torch.from_numpy(_flat(opt['v'])))
+    A.step = int(opt['step'])
+
+
+def _adam64(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    p, g, m, v = (a.astype(np.float64) for a in (p, g, m, v))
+    m = m + (1 - beta1) * (g - m)
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+    return p - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
+
+
+def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
+    from gist_amd import hip
+    from gist_amd.engine import SageEngine, dims_for
+    from gist_amd.sampler import EngineClusterIter
+    from oracle import gist_oracle as O
+    from oracle import train_oracle as TO
+    prev = hip.gemm_mode()
+    hip.gemm_mode(mode)
+    try:
+        g = ds.g
+        random.seed(seed)
+        it = EngineClusterIter(ds.name, g, len(ds.par_li), batch_parts,
+                               np.arange(g.number_of_nodes(), dtype=np.int64),
+                               par_li=[p.copy() for p in ds.par_li], device=DEV)
+        F_, C_ = g.ndata['feat'].shape[1], ds.num_classes
+        dims = dims_for(F_, hidden, C_, n_layers)
+        eng = SageEngine(dims, True, P_DROP, it.n_max, DEV, seed=seed + 11)
+        assert eng.fuse                                   # the fused sequence: what bench.py times
+        rs = np.random.RandomState(seed)
+        params = []
+        for (i, o) in dims:
+            s = 1.0 / np.sqrt(2 * i)
+            params.append((rs.uniform(-s, s, (o, 2 * i)).astype(np.float32),
+                           rs.uniform(-s, s, o).astype(np.float32)))
+        it.bind(eng)
+        assert eng.plan is not None                       # native step driver (gist_sage_step)
+        tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
+                           g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
+        opt = O.new_opt_state(params)
+        report = []
+        for j, batch in enumerate(it):
+            _teacher_force(eng, params, opt)
+            before = [(W.copy(), b.copy()) for (W, b) in params]
+            m_before = [(a.copy(), b.copy()) for (a, b) in opt['m']]
+            v_before = [(a.copy(), b.copy()) for (a, b) in opt['v']]
+            off = eng.drop_calls
+            loss = eng.train_step(batch, LR, 0.0)
+            n = batch.n
+            logits = eng.logits(n).cpu().numpy()
+            # the masks of this step, rebuilt on the host
+            masks, o_ = [], off
+            for (i, o) in dims:
+                masks.append(_mask(n, 2 * i, P_DROP, eng.seed, o_))
+                numel = n * 2 * i
+                o_ += numel + (numel & 1)
+            assert o_ == eng.drop_calls
+            b = tg.batch(it.batch_ids(j))
+            assert np.array_equal(batch.rowptr.cpu().numpy(), b[0])
+            ref_loss, ref_logits, ref_grads = O.train_step(b[0], b[1], b[2], b[3], b[4], b[5], params, opt,
+                                                           True, LR, drop_masks=masks, drop_p=P_DROP)
+            t = opt['step']
+            assert abs(float(loss.item()) - float(ref_loss)) < TOL * max(1.0, abs(float(ref_loss))), (j, float(loss.item()), ref_loss)
+            assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max()), j
+            got_p = eng.arena.export()
+            worst_rel, ill, n_all = 0.0, 0, 0
+            for k in range(len(dims)):
+                for name, gg, gr, pg, pr, pb, mb, vb in (
+                        ('W', eng.arena.dW[k].cpu().numpy(), ref_grads[k][0], got_p[k][0], params[k][0],
+                         before[k][0], m_before[k][0], v_before[k][0]),
+                        ('b', eng.arena.db[k].cpu().numpy(), ref_grads[k][1], got_p[k][1], params[k][1],
+                         before[k][1], m_before[k][1], v_before[k][1])):
+                    rel = float(np.linalg.norm((gg - gr).astype(np.float64)) / max(np.linalg.norm(gr.astype(np.float64)), 1e-30))
+                    assert rel < 2e-5, (j, k, name, rel)
+                    assert np.abs(gg - gr).max() <= TOL * np.abs(gr).max(), (j, k, name)
+                    worst_rel = max(worst_rel, rel)
+                    # post-step parameters: max-norm where Adam is well-conditioned; the rest counted and bounded
+                    well = np.abs(gr) >= 1e-6
+                    d = np.abs(pg - pr)
+                    assert d[well].max(initial=0.0) < TOL, (j, k, name, float(d[well].max(initial=0.0)))
+                    assert d.max(initial=0.0) <= 2 * LR + 1e-6, (j, k, name)
+                    ill += int((~well).sum())
+                    n_all += well.size
+                    # the Adam kernel on ALL elements, from the GPU's own gradient
+                    p64 = _adam64(pb, gg, mb, vb, t, LR)
+                    assert np.abs(pg.astype(np.float64) - p64).max() < 2e-7, (j, k, name)
+            assert ill < 0.01 * n_all, (ill, n_all)
+            report.append((j, float(ref_loss), worst_rel, ill / float(n_all)))
+            if j == n_steps - 1:
+                break
+        return report
+    finally:
+        hip.gemm_mode(prev)
+
+
+@pytest.mark.parametrize('hidden', [4096, 512])
+def test_config3_timed_step_dropout_teacher_forced(hidden):
+    """BASELINE config 3: the default bench workload (Reddit-like, L=2, H=4096: kept bf16x3 splits, block-dense
+    aggregation) and the per-rank width of its 8-GPU point (512: convert-on-load bf16x3 + fp32 kernels, LDS gather)."""
+    from gist_amd import datasets
+    rep = _run(datasets.reddit_synth(seed=0), 20, hidden, 2, 5, seed=3)
+    assert len(rep) == 5
+
+
+def test_config2_timed_step_dropout_teacher_forced():
+    """BASELINE config 2: Reddit-like, hidden 256, 4 hidden layers (--config 2)."""
+    from gist_amd import datasets
+    rep = _run(datasets.reddit_synth(seed=0), 20, 256, 4, 5, seed=4)
+    assert len(rep) == 5
+
+
+def test_config4_full_size_timed_step_dropout_teacher_forced():
+    """BASELINE config 4 at its FULL size: the Amazon-like graph with 1 709 997 training nodes in 15 000 parts
+    (F=100, C=47), batch of 10 parts, the per-rank sub-GCN of the 8-GPU run (width 512, 4 hidden layers).  Exercises
+    the resident-graph scale (int32 offsets of a ~40 M-edge CSR, part tables of 15 000 parts, 1 500 batches per
+    epoch) that the 171 k-node case of test_e2e_gpu.py does not; plus structural properties of the epoch."""
+    from gist_amd import datasets
+    from gist_amd.sampler import EngineClusterIter
+    ds = datasets.amazon_synth(seed=1)
+    g = ds.g
+    assert g.number_of_nodes() == 1709997 and len(ds.par_li) == 15000
+    rep = _run(ds, 10, 512, 4, 3, seed=5)
+    assert len(rep) == 3
+    # properties of one epoch at this size: every node appears in exactly one batch; the batches' induced edge
+    # counts never exceed the extraction buffers
+    random.seed(6)
+    it = EngineClusterIter(ds.name, g, len(ds.par_li), 10, np.arange(g.number_of_nodes(), dtype=np.int64),
+                           par_li=[p.copy() for p in ds.par_li], device=DEV)
+    assert len(it) == 1500
+    seen = np.zeros(g.number_of_nodes(), np.int32)
+    for j in range(len(it)):
+        np.add.at(seen, it.batch_ids(j), 1)
+    assert seen.min() == 1 and seen.max() == 1
