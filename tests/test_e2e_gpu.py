@@ -464,7 +464,7 @@ def test_config5_ultra_wide_H32768_S8():
     errs = np.concatenate([np.abs(W - Wr).ravel() for (W, _), (Wr, _) in zip(m0.sub.export(), params)])
     stats = (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
     _record_parity('config5_sub_step_vs_oracle', 'bf16x3', 4096, stats)
-    assert stats[2] <= 3 * 0.01
+    assert stats[2] <= 2 * 0.01 + 1e-6
     m0.sub.params.copy_(saved)
     m0.sub.reset_optimizer()
     del saved, params, errs
@@ -707,7 +707,7 @@ def test_metric_config_hidden4096_vs_oracle(mode, hidden):
                                zip(eng.arena.export(), params)])
         stats = (float(errs.mean()), float((errs > TOL).mean()), float(errs.max()))
         _record_parity('metric_config_vs_oracle', mode, hidden, stats)
-        assert stats[2] <= 3 * 0.01          # never more than lr per step
+        assert stats[2] <= 4 * 0.01 + 1e-6   # two Adam steps: at most 2 lr apart per step
     finally:
         hip.gemm_mode(prev)
 

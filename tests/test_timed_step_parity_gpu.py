@@ -14,10 +14,14 @@ Per step, against O.train_step(..., drop_masks=..., drop_p=0.2):
   * loss and logits at 1e-4 (relative to max(1, |ref|));
   * the PRE-Adam gradients (Adam writes the summed split-K slabs / bias chunk sums back to the gradient arena):
     every tensor within 2e-5 of the oracle's in relative L2 norm and within 1e-4 x max|g| in max-norm;
-  * the POST-step parameters in max-norm 1e-4 wherever Adam's update is a well-conditioned function of the gradient
-    (|g| >= 1e-6: with exp_avg_sq ~ g^2 the update g / (|g| + 1e-8) of a gradient at the 1e-8 level turns a 1e-9
-    difference into a different step of up to lr -- in ANY two fp32 implementations); those ill-conditioned
-    elements are counted (< 1 %) and bounded by 2 lr;
+  * the POST-step parameters in max-norm 1e-4; an element may exceed it only where Adam's update is an
+    ill-conditioned function of the gradient (|g| < 1e-7, ten times Adam's eps: with exp_avg_sq ~ g^2 the update
+    g / (|g| + 1e-8) turns a 1e-9 difference into a different step of up to lr -- in ANY two fp32 implementations);
+    those elements are counted (< 1 %) and bounded by 2 lr;
+  * ReLU: the GPU's and the oracle's masks agree on every activation except LayerNorm outputs within 4e-6 of zero
+    (at most 8 per layer and step); on those the oracle's backward follows the GPU's decision -- one such flip
+    moves a 512-wide layer's weight gradient by 1e-3 of its norm, which is a property of ReLU, not of either
+    implementation;
   * the Adam kernel itself on ALL elements: float64 Adam applied on the host to the GPU's own gradient reproduces
     the GPU's parameters to 2e-7.
 """
@@ -96,7 +100,7 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
                            g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
         opt = O.new_opt_state(params)
-        report = []
+        report, flips = [], []
         for j, batch in enumerate(it):
             _teacher_force(eng, params, opt)
             before = [(W.copy(), b.copy()) for (W, b) in params]
@@ -115,8 +119,34 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
             assert o_ == eng.drop_calls
             b = tg.batch(it.batch_ids(j))
             assert np.array_equal(batch.rowptr.cpu().numpy(), b[0])
-            ref_loss, ref_logits, ref_grads = O.train_step(b[0], b[1], b[2], b[3], b[4], b[5], params, opt,
-                                                           True, LR, drop_masks=masks, drop_p=P_DROP)
+            # the oracle's step, composed from its own parts (O.train_step's body) so that the ReLU decision of the
+            # handful of LayerNorm outputs WITHIN ROUNDING OF ZERO can follow the GPU's: everywhere else the two
+            # ReLU masks must agree, and the ambiguous elements are counted
+            ref_logits, caches = O.gcn_forward(b[0], b[1], b[4], params, True, drop_masks=masks, drop_p=P_DROP)
+            for k in range(len(dims) - 1):
+                i_next = dims[k + 1][0]
+                pos_gpu = (eng.Z[k + 1][:n, :i_next] > 0)
+                if eng.H[k + 1] is not None:           # the undropped copy the fused producers leave
+                    pos_gpu = pos_gpu | (eng.H[k + 1][:n, :i_next] > 0)
+                pos_gpu = pos_gpu.cpu().numpy()
+                yhat = caches[k]['yhat']
+                pos_ref = caches[k]['out'] > 0
+                differ = pos_gpu != pos_ref
+                # a dropped element reads 0 in Z's left half whatever its sign: only trust "GPU says positive" there
+                if eng.H[k + 1] is None:
+                    differ &= pos_gpu
+                assert np.abs(yhat[differ]).max(initial=0.0) < 4e-6, (j, k, float(np.abs(yhat[differ]).max()))
+                assert int(differ.sum()) <= 8, (j, k, int(differ.sum()))
+                flips.append(int(differ.sum()))
+                out = caches[k]['out']
+                out[differ & pos_gpu] = np.float32(1e-30)          # backward reads only (out > 0)
+                out[differ & ~pos_gpu] = 0.0
+            ref_loss, dlog = O.cross_entropy(ref_logits, b[5])
+            ref_grads = O.gcn_backward(caches, dlog, b[2], b[3])
+            opt['step'] += 1
+            for k, ((W, bb), (dW, db)) in enumerate(zip(params, ref_grads)):
+                O.adam_step(W, dW, opt['m'][k][0], opt['v'][k][0], opt['step'], LR)
+                O.adam_step(bb, db, opt['m'][k][1], opt['v'][k][1], opt['step'], LR)
             t = opt['step']
             assert abs(float(loss.item()) - float(ref_loss)) < TOL * max(1.0, abs(float(ref_loss))), (j, float(loss.item()), ref_loss)
             assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max()), j
@@ -132,13 +162,16 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
                     assert rel < 2e-5, (j, k, name, rel)
                     assert np.abs(gg - gr).max() <= TOL * np.abs(gr).max(), (j, k, name)
                     worst_rel = max(worst_rel, rel)
-                    # post-step parameters: max-norm where Adam is well-conditioned; the rest counted and bounded
-                    well = np.abs(gr) >= 1e-6
+                    # post-step parameters in max-norm 1e-4.  The only elements allowed above it are those where Adam's
+                    # update is an ill-conditioned function of the gradient -- |g| within 10x of Adam's eps = 1e-8, where
+                    # g / (|g| + eps) turns a 1e-9 difference into a different step in ANY two fp32 implementations --
+                    # they are counted (< 1 % of the tensor) and can differ by at most 2 lr
                     d = np.abs(pg - pr)
-                    assert d[well].max(initial=0.0) < TOL, (j, k, name, float(d[well].max(initial=0.0)))
+                    above = d >= TOL
+                    assert np.abs(gr[above]).max(initial=0.0) < 1e-7, (j, k, name, float(np.abs(gr[above]).max(initial=0.0)))
                     assert d.max(initial=0.0) <= 2 * LR + 1e-6, (j, k, name)
-                    ill += int((~well).sum())
-                    n_all += well.size
+                    ill += int(above.sum())
+                    n_all += d.size
                     # the Adam kernel on ALL elements, from the GPU's own gradient
                     p64 = _adam64(pb, gg, mb, vb, t, LR)
                     assert np.abs(pg.astype(np.float64) - p64).max() < 2e-7, (j, k, name)
