@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GistLibraryError(RuntimeError):
@@ -92,6 +92,11 @@ SIGNATURES = {
     'gist_row_chunks16': (_i64, [_i64]),
     'gist_ln_relu_bwd_colsum_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p, _p]),
     'gist_colsum_chunks_f32': (_int, [_p, _i64, _i64, _p, _p]),
+    'gist_class_layer_takes': (_int, [_i64, _i64, _i64, _i64, _i64, _p, _p]),
+    'gist_class_layer_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _f, _u64, _u64,
+                                    _p, _i64, _i64, _i64, _p]),
+    'gist_class_dw_slab_bytes': (_i64, [_i64, _i64, _i64]),
+    'gist_class_dw_slabs_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     'gist_gemm_nn_dropout_colsum_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _u64, _u64,
                                                _p, _i64, _p, _p]),
     'gist_softmax_xent_slabs_f32': (_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64,
@@ -110,7 +115,7 @@ SIGNATURES = {
 
 GIST_MAX_LAYERS = 16
 TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_splits': 4,
-        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8}
+        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 

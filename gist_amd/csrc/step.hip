@@ -292,6 +292,11 @@ FusedLayout fused_layout(const gist_step_plan *p, char *base, float *partials) {
     for (int k = 0; k < L1; ++k) {
         const gist_layer_desc &l = p->layer[k];
         f.dw_bytes[k] = slab_need(l.n_out, 2 * l.n_in, p->n_max, true);
+        if (k == L1 - 1 && gist_class_layer_takes(p->n_max, l.n_out, 2 * l.n_in, 2 * l.n_in, 2 * l.n_in, nullptr, nullptr)) {
+            // the fused class layer leaves dW as one slab per 128 rows (gist_class_dw_slabs_f32)
+            const int64_t b = gist_class_dw_slab_bytes(p->n_max, l.n_out, 2 * l.n_in);
+            f.dw_bytes[k] = b > f.dw_bytes[k] ? b : f.dw_bytes[k];
+        }
         f.dw_slabs[k] = f.dw_bytes[k] > 0 ? take(f.dw_bytes[k]) : nullptr;
         f.partials[k] = partials ? partials + poff : nullptr;
         poff += ceil_div(chunks * l.n_out, 64) * 64;
@@ -419,6 +424,17 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     }
     const float keep = drop ? 1.0f / (1.0f - p->p_drop) : 1.f;
     const uint64_t sm = p->seed * 0x9E3779B97F4A7C15ULL;
+    // the class layer as gist_class_layer_f32 + gist_class_dw_slabs_f32 (projection, CE, dZ with its mask and the
+    // bias gradient's chunk sums in one launch, dW as slabs for the optimiser) instead of four launches
+    bool cls_fused = false;
+    {
+        const gist_layer_desc &l = p->layer[L1 - 1];
+        cls_fused = train && defer && plain[L1 - 1] && p->ldc <= 64 && (offs[L1 - 1] & 1) == 0 &&
+                    tune(GIST_TUNE_CLASS_FUSED) >= 0.0 &&
+                    gist_class_layer_takes(n, l.n_out, 2 * l.n_in, l.ldz, 2 * l.n_in, l.Z, l.W) == 1 &&
+                    fl.dw_slabs[L1 - 1] != nullptr &&
+                    fl.dw_bytes[L1 - 1] >= gist_class_dw_slab_bytes(n, l.n_out, 2 * l.n_in);
+    }
     // layers on split operands (their dZ comes from a split projection, unmasked): can the reverse aggregation
     // carry dZ_k's mask instead of a dropout pass over dZ_k?
     bool bwd_fold_split[GIST_MAX_LAYERS];
@@ -568,6 +584,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         } else {
             if (drop && !fwd_fold[k])
                 GIST_TRY(gist_dropout_f32(l.Z, l.ldz, n, 2 * l.n_in, p->p_drop, p->seed, offs[k], s));
+            if (cls_fused && k == L1 - 1) continue;      // (projection, loss and dZ follow in one launch)
             Scope sc(p->timer, 1, n, l.n_out, 2 * l.n_in, st);
             if (defer && k == L1 - 1 && fl.logit_slabs != nullptr) {      // the loss kernel sums the slabs
                 GIST_TRY(gemm_slabs(0, l.Z, l.ldz, l.W, 2 * l.n_in, l.b, l.Y, l.ldy, n, l.n_out, 2 * l.n_in,
@@ -609,6 +626,13 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     const gist_layer_desc &last = p->layer[L1 - 1];
     // the optimiser kernel reduces the loss when it runs with deferred work anyway
     const bool loss_in_adam = train && defer;
+    if (cls_fused) {
+        Scope sc(p->timer, 1, n, (L1 > 1 ? 2 : 1) * last.n_out, 2 * last.n_in, st);
+        GIST_TRY(gist_class_layer_f32(last.Z, last.ldz, last.W, 2 * last.n_in, last.b, p->labels, n, last.Y, last.ldy,
+                                      p->dlogits, p->ldc, p->row_loss, L1 > 1 ? p->dZ : nullptr, 2 * last.n_in,
+                                      drop ? p->p_drop : 0.f, p->seed, offs[L1 - 1], fl.partials[L1 - 1], n,
+                                      last.n_out, 2 * last.n_in, s));
+    } else
     GIST_TRY(softmax_xent_ex("gist_sage_step", last.Y, last.ldy, logit_slabs > 1 ? fl.logit_slabs : nullptr,
                              n * last.n_out, logit_slabs > 1 ? logit_slabs : 0, last.b, p->labels, nullptr, n,
                              p->row_loss, loss_in_adam ? nullptr : p->loss, p->dlogits, p->ldc, n,
@@ -741,7 +765,9 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
             continue;
         }
-        if (k > 0) {      // dZ with its dropout mask (or the mask left to the reverse aggregation)
+        if (cls_fused && k == L1 - 1) {
+            db_done = true;      // (dZ and the bias chunks came with the loss)
+        } else if (k > 0) {      // dZ with its dropout mask (or the mask left to the reverse aggregation)
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
             const bool chunk_db = defer && k == L1 - 1;      // the class layer's dZ kernel sees dlogits in 16-row chunks
             GIST_TRY(gemm_nn_dropout_ex("gist_sage_step", dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
@@ -752,7 +778,14 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         }
         {
             Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
-            if (defer && fl.dw_slabs[k] != nullptr) {      // the optimiser sums the slabs
+            if (cls_fused && k == L1 - 1) {
+                int32_t ns = 1;
+                GIST_TRY(gist_class_dw_slabs_f32(dy, lddy, l.Z, l.ldz, fl.dw_slabs[k], fl.dw_bytes[k], &ns, n, l.n_out,
+                                                 2 * l.n_in, s));
+                gist_grad_segment &g = segs[n_segs++];
+                g.begin = l.dW - p->grads; g.end = g.begin + l.n_out * 2 * l.n_in;
+                g.src = fl.dw_slabs[k]; g.stride = l.n_out * 2 * l.n_in; g.n_src = ns;
+            } else if (defer && fl.dw_slabs[k] != nullptr) {      // the optimiser sums the slabs
                 int ns = 1;
                 GIST_TRY(gemm_slabs(2, dy, lddy, l.Z, l.ldz, nullptr, l.dW, 2 * l.n_in, l.n_out, 2 * l.n_in, n,
                                     fl.dw_slabs[k], fl.dw_bytes[k], &ns, st));

@@ -477,8 +477,16 @@ class SageEngine(object):
                     hip.dropout_(z, self.p_drop, self.seed, offs[k])
             last = k == self.L1 - 1
             if last:
+                self._cls_fused = False
                 if self.fuse and training and _step:      # the loss kernel sums the split-K slabs
                     fb = self._fused_buffers()
+                    # gist_sage_step's class layer: projection, CE, dZ and bias chunks in ONE launch (loss_and_backward)
+                    L_ = hip._lib.load()
+                    if (fb['dw'][k] is not None and self.ldc <= 64 and (not offs or offs[k] % 2 == 0) and
+                            hip.tuning('class_fused') >= 0 and hip.class_layer_takes(z, A.W[k], o) and
+                            fb['dw'][k].numel() >= L_.gist_class_dw_slab_bytes(n, o, 2 * i)):
+                        self._cls_fused = True
+                        continue
                     if fb['logits'] is not None:
                         self._logit_slabs_n = hip.gemm_slabs('nt', z, A.W[k], A.b[k], self.Y[k][:n, :o],
                                                              fb['logits'])
@@ -523,7 +531,15 @@ class SageEngine(object):
         fb = self._fused_buffers() if defer else None
         self._segments = []
         self._loss_rows = n if defer else 0
-        if defer:
+        cls_fused = defer and getattr(self, '_cls_fused', False)
+        if cls_fused:
+            kL = self.L1 - 1
+            iL, oL = self.dims[kL]
+            dzL = self.dZ[:n * 2 * iL].view(n, 2 * iL) if kL > 0 else None
+            hip.class_layer(self.Z[kL][:n], A.W[kL], A.b[kL], b.labels, n, self.Y[kL][:n, :oL], self.dlogits[:n],
+                            self.row_loss[:n], dzL, self.p_drop if drop else 0.0, self.seed,
+                            self._drop_offsets[kL] if drop else 0, fb['partials'][kL])
+        elif defer:
             hip.softmax_xent_slabs(self.logits(n), fb['logits'], self._logit_slabs_n, A.b[-1], b.labels, None, n,
                                    self.row_loss[:n], None, self.dlogits[:n])
         else:
@@ -552,6 +568,16 @@ class SageEngine(object):
                 else:
                     hip.ln_relu_bwd(d_out, dy, rstd, dy, self.use_layernorm, True)
             bwd_fold = False
+            if cls_fused and k == self.L1 - 1:
+                db_done = True                   # (dZ and the bias chunks came with the loss)
+                ns = hip.class_dw_slabs(dy, z, fb['dw'][k])
+                self._segments.append((goff(A.dW[k]), goff(A.dW[k]) + o * 2 * i, fb['dw'][k], o * 2 * i, ns))
+                self._segments.append((goff(A.db[k]), goff(A.db[k]) + o, fb['partials'][k], o, chunks))
+                if k > 0:
+                    dz = self.dZ[:n * 2 * i].view(n, 2 * i)
+                    hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
+                             accumulate=True, row_blocks=b.row_blocks)
+                continue
             if k > 0:
                 dz = self.dZ[:n * 2 * i].view(n, 2 * i)
                 bwd_fold = (self.fuse and drop and k < self.L1 - 1 and

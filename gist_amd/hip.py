@@ -608,6 +608,52 @@ def gemm_nn_dropout_colsum_(g, w, z, p, seed, offset, g_col_partials):
     return z
 
 
+def class_layer_takes(z, w, n_classes):
+    """Does gist_class_layer_f32 take this class layer (z [n, k] its dropped input, w [C, k])?"""
+    L = _lib.load()
+    zp, ldz = _mat(z, 'z')
+    wp, ldw = _mat(w, 'w')
+    return bool(L.gist_class_layer_takes(z.shape[0], int(n_classes), z.shape[1], ldz, ldw, zp, wp))
+
+
+def class_layer(z, w, bias, labels, count, logits, d_logits, row_loss, dz, p, seed, offset, col_partials):
+    """gist_class_layer_f32: logits, CE rows, d_logits, dz = mask(d_logits . w), d_logits' 16-row chunk sums."""
+    L = _lib.load()
+    zp, ldz = _mat(z, 'z')
+    wp, ldw = _mat(w, 'w')
+    lp, ldl = _mat(logits, 'logits')
+    gp, ldg = _mat(d_logits, 'd_logits')
+    n, k = z.shape
+    c = w.shape[0]
+    dzp, lddz = (None, 0) if dz is None else _mat(dz, 'dz')
+    with _Timed('gemm', ('nt', n, 2 * c if dz is not None else c, k)):
+        rc = L.gist_class_layer_f32(zp, ldz, wp, ldw, _opt(bias, 'bias', torch.float32, c),
+                                    _vec(labels, 'labels', torch.int32, n), int(count), lp, ldl, gp, ldg,
+                                    _vec(row_loss, 'row_loss', torch.float32, n), dzp, lddz, float(p), int(seed),
+                                    int(offset),
+                                    None if col_partials is None else
+                                    _vec(col_partials, 'col_partials', torch.float32, L.gist_row_chunks16(n) * c),
+                                    n, c, k, _stream())
+    _lib.check(rc, 'gist_class_layer_f32')
+    return logits
+
+
+def class_dw_slabs(d_logits, z, slabs):
+    """gist_class_dw_slabs_f32: dW = d_logits^T . z left as 128-row slabs in `slabs`; returns their number."""
+    import ctypes
+    L = _lib.load()
+    gp, ldg = _mat(d_logits, 'd_logits')
+    zp, ldz = _mat(z, 'z')
+    n, c = d_logits.shape
+    k = z.shape[1]
+    ns = ctypes.c_int32(0)
+    with _Timed('gemm', ('tn', c, k, n)):
+        rc = L.gist_class_dw_slabs_f32(gp, ldg, zp, ldz, slabs.data_ptr(), slabs.numel() * slabs.element_size(),
+                                       ctypes.byref(ns), n, c, k, _stream())
+    _lib.check(rc, 'gist_class_dw_slabs_f32')
+    return int(ns.value)
+
+
 def softmax_xent_slabs(logits, slabs, n_slabs, bias, labels, mask, count, row_loss, loss, d_logits):
     L = _lib.load()
     lp, ldl = _mat(logits, 'logits')

@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 10 */
+int gist_abi_version(void);   /* currently 11 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -221,7 +221,8 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_SPMM_SPLIT 6    /* row split of the LDS-staged SpMM (1..8)                    */
 #define GIST_TUNE_SPMM_KERNEL 7   /* blocked SpMM: 1 = LDS gather kernel, 2 = block-dense MFMA kernel  */
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
-#define GIST_TUNE_COUNT 9
+#define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: -1 = the four-launch sequence (gist_class_layer_f32 off) */
+#define GIST_TUNE_COUNT 10
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
 
@@ -308,6 +309,31 @@ int gist_gemm_nn_dropout_colsum_f32(const float *g, int64_t ldg, const float *w,
                                     float p, uint64_t seed, uint64_t offset,
                                     void *workspace, int64_t workspace_bytes, float *g_col_partials,
                                     gist_stream_t stream);
+
+/* The CLASS LAYER of a training step in one launch (round 4): logits = z . w^T + bias (z [n_rows, k] = the layer's
+ * dropped input [h | ah], w [n_classes, k]); the mean cross entropy of gist_softmax_xent_f32 (row_loss[n_rows] = -log p,
+ * d_logits [n_rows, ldg] = (softmax - onehot) / count, zero in the pad columns; the caller reduces row_loss, e.g. inside
+ * gist_adam_segments_f32); dz [n_rows, k] = (d_logits . w) under the dropout mask of the layer's input (p, seed, offset:
+ * gist_dropout_f32's generator, element index offset + row * k + col; dz = NULL: forward and loss only); and
+ * dlogits_col_partials[gist_row_chunks16(n_rows)][n_classes] = d_logits' column sums per 16 rows (the bias gradient in
+ * chunks; NULL: skip).  fp32 FMA chains on v_mfma_f32_16x16x4_f32, one workgroup per 16 rows.
+ * gist_class_layer_takes: 1 if the shape is taken (n_classes <= 48, k % 64 == 0, k <= 4096, 16-byte aligned operands).
+ * Replaces nn.Linear of the last ISTSAGELayer (modules.py:233,299-308), nn.CrossEntropyLoss and their backward
+ * (cluster_gcn_ist_distrib.py:411-415) wrt the layer's input. */
+int gist_class_layer_takes(int64_t n_rows, int64_t n_classes, int64_t k, int64_t ldz, int64_t ldw,
+                           const float *z, const float *w);
+int gist_class_layer_f32(const float *z, int64_t ldz, const float *w, int64_t ldw, const float *bias,
+                         const int32_t *labels, int64_t count, float *logits, int64_t ldl,
+                         float *d_logits, int64_t ldg, float *row_loss, float *dz, int64_t lddz,
+                         float p, uint64_t seed, uint64_t offset, float *dlogits_col_partials,
+                         int64_t n_rows, int64_t n_classes, int64_t k, gist_stream_t stream);
+/* The class layer's weight gradient dW = d_logits^T . z as *n_slabs = ceil(n_rows / 128) dense fp32 slabs
+ * [n_classes][k] (one per 128 rows) for the consumer to sum in slab order (gist_adam_segments_f32);
+ * gist_class_dw_slab_bytes = the bytes the slabs need.  Autograd of that nn.Linear wrt its weight. */
+int64_t gist_class_dw_slab_bytes(int64_t n_rows, int64_t n_classes, int64_t k);
+int gist_class_dw_slabs_f32(const float *d_logits, int64_t ldg, const float *z, int64_t ldz,
+                            float *slabs, int64_t slab_bytes, int32_t *n_slabs, int64_t n_rows,
+                            int64_t n_classes, int64_t k, gist_stream_t stream);
 
 /* out[j] = sum_i g[i, j], deterministic two-stage reduction.
  * `partials` must hold gist_colsum_partials(n_rows) * d floats.

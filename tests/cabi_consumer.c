@@ -9,7 +9,7 @@
 int main(void) {
     gist_step_plan plan;
     memset(&plan, 0, sizeof plan);
-    if (gist_abi_version() != 10) return 1;
+    if (gist_abi_version() != 11) return 1;
     if (gist_gemm_workspace_bytes(2046, 41, 8192) <= 0) return 2;
     if (gist_colsum_partials(129) != 3) return 3;
     /* validation happens before any device work, so these are safe without a GPU */
@@ -36,7 +36,9 @@ int main(void) {
                         (void *)gist_block_scatter_f32, (void *)gist_mean_rows_f32,
                         (void *)gist_timer_create, (void *)gist_timer_destroy,
                         (void *)gist_timer_reset, (void *)gist_timer_count,
-                        (void *)gist_timer_read};
+                        (void *)gist_timer_read, (void *)gist_class_layer_f32,
+                        (void *)gist_class_dw_slabs_f32, (void *)gist_class_layer_takes,
+                        (void *)gist_class_dw_slab_bytes};
         size_t i;
         for (i = 0; i < sizeof syms / sizeof syms[0]; ++i)
             if (syms[i] == NULL) return 10;
