@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # dev knobs for A/B builds of kernel variants: extra -D flags and a different output name
 OUT = os.environ.get('GIST_LIB_OUT', os.path.join(HERE, 'libgist_hip.so'))
 EXTRA = os.environ.get('GIST_EXTRA_FLAGS', '').split()
-SOURCES = ['capi.hip', 'spmm.hip', 'spmm_mfma.hip', 'gemm.hip', 'gemm_h3.hip', 'gemm_b3.hip', 'gemm_b3c.hip', 'rowops.hip', 'classlayer.hip', 'subgraph.hip', 'step.hip',
+SOURCES = ['capi.hip', 'spmm.hip', 'spmm_mfma.hip', 'spmm_dense32.hip', 'gemm.hip', 'gemm_h3.hip', 'gemm_b3.hip', 'gemm_b3c.hip', 'rowops.hip', 'classlayer.hip', 'subgraph.hip', 'step.hip',
            'partition.hip', 'prep.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',

@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void class_layer_kernel(ClassArgs a) {
     const int r0 = blockIdx.x * kRows;
     const int C = a.n_classes, K = a.k;
     // ---- (A) partial logits of this wave's quarter of K ------------------------------------------
+    // Blocks of 16 k; the operands of FOUR blocks are loaded together and the next four are in flight while the
+    // current four feed the matrix cores (a block's 12 MFMAs take 384 cycles, a load from L2 ~1000: without the
+    // run-ahead the loop is one memory latency per block -- measured 24 us for the kernel, against 9 like this).
     {
         const int row = min(r0 + r, a.n_rows - 1);
         const float *zp = a.z + (int64_t)row * a.ldz + 4 * q;
@@ -62,19 +65,50 @@ __global__ __launch_bounds__(256) void class_layer_kernel(ClassArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int kq = K / 4, kb = wave * kq;
-#pragma unroll 4
-        for (int k0 = kb; k0 < kb + kq; k0 += 16) {
+        constexpr int U = 4;
+        float4 za0[U], wb0[U][3], za1[U], wb1[U][3];
+        auto load = [&](float4 (&za)[U], float4 (&wb)[U][3], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                za[u] = *reinterpret_cast<const float4 *>(zp + k0 + 16 * u);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wb[u][t] = *reinterpret_cast<const float4 *>(wp[t] + k0 + 16 * u);
+            }
+        };
+        auto compute = [&](const float4 (&za)[U], const float4 (&wb)[U][3]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float zs[4] = {za[u].x, za[u].y, za[u].z, za[u].w};
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const float ws = s_ == 0 ? wb[u][t].x : s_ == 1 ? wb[u][t].y : s_ == 2 ? wb[u][t].z : wb[u][t].w;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zs[s_], ws, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        const int n_chunks = kq / (16 * U);                 // (k % 256 == 0: whole chunks; else the tail loop below)
+        if (n_chunks > 0) load(za0, wb0, kb);
+        for (int c = 0; c < n_chunks; c += 2) {
+            if (c + 1 < n_chunks) load(za1, wb1, kb + (c + 1) * 16 * U);
+            compute(za0, wb0);
+            if (c + 2 < n_chunks) load(za0, wb0, kb + (c + 2) * 16 * U);
+            if (c + 1 < n_chunks) compute(za1, wb1);
+        }
+        for (int k0 = kb + n_chunks * 16 * U; k0 < kb + kq; k0 += 16) {      // at most three blocks
             const float4 za = *reinterpret_cast<const float4 *>(zp + k0);
             float4 wb[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) wb[t] = *reinterpret_cast<const float4 *>(wp[t] + k0);
             const float zs[4] = {za.x, za.y, za.z, za.w};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s_ = 0; s_ < 4; ++s_) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const float ws = s == 0 ? wb[t].x : s == 1 ? wb[t].y : s == 2 ? wb[t].z : wb[t].w;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zs[s], ws, acc[t], 0, 0, 0);
+                    const float ws = s_ == 0 ? wb[t].x : s_ == 1 ? wb[t].y : s_ == 2 ? wb[t].z : wb[t].w;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zs[s_], ws, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -145,19 +179,22 @@ __global__ __launch_bounds__(256) void class_layer_kernel(ClassArgs a) {
 #pragma unroll
     for (int s = 0; s < 12; ++s) wrow[s] = a.w + (int64_t)min(4 * s + q, C - 1) * a.ldw + r;
     const int n_tiles = K / 16;
-    for (int nt = 2 * wave; nt < n_tiles; nt += 8) {
-        const int n0 = nt * 16, n1 = n0 + 16;      // (K % 32 == 0: the pair is complete)
-        float b0[12], b1[12];
+    // tile pairs wave, wave + 4, ...: the 24 W loads of the next pair are in flight under the current pair's MFMAs
+    float b0[2][12], b1[2][12];
+    auto loadb = [&](float (&p0)[12], float (&p1)[12], int nt) {
+        const int n0 = nt * 16;
 #pragma unroll
-        for (int s = 0; s < 12; ++s) {
-            if (s < ksteps) { b0[s] = wrow[s][n0]; b1[s] = wrow[s][n1]; }
-        }
+        for (int s_ = 0; s_ < 12; ++s_)
+            if (s_ < ksteps) { p0[s_] = wrow[s_][n0]; p1[s_] = wrow[s_][n0 + 16]; }
+    };
+    auto tile = [&](const float (&p0)[12], const float (&p1)[12], int nt) {
+        const int n0 = nt * 16;
         f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 12; ++s) {
-            if (s < ksteps) {
-                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], b0[s], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], b1[s], d1, 0, 0, 0);
+        for (int s_ = 0; s_ < 12; ++s_) {
+            if (s_ < ksteps) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_], p0[s_], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_], p1[s_], d1, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -174,6 +211,14 @@ __global__ __launch_bounds__(256) void class_layer_kernel(ClassArgs a) {
             o[0] = v0;
             o[16] = v1;
         }
+    };
+    int nt = 2 * wave;                                   // (K % 32 == 0: every pair is complete)
+    if (nt < n_tiles) loadb(b0[0], b1[0], nt);
+    for (; nt < n_tiles; nt += 16) {
+        if (nt + 8 < n_tiles) loadb(b0[1], b1[1], nt + 8);
+        tile(b0[0], b1[0], nt);
+        if (nt + 16 < n_tiles) loadb(b0[0], b1[0], nt + 16);
+        if (nt + 8 < n_tiles) tile(b0[1], b1[1], nt + 8);
     }
 }
 
@@ -198,17 +243,34 @@ __global__ __launch_bounds__(256) void class_dw_kernel(ClassDwArgs a) {
     f32x4 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = rb; k0 < re; k0 += 4) {
-        const int rr = k0 + q;
-        const bool live = rr < re;
-        const int rc = live ? rr : re - 1;
-        const float bz = live ? a.z[(int64_t)rc * a.ldz + n0 + r] : 0.f;
-        float av[3];
+    // eight k steps (32 rows) per chunk, the next chunk's 32 loads in flight under the current chunk's 24 MFMAs
+    constexpr int U = 8;
+    float bz[2][U], av[2][U][3];
+    auto load = [&](float (&bzz)[U], float (&avv)[U][3], int k0) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) av[t] = a.dlog[(int64_t)rc * a.ldg + cls[t]];
+        for (int u = 0; u < U; ++u) {
+            const int rr = k0 + 4 * u + q;
+            const bool live = rr < re;
+            const int rc = live ? rr : re - 1;
+            const float zv = a.z[(int64_t)rc * a.ldz + n0 + r];
+            bzz[u] = live ? zv : 0.f;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bz, acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) avv[u][t] = a.dlog[(int64_t)rc * a.ldg + cls[t]];
+        }
+    };
+    auto compute = [&](const float (&bzz)[U], const float (&avv)[U][3]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv[u][t], bzz[u], acc[t], 0, 0, 0);
+    };
+    const int n_chunks = (re - rb + 4 * U - 1) / (4 * U);
+    if (n_chunks > 0) load(bz[0], av[0], rb);
+    for (int c = 0; c < n_chunks; c += 2) {
+        if (c + 1 < n_chunks) load(bz[1], av[1], rb + (c + 1) * 4 * U);
+        compute(bz[0], av[0]);
+        if (c + 2 < n_chunks) load(bz[0], av[0], rb + (c + 2) * 4 * U);
+        if (c + 1 < n_chunks) compute(bz[1], av[1]);
     }
     float *slab = a.slabs + (int64_t)blockIdx.y * C * K;
 #pragma unroll

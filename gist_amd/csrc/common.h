@@ -152,6 +152,12 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
                      int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
                      hipStream_t st, const SpmmDrop *dr = nullptr);
 int64_t spmm_blocks_bytes(int64_t n_blocks);
+// spmm_dense32.hip: the block-dense aggregation on the fp32 matrix cores, operands from memory (prepared blocks only)
+bool spmm_dense32_takes(int64_t d, int64_t ldx, int64_t ldy);
+int launch_spmm_dense32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
+                        int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
+                        int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
+                        hipStream_t st, const SpmmDrop *dr = nullptr);
 bool spmm_prepared_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);   // spmm.hip
 int launch_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, const int32_t *rowptr2,
                                const int32_t *col2, int64_t n_rows, const int32_t *row_blocks,

@@ -847,6 +847,9 @@ int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t
     GIST_REQUIRE(dr.p >= 0.f && dr.p < 1.f && dr.ld >= d, "gist_spmm_csr_drop_f32: bad mask description");
     GIST_REQUIRE(spmm_drop_takes(dr.mode, d, ldx, ldy, x, y, row_blocks),
                  "gist_spmm_csr_drop_f32: this shape cannot carry the mask (use gist_dropout_f32)");
+    if (prepared != nullptr && aligned16(prepared) && spmm_dense32_takes(d, ldx, ldy))
+        return launch_spmm_dense32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
+                                   row_blocks, n_row_blocks, prepared, st, &dr);
     if (mfma_takes(d, ldx, ldy, x, y, row_blocks))
         return launch_spmm_mfma(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
                                 row_blocks, n_row_blocks, prepared, st, &dr);
@@ -882,6 +885,23 @@ extern "C" int gist_spmm_csr_drop_f32(const int32_t *rowptr, const int32_t *col,
     dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.y_base = y_offset; dr.src_base = src_offset; dr.ld = mask_ld;
     return gist::spmm_drop(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate, row_blocks,
                            n_row_blocks, dr, gist::as_stream(stream));
+}
+
+extern "C" int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
+                                               float *y, int64_t ldy, int64_t n_rows, int64_t d,
+                                               const float *out_scale, const float *src_scale, int accumulate,
+                                               const int32_t *row_blocks, int64_t n_row_blocks, int mode, float p,
+                                               uint64_t seed, uint64_t y_offset, uint64_t src_offset,
+                                               int64_t mask_ld, const void *prepared, gist_stream_t stream) {
+    gist::SpmmDrop dr{};
+    dr.mode = mode; dr.p = p; dr.scale = (p > 0.f && p < 1.f) ? 1.0f / (1.0f - p) : 1.f;
+    dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.y_base = y_offset; dr.src_base = src_offset; dr.ld = mask_ld;
+    return gist::spmm_drop(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate, row_blocks,
+                           n_row_blocks, dr, gist::as_stream(stream), prepared);
+}
+
+extern "C" int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y) {
+    return (gist::spmm_dense32_takes(d, ldx, ldy) || gist::spmm_prepared_takes(d, ldx, ldy, x, y)) ? 1 : 0;
 }
 
 extern "C" int gist_spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
@@ -960,6 +980,10 @@ extern "C" int gist_spmm_csr_prepared_f32(const int32_t *rowptr, const int32_t *
     GIST_REQUIRE(n_rows < (1LL << 31) && d < (1LL << 31), "gist_spmm_csr_prepared_f32: size >= 2^31");
     GIST_REQUIRE(row_blocks == nullptr || n_row_blocks > 0,
                  "gist_spmm_csr_prepared_f32: row_blocks given but n_row_blocks <= 0");
+    // below the bf16x3 matrix-core kernel's widths (and for unaligned rows): the fp32 block-dense kernel
+    if (aligned16(prepared) && spmm_dense32_takes(d, ldx, ldy))
+        return launch_spmm_dense32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
+                                   row_blocks, n_row_blocks, prepared, as_stream(stream));
     // widths / alignments the matrix-core kernel does not take: the unprepared entry point decides
     if (!spmm_prepared_takes(d, ldx, ldy, x, y) || !aligned16(prepared))
         return gist_spmm_csr_blocked_f32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale,

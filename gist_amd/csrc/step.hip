@@ -430,7 +430,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     {
         const gist_layer_desc &l = p->layer[L1 - 1];
         cls_fused = train && defer && plain[L1 - 1] && p->ldc <= 64 && (offs[L1 - 1] & 1) == 0 &&
-                    tune(GIST_TUNE_CLASS_FUSED) >= 0.0 &&
+                    (int)tune(GIST_TUNE_CLASS_FUSED) != 1 &&
                     gist_class_layer_takes(n, l.n_out, 2 * l.n_in, l.ldz, 2 * l.n_in, l.Z, l.W) == 1 &&
                     fl.dw_slabs[L1 - 1] != nullptr &&
                     fl.dw_bytes[L1 - 1] >= gist_class_dw_slab_bytes(n, l.n_out, 2 * l.n_in);
@@ -517,7 +517,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         bool wide = false;      // is there an aggregation the prepared kernel takes?
         for (int k = 0; k < L1; ++k)
             wide = wide || spmm_prepared_takes(p->layer[k].n_in, p->layer[k].ldz, p->layer[k].ldz,
-                                               p->layer[k].Z, p->layer[k].Z + p->layer[k].n_in);
+                                               p->layer[k].Z, p->layer[k].Z + p->layer[k].n_in) ||
+                   spmm_dense32_takes(p->layer[k].n_in, p->layer[k].ldz, p->layer[k].ldz);
         if (wide && p->spmm_prepared_bytes >= (train ? 2 : 1) * one) {
             char *base = static_cast<char *>(p->spmm_prepared);
             GIST_TRY(launch_spmm_blocks_prepare(p->rowptr, p->col, train ? p->t_rowptr : nullptr,

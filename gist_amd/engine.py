@@ -453,6 +453,15 @@ class SageEngine(object):
             b.ready = True
             b.z0_dropped = dr is not None
         self._logit_slabs_n = 1
+        # block structure of the batch, once for all its aggregations (gist_sage_step does the same): every
+        # blocked aggregation then runs on a kernel that reads it (fp32 block-dense below 1536 columns, bf16x3 above)
+        self._prep_fwd = self._prep_bwd = None
+        if blocked and any(hip.spmm_prepared_useful(self.Z[k][:n, :i], self.Z[k][:n, i:])
+                           for k, (i, o) in enumerate(self.dims)):
+            self._prep_fwd = hip.spmm_prepare(b.rowptr, b.col, rb)
+            if training:
+                self._prep_bwd = hip.spmm_prepare(b.t_rowptr, b.t_col, rb)
+        pf = self._prep_fwd
         for k, (i, o) in enumerate(self.dims):
             z = self.Z[k][:n]
             if not training and o < i and k == self.L1 - 1 and self.project_first:
@@ -470,9 +479,10 @@ class SageEngine(object):
                 continue
             if fold[k]:      # source = the undropped input, store = dropout(ah)
                 hip.spmm_drop(b.rowptr, b.col, self.H[k][:n, :i], z[:, i:], 1, self.p_drop, self.seed,
-                              offs[k] + i, 0, 2 * i, out_scale=b.norm, row_blocks=rb)
+                              offs[k] + i, 0, 2 * i, out_scale=b.norm, row_blocks=rb, prepared=pf)
             else:
-                hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm, row_blocks=b.row_blocks)
+                hip.spmm(b.rowptr, b.col, z[:, :i], z[:, i:], out_scale=b.norm, row_blocks=b.row_blocks,
+                         prepared=pf if blocked else None)
                 if drop:
                     hip.dropout_(z, self.p_drop, self.seed, offs[k])
             last = k == self.L1 - 1
@@ -483,7 +493,7 @@ class SageEngine(object):
                     # gist_sage_step's class layer: projection, CE, dZ and bias chunks in ONE launch (loss_and_backward)
                     L_ = hip._lib.load()
                     if (fb['dw'][k] is not None and self.ldc <= 64 and (not offs or offs[k] % 2 == 0) and
-                            hip.tuning('class_fused') >= 0 and hip.class_layer_takes(z, A.W[k], o) and
+                            int(hip.tuning('class_fused')) != 1 and hip.class_layer_takes(z, A.W[k], o) and
                             fb['dw'][k].numel() >= L_.gist_class_dw_slab_bytes(n, o, 2 * i)):
                         self._cls_fused = True
                         continue
@@ -529,6 +539,7 @@ class SageEngine(object):
         drop = bool(self._drop_offsets)
         blocked = b.row_blocks is not None and b.row_blocks.numel() > 1
         fb = self._fused_buffers() if defer else None
+        pb = getattr(self, '_prep_bwd', None)
         self._segments = []
         self._loss_rows = n if defer else 0
         cls_fused = defer and getattr(self, '_cls_fused', False)
@@ -576,7 +587,7 @@ class SageEngine(object):
                 if k > 0:
                     dz = self.dZ[:n * 2 * i].view(n, 2 * i)
                     hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
-                             accumulate=True, row_blocks=b.row_blocks)
+                             accumulate=True, row_blocks=b.row_blocks, prepared=pb if blocked else None)
                 continue
             if k > 0:
                 dz = self.dZ[:n * 2 * i].view(n, 2 * i)
@@ -605,10 +616,10 @@ class SageEngine(object):
                 if bwd_fold:
                     hip.spmm_drop(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], 2, self.p_drop, self.seed,
                                   self._drop_offsets[k], self._drop_offsets[k] + i, 2 * i, src_scale=b.norm,
-                                  accumulate=True, row_blocks=b.row_blocks)
+                                  accumulate=True, row_blocks=b.row_blocks, prepared=pb)
                 else:
                     hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
-                             accumulate=True, row_blocks=b.row_blocks)
+                             accumulate=True, row_blocks=b.row_blocks, prepared=pb if blocked else None)
         return self.loss
 
     def adam_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):

@@ -497,9 +497,32 @@ def spmm_drop_takes(mode, d, x, y, has_row_blocks):
     return bool(L.gist_spmm_drop_takes(int(mode), d, ldx, ldy, xp, yp, int(bool(has_row_blocks))))
 
 
+def spmm_prepared_useful(x, y):
+    """Does an aggregation of x's width read a prepared block structure (gist_spmm_prepared_useful)?"""
+    L = _lib.load()
+    xp, ldx = _mat(x, 'x')
+    yp, ldy = _mat(y, 'y')
+    return bool(L.gist_spmm_prepared_useful(x.shape[1], ldx, ldy, xp, yp))
+
+
 def spmm_drop(rowptr, col, x, y, mode, p, seed, y_offset, src_offset, mask_ld, out_scale=None,
-              src_scale=None, accumulate=False, row_blocks=None):
-    """spmm with gist_dropout_f32's mask folded in (gist_spmm_csr_drop_f32)."""
+              src_scale=None, accumulate=False, row_blocks=None, prepared=None):
+    """spmm with gist_dropout_f32's mask folded in (gist_spmm_csr_drop_f32 / _prepared_f32)."""
+    if prepared is not None:
+        L = _lib.load()
+        n = rowptr.numel() - 1
+        xp, ldx = _mat(x, 'x')
+        yp, ldy = _mat(y, 'y')
+        d = x.shape[1]
+        nb = 0 if row_blocks is None else row_blocks.numel() - 1
+        with _Timed('spmm', (n, x.shape[0], d)):
+            rc = L.gist_spmm_csr_drop_prepared_f32(
+                _vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n, d,
+                _opt(out_scale, 'out_scale', torch.float32, n), _opt(src_scale, 'src_scale', torch.float32, x.shape[0]),
+                int(bool(accumulate)), _opt(row_blocks, 'row_blocks', torch.int32), nb, int(mode), float(p), int(seed),
+                int(y_offset), int(src_offset), int(mask_ld), prepared.data_ptr(), _stream())
+        _lib.check(rc, 'gist_spmm_csr_drop_prepared_f32')
+        return y
     L = _lib.load()
     n = rowptr.numel() - 1
     xp, ldx = _mat(x, 'x')

@@ -88,7 +88,9 @@ int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col,
  * ids of each row's neighbours outside the block.  gist_spmm_blocks_bytes(n_row_blocks) bytes
  * (row_blocks = NULL: ceil(n_rows / 128) uniform blocks), 16-byte aligned; valid until rowptr / col /
  * row_blocks change.  gist_spmm_csr_prepared_f32 == gist_spmm_csr_blocked_f32 on the same arguments
- * (same results; shapes the matrix-core kernel does not take fall through to it). */
+ * (same results up to the order of fp32 sums).  Round 4: below 1536 columns, and for any width whose rows are not
+ * 16-byte aligned (the F = 602 input layer), the prepared call runs the product on the fp32 matrix cores with
+ * its operands read straight from memory (spmm_dense32.hip) -- 4-6 us where the LDS-gather kernel took 12-22. */
 int64_t gist_spmm_blocks_bytes(int64_t n_row_blocks);                      /* host function */
 int gist_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, int64_t n_rows,
                              const int32_t *row_blocks, int64_t n_row_blocks,
@@ -119,6 +121,20 @@ int gist_spmm_csr_drop_f32(const int32_t *rowptr, const int32_t *col,
                            int64_t mask_ld, gist_stream_t stream);
 int gist_spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
                          int has_row_blocks);
+/* gist_spmm_csr_drop_f32 on a row set whose block structure is prepared (gist_spmm_blocks_prepare; NULL: as
+ * gist_spmm_csr_drop_f32).  Same results up to the order of fp32 sums. */
+int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col,
+                                    const float *x, int64_t ldx, float *y, int64_t ldy,
+                                    int64_t n_rows, int64_t d,
+                                    const float *out_scale, const float *src_scale, int accumulate,
+                                    const int32_t *row_blocks, int64_t n_row_blocks,
+                                    int mode, float p, uint64_t seed, uint64_t y_offset, uint64_t src_offset,
+                                    int64_t mask_ld, const void *prepared, gist_stream_t stream);
+/* 1 if an aggregation of this width runs on a kernel that reads the prepared block structure (round 4: every width
+ * from 16 columns up -- the fp32 block-dense kernel below 1536 columns and for rows that are not 16-byte aligned,
+ * the bf16x3 matrix-core kernel from 1536 on): a caller that aggregates over a batch more than once should prepare
+ * its blocks.  Host function. */
+int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);
 
 /* ---------------------------------------------------------------------------
  * Data preparation (HOST function, host pointers)
@@ -219,9 +235,9 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_GEMM_SPLITS 4   /* fp32 GEMM split-K factor                                   */
 #define GIST_TUNE_SPMM_CHUNK 5    /* rows per XCD chunk of the row-split SpMM                   */
 #define GIST_TUNE_SPMM_SPLIT 6    /* row split of the LDS-staged SpMM (1..8)                    */
-#define GIST_TUNE_SPMM_KERNEL 7   /* blocked SpMM: 1 = LDS gather kernel, 2 = block-dense MFMA kernel  */
+#define GIST_TUNE_SPMM_KERNEL 7   /* blocked SpMM: 1 = LDS gather kernel, 2 = block-dense bf16x3 MFMA kernel, 3 = fp32 block-dense kernel at every width (prepared calls) */
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
-#define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: -1 = the four-launch sequence (gist_class_layer_f32 off) */
+#define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off) */
 #define GIST_TUNE_COUNT 10
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);

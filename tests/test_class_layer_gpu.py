@@ -116,7 +116,7 @@ def test_class_dw_slabs_against_float64(hip, n, c, k):
 @pytest.mark.parametrize('p_drop,n_layers,hidden', [(0.2, 2, 512), (0.0, 2, 512), (0.2, 4, 256), (0.2, 1, 512)])
 def test_step_with_fused_class_layer_equals_four_launch_sequence(hip, p_drop, n_layers, hidden):
     """gist_sage_step with the class layer as gist_class_layer_f32 + gist_class_dw_slabs_f32 (the default) against the
-    same step with the tuning hook `class_fused` = -1 (projection GEMM, CE kernel, narrow dZ kernel, transposed GEMM):
+    same step with the tuning hook `class_fused` = 1 (projection GEMM, CE kernel, narrow dZ kernel, transposed GEMM):
     GEMM mode f32, 3 steps; same arithmetic up to the order of fp32 sums (k split over four waves / 128-row slabs)."""
     import random
     from gist_amd import datasets
@@ -126,7 +126,7 @@ def test_step_with_fused_class_layer_equals_four_launch_sequence(hip, p_drop, n_
     hip.gemm_mode('f32')
     try:
         res = []
-        for knob in (-1, 0):
+        for knob in (1, 0):
             hip.tuning('class_fused', knob)
             random.seed(9)
             ds = datasets.toy(seed=9, n=3000, n_blocks=30, n_feats=302, n_classes=5, train_frac=1.0)
