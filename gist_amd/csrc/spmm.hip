@@ -901,7 +901,9 @@ extern "C" int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int3
 }
 
 extern "C" int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y) {
-    return (gist::spmm_dense32_takes(d, ldx, ldy) || gist::spmm_prepared_takes(d, ldx, ldy, x, y)) ? 1 : 0;
+    // (the fp32 block-dense kernel rides along when the structure exists; alone it does not pay for the 11-us
+    // prepare launch)
+    return gist::spmm_prepared_takes(d, ldx, ldy, x, y) ? 1 : 0;
 }
 
 extern "C" int gist_spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,

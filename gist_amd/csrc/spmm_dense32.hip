@@ -59,7 +59,8 @@ __device__ __forceinline__ void d32_store(const D32Args &a, int g_row, int col, 
     if constexpr (MODE == 1) v *= drop_keep(yi, a.dr.sm, a.dr.p, a.dr.scale);
     if (a.accumulate) {
         float old = *o;
-        if constexpr (MODE == 2) old *= drop_keep(yi, a.dr.sm, a.dr.p, a.dr.scale);
+        // (__fmul_rn: no contraction into an FMA with the add -- the separate dropout pass rounds the product)
+        if constexpr (MODE == 2) old = __fmul_rn(old, drop_keep(yi, a.dr.sm, a.dr.p, a.dr.scale));
         v += old;
     }
     *o = v;
@@ -162,21 +163,71 @@ __global__ __launch_bounds__(256) void spmm_dense32_kernel(D32Args a) {
         compute(bv[0], cw[0]);
         if (two) compute(bv[1], cw[1]);
         // ---- epilogue: the lane holds rows rt * 16 + 4 q + i of column `col` ----
+        // Every load of the epilogue is issued before the first store (a load behind a store that may alias it is
+        // waited for store by store: sixteen round trips), and the outside neighbours are fetched list position by
+        // list position for all sixteen outputs of the lane at once.
+        int cnt[RT][4];
+        float osc[RT][4], old[RT][4];
+        bool ok[RT][4];
+        int maxc = 0;
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            if (rt0 + t >= rt1) break;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (rt0 + t) * 16 + 4 * q + i;
-                if (row >= nloc || !col_ok) continue;
-                const int cnt = rem_cnt[row];
-                float v = acc[t][i];
-                if (cnt < 0) {
-                    v = d32_gather_row<MODE>(a, r0 + row, col);
-                } else {
-                    for (int j = 0; j < cnt; ++j) v += d32_src<MODE>(a, rem_col[row * DB_REM + j], col);
+                ok[t][i] = rt0 + t < rt1 && row < nloc && col_ok;
+                const int rowc = min(row, nloc - 1);
+                const int c = rem_cnt[rowc];
+                cnt[t][i] = ok[t][i] ? c : 0;
+                osc[t][i] = a.out_scale ? a.out_scale[r0 + rowc] : 1.f;
+                old[t][i] = (a.accumulate && ok[t][i]) ? a.y[(int64_t)(r0 + rowc) * a.ldy + colc] : 0.f;
+                maxc = max(maxc, cnt[t][i]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cnt[t][i] < 0) acc[t][i] = d32_gather_row<MODE>(a, r0 + (rt0 + t) * 16 + 4 * q + i, col);
+        }
+        for (int j = 0; j < DB_REM; ++j) {
+            if (!__any(maxc > j)) break;
+            int u[RT][4];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = min((rt0 + t) * 16 + 4 * q + i, nloc - 1);
+                    u[t][i] = cnt[t][i] > j ? rem_col[row * DB_REM + j] : -1;
                 }
-                d32_store<MODE>(a, r0 + row, col, v);
+            }
+            float xv[RT][4];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[t][i] = u[t][i] >= 0 ? d32_src<MODE>(a, u[t][i], col) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] += xv[t][i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!ok[t][i]) continue;
+                const int g_row = r0 + (rt0 + t) * 16 + 4 * q + i;
+                float v = acc[t][i] * osc[t][i];
+                const uint64_t yi = a.dr.y_base + (uint64_t)g_row * (uint64_t)a.dr.ld + (uint64_t)col;
+                if constexpr (MODE == 1) v *= drop_keep(yi, a.dr.sm, a.dr.p, a.dr.scale);
+                if (a.accumulate) {
+                    float o_ = old[t][i];
+                    if constexpr (MODE == 2) o_ = __fmul_rn(o_, drop_keep(yi, a.dr.sm, a.dr.p, a.dr.scale));
+                    v += o_;
+                }
+                a.y[(int64_t)g_row * a.ldy + col] = v;
             }
         }
     }
@@ -189,12 +240,18 @@ __global__ __launch_bounds__(256) void spmm_dense32_kernel(D32Args a) {
 
 }  // namespace
 
-// Widths the fp32 block-dense kernel takes when the batch's block structure is prepared: everything below the bf16x3
-// matrix-core kernel's range (tuning hook GIST_TUNE_SPMM_KERNEL: 1 = never, 3 = every width)
+// Which prepared aggregations run here.  Measured on the Reddit-like batch (rocprofv3, profiles/r04_spmm_dense32.txt):
+// against the LDS-gather kernel 11.6 vs 10.5 us at D = 256, 13.6 vs 11.8 at 512, 19.5 vs 15.9 at 1024 (both kernels are
+// their chain of four or five dependent memory round trips, not their arithmetic: 1 us of MFMA time at D = 256), against
+// the bf16x3 matrix-core kernel 37 vs 19 at 2048 and 57 vs 27 at 4096 (the fp32 pipe is a sixteenth of the bf16 one) --
+// but 15.7 against 22.0 us for the row-split kernel at D = 602, the one width of the step whose rows are not 16-byte
+// aligned.  So: the widths the other blocked kernels do not take (tuning hook GIST_TUNE_SPMM_KERNEL = 3: every width).
 bool spmm_dense32_takes(int64_t d, int64_t ldx, int64_t ldy) {
     const int want = (int)tune(GIST_TUNE_SPMM_KERNEL);
     if (want == 1 || want == 2) return false;
-    return d >= 16 && ldx >= d && ldy >= d && (d < 1536 || d % 4 != 0 || want == 3);
+    if (!(d >= 16 && ldx >= d && ldy >= d)) return false;
+    if (want == 3) return true;
+    return d >= 128 && (d % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0);
 }
 
 int launch_spmm_dense32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
@@ -217,8 +274,8 @@ int launch_spmm_dense32(const int32_t *rowptr, const int32_t *col, const float *
     a.n_col_tiles = (int)ceil_div(d, 16);
     // row-tile groups: enough wave tasks for the chip's 1024 SIMDs (a block has up to 8 row tiles)
     const int64_t col_tasks = nb * a.n_col_tiles;
-    int rt = 4;
-    if (col_tasks * 2 < 1024) rt = 2;
+    int rt = 2;                                                  // (measured: four groups of two row tiles beat two of four up to D = 1024)
+    if (col_tasks * 4 > 8192) rt = 4;
     const int forced = (int)tune(GIST_TUNE_SPMM_SPLIT);          // 2, 4: row-tile groups per block
     if (forced == 2 || forced == 4) rt = 8 / forced;
     a.rt_per_group = rt;

@@ -517,8 +517,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         bool wide = false;      // is there an aggregation the prepared kernel takes?
         for (int k = 0; k < L1; ++k)
             wide = wide || spmm_prepared_takes(p->layer[k].n_in, p->layer[k].ldz, p->layer[k].ldz,
-                                               p->layer[k].Z, p->layer[k].Z + p->layer[k].n_in) ||
-                   spmm_dense32_takes(p->layer[k].n_in, p->layer[k].ldz, p->layer[k].ldz);
+                                               p->layer[k].Z, p->layer[k].Z + p->layer[k].n_in);
         if (wide && p->spmm_prepared_bytes >= (train ? 2 : 1) * one) {
             char *base = static_cast<char *>(p->spmm_prepared);
             GIST_TRY(launch_spmm_blocks_prepare(p->rowptr, p->col, train ? p->t_rowptr : nullptr,

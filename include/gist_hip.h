@@ -88,9 +88,9 @@ int gist_spmm_csr_blocked_f32(const int32_t *rowptr, const int32_t *col,
  * ids of each row's neighbours outside the block.  gist_spmm_blocks_bytes(n_row_blocks) bytes
  * (row_blocks = NULL: ceil(n_rows / 128) uniform blocks), 16-byte aligned; valid until rowptr / col /
  * row_blocks change.  gist_spmm_csr_prepared_f32 == gist_spmm_csr_blocked_f32 on the same arguments
- * (same results up to the order of fp32 sums).  Round 4: below 1536 columns, and for any width whose rows are not
- * 16-byte aligned (the F = 602 input layer), the prepared call runs the product on the fp32 matrix cores with
- * its operands read straight from memory (spmm_dense32.hip) -- 4-6 us where the LDS-gather kernel took 12-22. */
+ * (same results up to the order of fp32 sums).  Round 4: for a width whose rows are not 16-byte aligned (the
+ * F = 602 input layer) the prepared call runs the product on the fp32 matrix cores with its operands read
+ * straight from memory (spmm_dense32.hip: 15.7 us where the row-split kernel takes 22). */
 int64_t gist_spmm_blocks_bytes(int64_t n_row_blocks);                      /* host function */
 int gist_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, int64_t n_rows,
                              const int32_t *row_blocks, int64_t n_row_blocks,
@@ -130,10 +130,10 @@ int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col,
                                     const int32_t *row_blocks, int64_t n_row_blocks,
                                     int mode, float p, uint64_t seed, uint64_t y_offset, uint64_t src_offset,
                                     int64_t mask_ld, const void *prepared, gist_stream_t stream);
-/* 1 if an aggregation of this width runs on a kernel that reads the prepared block structure (round 4: every width
- * from 16 columns up -- the fp32 block-dense kernel below 1536 columns and for rows that are not 16-byte aligned,
- * the bf16x3 matrix-core kernel from 1536 on): a caller that aggregates over a batch more than once should prepare
- * its blocks.  Host function. */
+/* 1 if an aggregation of this width runs on the kernel the prepared block structure is built for (the bf16x3
+ * matrix-core kernel, from 1536 columns on): a caller that aggregates over a batch more than once should then
+ * prepare its blocks -- and every other prepared call of the batch may use the structure too (the fp32 block-dense
+ * kernel takes the widths whose rows are not 16-byte aligned).  Host function. */
 int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);
 
 /* ---------------------------------------------------------------------------
@@ -333,7 +333,7 @@ int gist_gemm_nn_dropout_colsum_f32(const float *g, int64_t ldg, const float *w,
  * gist_dropout_f32's generator, element index offset + row * k + col; dz = NULL: forward and loss only); and
  * dlogits_col_partials[gist_row_chunks16(n_rows)][n_classes] = d_logits' column sums per 16 rows (the bias gradient in
  * chunks; NULL: skip).  fp32 FMA chains on v_mfma_f32_16x16x4_f32, one workgroup per 16 rows.
- * gist_class_layer_takes: 1 if the shape is taken (n_classes <= 48, k % 64 == 0, k <= 4096, 16-byte aligned operands).
+ * gist_class_layer_takes: 1 if the shape is taken (n_classes <= 48, k % 64 == 0, k <= 1024, 16-byte aligned operands).
  * Replaces nn.Linear of the last ISTSAGELayer (modules.py:233,299-308), nn.CrossEntropyLoss and their backward
  * (cluster_gcn_ist_distrib.py:411-415) wrt the layer's input. */
 int gist_class_layer_takes(int64_t n_rows, int64_t n_classes, int64_t k, int64_t ldz, int64_t ldw,

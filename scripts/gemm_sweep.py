@@ -12,11 +12,15 @@ SHAPES = [('nt', 2046, 4096, 8192), ('nt', 2046, 4096, 1204), ('tn', 4096, 1204,
           ('nt', 2046, 512, 1204), ('nt', 2046, 512, 1024), ('tn', 512, 1024, 2046), ('nn', 2046, 1024, 512),
           ('tn', 512, 1204, 2046), ('nt', 2046, 41, 1024), ('tn', 41, 1024, 2046), ('nn', 2046, 1024, 41),
           ('nt', 2046, 256, 1204), ('nt', 2046, 256, 512), ('tn', 256, 512, 2046), ('nn', 2046, 512, 256)]
+if os.environ.get('GIST_SWEEP_SHAPES'):      # e.g. 'nt,1140,512,1024;nn,1140,1024,512'
+    SHAPES = [(t.split(',')[0],) + tuple(int(v) for v in t.split(',')[1:]) for t in os.environ['GIST_SWEEP_SHAPES'].split(';')]
 CHILD = r'''
 import sys, json, os, torch
 sys.path.insert(0, %r)
 from gist_amd import hip
 dev = torch.device('cuda', 0)
+if os.environ.get('GIST_B3C'):
+    hip.tuning('b3c', int(os.environ['GIST_B3C']))
 if os.environ.get('GIST_GEMM_TILE') and os.environ.get('GIST_GEMM_SPLITS'):
     hip.tuning('gemm_tile', int(os.environ['GIST_GEMM_TILE']))
     hip.tuning('gemm_splits', int(os.environ['GIST_GEMM_SPLITS']))

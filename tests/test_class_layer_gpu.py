@@ -32,8 +32,8 @@ def _mask(n, d, p, seed, offset):
 
 
 @pytest.mark.parametrize('n,c,k,p,with_dz', [
-    (2046, 41, 1024, 0.2, True), (1140, 47, 1024, 0.2, True), (2046, 41, 512, 0.0, True), (2046, 41, 2048, 0.2, True),
-    (50, 7, 64, 0.5, True), (17, 3, 128, 0.0, True), (300, 48, 192, 0.2, True), (2046, 41, 4096, 0.2, True),
+    (2046, 41, 1024, 0.2, True), (1140, 47, 1024, 0.2, True), (2046, 41, 512, 0.0, True), (2046, 41, 768, 0.2, True),
+    (50, 7, 64, 0.5, True), (17, 3, 128, 0.0, True), (300, 48, 192, 0.2, True), (2046, 41, 256, 0.2, True),
     (333, 41, 1024, 0.0, False), (16, 1, 64, 0.2, True)])
 def test_class_layer_against_float64(hip, n, c, k, p, with_dz):
     rs = np.random.RandomState(n + c + k)
@@ -89,7 +89,7 @@ def test_class_layer_against_float64(hip, n, c, k, p, with_dz):
 
 
 @pytest.mark.parametrize('n,c,k', [(2046, 41, 1024), (1140, 47, 1024), (2046, 41, 512), (129, 5, 64), (128, 48, 2048),
-                                   (2060, 41, 4096)])
+                                   (2060, 41, 4096)])      # (the slab kernel itself takes any k % 64 == 0)
 def test_class_dw_slabs_against_float64(hip, n, c, k):
     from gist_amd import _lib
     L = _lib.load()

@@ -275,7 +275,7 @@ def _native_vs_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden):
             rec = eng.read_timer()
             # (round 4: the class layer's projection and dZ are ONE launch -- gist_class_layer_f32 -- where it is taken)
             k_cls, c_cls = 2 * dims[-1][0], dims[-1][1]
-            cls_fused = k_cls % 64 == 0 and k_cls <= 4096 and c_cls <= 48
+            cls_fused = k_cls % 64 == 0 and k_cls <= 1024 and c_cls <= 48
             assert len(rec) == 4 * (5 * len(dims) - 2 - (1 if cls_fused else 0))
             assert all(ms > 0 for ms, *_ in rec)
             eng.disable_timer()

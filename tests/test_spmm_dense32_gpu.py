@@ -18,9 +18,14 @@ DEV = 'cuda:0'
 
 @pytest.fixture(scope='module')
 def hip():
+    """The library routes a prepared aggregation to the fp32 block-dense kernel only for widths the other blocked
+    kernels do not take (rows that are not 16-byte aligned: the F = 602 input layer); the tuning hook spmm_kernel = 3
+    sends EVERY prepared call there, so that the kernel is tested at all widths."""
     from gist_amd import hip as h
     assert h.device_count() >= 1
-    return h
+    h.tuning('spmm_kernel', 3)
+    yield h
+    h.tuning('spmm_kernel', 0)
 
 
 def _graph(n, bounds, deg_in, deg_out, seed, hub=0, fold=0):
@@ -68,7 +73,6 @@ def test_dense32_against_oracle_forward_and_backward(hip, n, bounds, d, pad):
     xt = torch.from_numpy(x).to(DEV)[:, :d]
     norm = hip.in_degree_norm(rp)
     nrm = norm.cpu().numpy()
-    assert hip.spmm_prepared_useful(xt, xt)
     prep = hip.spmm_prepare(rp, cl, rb)
     prep_t = hip.spmm_prepare(trp, tcl, rb)
     # forward: y = norm * sum of in-neighbours
@@ -154,3 +158,27 @@ def test_dense32_row_tile_groups_agree(hip):
     finally:
         hip.tuning('spmm_split', 0)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_default_routing_of_prepared_calls(hip):
+    """Without the hook: the unaligned input width runs on the fp32 block-dense kernel when the batch's blocks are
+    prepared (bit-equal to the forced call), an aligned narrow width keeps the LDS-gather kernel (bit-equal to the
+    unprepared blocked call)."""
+    n = 700
+    _, (rp, cl, _, _, rb) = _graph(n, np.linspace(0, n, 8).astype(int), 12, 2, seed=9, hub=40)
+    prep = hip.spmm_prepare(rp, cl, rb)
+    x602 = torch.randn(n, 604, device=DEV)[:, :602]
+    x512 = torch.randn(n, 512, device=DEV)
+    forced = torch.zeros(n, 602, device=DEV)
+    hip.spmm(rp, cl, x602, forced, row_blocks=rb, prepared=prep)          # (hook = 3 from the fixture)
+    try:
+        hip.tuning('spmm_kernel', 0)
+        a = torch.zeros(n, 602, device=DEV)
+        hip.spmm(rp, cl, x602, a, row_blocks=rb, prepared=prep)
+        assert torch.equal(a, forced)
+        b, c = torch.zeros(n, 512, device=DEV), torch.zeros(n, 512, device=DEV)
+        hip.spmm(rp, cl, x512, b, row_blocks=rb, prepared=prep)
+        hip.spmm(rp, cl, x512, c, row_blocks=rb)
+        assert torch.equal(b, c)
+    finally:
+        hip.tuning('spmm_kernel', 3)
