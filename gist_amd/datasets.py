@@ -22,8 +22,12 @@ from .graph import Graph
 Dataset = namedtuple('Dataset', ['num_classes', 'g', 'par_li', 'name'])
 
 
-def sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed):
-    """Directed edge list (symmetrised + self loops) of a block model on n nodes."""
+def sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed, inter_locality=0.0, neigh_parts=8):
+    """Directed edge list (symmetrised + self loops) of a block model on n nodes.
+    inter_locality: share of a node's inter-block edges that go to one of its block's `neigh_parts` NEIGHBOUR
+    blocks (the blocks at ring distance 1 .. neigh_parts / 2 on either side: a symmetric relation) instead of
+    to a uniformly random node -- partitions of real graphs cut few block pairs heavily rather than all pairs
+    thinly; 0 = the uniform model (the worst case for the evaluation's gathers)."""
     rs = np.random.RandomState(seed)
     base, extra = divmod(n, n_blocks)
     sizes = np.full(n_blocks, base, np.int64)
@@ -41,6 +45,13 @@ def sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed):
     dst_i = starts[b] + (rs.random_sample(src_i.shape[0]) * sizes[b]).astype(np.int64)
     src_o = np.repeat(nodes, inter_deg * mult)
     dst_o = rs.randint(0, n, src_o.shape[0]).astype(np.int64)
+    if inter_locality > 0.0 and n_blocks > neigh_parts:
+        near = rs.random_sample(src_o.shape[0]) < inter_locality
+        half = max(neigh_parts // 2, 1)
+        step = rs.randint(1, half + 1, src_o.shape[0]) * np.where(rs.random_sample(src_o.shape[0]) < 0.5, -1, 1)
+        nb = (block_of[src_o] + step) % n_blocks
+        dst_near = starts[nb] + (rs.random_sample(src_o.shape[0]) * sizes[nb]).astype(np.int64)
+        dst_o = np.where(near, dst_near, dst_o)
     src = np.concatenate([src_i, dst_i, src_o, dst_o, nodes])
     dst = np.concatenate([dst_i, src_i, dst_o, src_o, nodes])
     blocks = [np.arange(starts[k], starts[k + 1], dtype=np.int64) for k in range(n_blocks)]
@@ -48,11 +59,12 @@ def sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed):
 
 
 def make_block_dataset(name, n, n_blocks, n_feats, n_classes, intra_deg, inter_deg, seed,
-                       hub_frac=0.01, hub_mult=10, train_frac=1.0):
+                       hub_frac=0.01, hub_mult=10, train_frac=1.0, inter_locality=0.0, neigh_parts=8):
     """Graph with ndata feat/label/{train,val,test}_mask on the host + partition list of
     the TRAIN-induced graph (ids relative to the train graph, like METIS on
     ClusterIter.g, sampler.py:34,50)."""
-    src, dst, blocks = sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed)
+    src, dst, blocks = sbm_edges(n, n_blocks, intra_deg, inter_deg, hub_frac, hub_mult, seed, inter_locality,
+                                 neigh_parts)
     g = Graph.from_edges(src, dst, n)
     # the node ids are ordered by block: boundaries for the evaluator's block-diagonal split
     # (trainer.FullGraphEvaluator node_blocks; blocks of at most 128 nodes only)

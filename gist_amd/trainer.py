@@ -48,7 +48,7 @@ class FullGraphEvaluator(object):
     datasets do), else one gather pass over A (any graph); False = one gather pass."""
 
     def __init__(self, g, dims, use_layernorm, arena, device, row_block=None,
-                 block_bytes=4 << 30, node_blocks=None):
+                 block_bytes=4 << 30, node_blocks=None, pair_min_edges=300):
         self.g = g if g.device == device else g.to(device)
         self.dims = [(int(i), int(o)) for i, o in dims]
         self.use_layernorm = bool(use_layernorm)
@@ -73,6 +73,12 @@ class FullGraphEvaluator(object):
         self.row_block = int(min(max(row_block, 1), n))
         self.split = None
         self.rest_tile = 512        # floats per column tile of the remainder's gather passes
+        # Round 4: an OFF-diagonal pair of node blocks that shares at least this many edges is a dense block too and
+        # runs as counts x features on the fp32 matrix cores (gist_spmm_block_pairs_f32) instead of one gathered row
+        # per edge: 0.65 us of chip time per pair at D = 4096 against 2.2 ns per gathered edge = break-even ~300.
+        # A partition of a real graph cuts few block pairs heavily; the uniform block model cuts all pairs thinly
+        # (10 edges per pair) and keeps the gathers.  0 = off.
+        self.pair_min_edges = int(pair_min_edges) if os.environ.get('GIST_EVAL_PAIRS', '1') != '0' else 0
         self.row_cuts = list(range(0, n, self.row_block)) + [n]
         hidden = max([o for (i, o) in self.dims[:-1]] + [1])
         self.h = [torch.empty(n, hidden, **f32) for _ in range(2 if L1 > 2 else 1)] if L1 > 1 else []
@@ -122,8 +128,12 @@ class FullGraphEvaluator(object):
                     # everything else: gathered, accumulated -- one column tile at a time, so that the slab of
                     # X a pass gathers from (N x rest_tile floats: 238 MB at Reddit's size) stays in the
                     # Infinity Cache instead of every gather going to HBM
+                    if sp['n_pairs'] > 0:      # dense off-diagonal blocks: counts x features, accumulated
+                        lo, hi = sp['block_range'][bi]
+                        hip.spmm_block_pairs(sp['bounds32'], sp['pair_ptr'], sp['pair_cb'], sp['images'], lo, hi - lo,
+                                             cur[:, :i], z[:, i:], r0, out_scale=self.norm, accumulate=True)
                     ct = self.rest_tile
-                    for c0 in range(0, i, ct):
+                    for c0 in range(0, i, ct if sp['rest_edges'] > 0 else i):
                         c1 = min(c0 + ct, i)
                         hip.spmm(sp['rowptr_r'][r0:r1 + 1], sp['col_r'], cur[:, c0:c1], z[:, i + c0:i + c1],
                                  out_scale=self.norm[r0:r1], accumulate=True)
@@ -187,18 +197,59 @@ class FullGraphEvaluator(object):
             return rp.to(torch.int32), c.to(torch.int32).contiguous()
 
         rp_d, col_d = csr(inside, True)
-        rp_r, col_r = csr(~inside, False)
-        del rows, col, inside
-        blocks, prepared = [], []
+        # ---- dense off-diagonal block pairs ----
+        nb = len(bounds) - 1
+        pairs = dict(n_pairs=0, pair_edges=0)
+        rest_mask = ~inside
+        if self.pair_min_edges > 0 and bool(rest_mask.any()):
+            blk_of = torch.bucketize(torch.arange(n, device=dev), bd, right=True) - 1
+            sel = torch.nonzero(rest_mask).squeeze(1)
+            er, ec = rows[sel], col[sel]
+            key = blk_of[er] * nb + blk_of[ec]
+            uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+            dense = cnt >= self.pair_min_edges
+            for _ in range(2):                         # (second round only if a pair had a count above 256)
+                if not bool(dense.any()):
+                    break
+                rank = torch.cumsum(dense.to(torch.int64), 0) - 1
+                e_dense = dense[inv]
+                p_e = rank[inv][e_dense]
+                r_loc = er[e_dense] - bd[blk_of[er[e_dense]]]
+                k_loc = ec[e_dense] - bd[blk_of[ec[e_dense]]]
+                n_pairs = int(dense.sum().item())
+                flat = p_e * 16384 + ((k_loc >> 3) * 128 + r_loc) * 8 + (k_loc & 7)
+                counts = torch.bincount(flat, minlength=n_pairs * 16384)
+                big = counts.view(n_pairs, 16384).max(1).values > 256      # not exact in bf16: back to the gathers
+                if bool(big.any()):
+                    idx = torch.nonzero(dense).squeeze(1)[big]
+                    dense[idx] = False
+                    del counts
+                    continue
+                images = counts.to(torch.float32).to(torch.bfloat16).contiguous()
+                del counts, flat
+                dk = uniq[dense]
+                pair_ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(torch.bincount(dk // nb, minlength=nb), 0, out=pair_ptr[1:])
+                pairs = dict(n_pairs=n_pairs, pair_edges=int(e_dense.sum().item()), images=images,
+                             pair_ptr=pair_ptr.to(torch.int32), pair_cb=(dk % nb).to(torch.int32).contiguous())
+                rest_mask = rest_mask.clone()
+                rest_mask[sel[e_dense]] = False
+                break
+            del key, uniq, inv, cnt, er, ec, sel, blk_of
+        rp_r, col_r = csr(rest_mask, False)
+        del rows, col, inside, rest_mask
+        blocks, prepared, block_range = [], [], []
         for r0, r1 in zip(cuts[:-1], cuts[1:]):
             lo = int(np.searchsorted(bounds, r0))
             hi = int(np.searchsorted(bounds, r1))
             rb = torch.from_numpy((bounds[lo:hi + 1] - r0).astype(np.int32)).to(dev)
             blocks.append(rb)
+            block_range.append((lo, hi))
             # (row pointers of a row block are absolute offsets into col_d: prepare on the slice)
             prepared.append(hip.spmm_prepare(rp_d[r0:r1 + 1], col_d, rb))
         self.split = dict(rowptr_d=rp_d, col_d=col_d, rowptr_r=rp_r, col_r=col_r, blocks=blocks,
-                          prepared=prepared, diag_edges=int(col_d.numel()), rest_edges=int(col_r.numel()))
+                          prepared=prepared, diag_edges=int(col_d.numel()), rest_edges=int(col_r.numel()),
+                          block_range=block_range, bounds32=torch.from_numpy(bounds.astype(np.int32)).to(dev), **pairs)
 
     def accuracy(self, mask_name):
         if mask_name not in self.masks:

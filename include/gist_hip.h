@@ -136,6 +136,19 @@ int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col,
  * kernel takes the widths whose rows are not 16-byte aligned).  Host function. */
 int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);
 
+/* Full-graph evaluation (cluster_gcn/utils.py:70-80) on a graph whose node ids are ordered by part: the edges between
+ * a row block rb and a column block cb that share many edges (a dense off-diagonal block of the adjacency) as a counts x
+ * features product on the fp32 matrix cores instead of one gathered row per edge.  bounds[n_blocks + 1] = the parts' node
+ * boundaries (parts of at most 128 nodes); pair_ptr[n_blocks + 1] / pair_cb[n_pairs] = per row block the column blocks of
+ * its listed pairs; images = per pair 32 KiB of bf16 edge counts (<= 256: exact) laid out [16][128 rows][8]: count of
+ * (row r, source k) at ((k / 8) * 128 + r) * 8 + k % 8.  For row blocks b0 .. b0 + n_row_blocks - 1:
+ *   y[g - y_row0, :d] (+)= out_scale[g] * sum over the pairs of C_pair . x[rows of cb, :d]      (g = global row)
+ * with accumulate = 0 rows of blocks without pairs are written as zero.  Exact fp32 products and sums. */
+int gist_spmm_block_pairs_f32(const int32_t *bounds, const int32_t *pair_ptr, const int32_t *pair_cb,
+                              const void *images, int64_t b0, int64_t n_row_blocks, const float *x, int64_t ldx,
+                              float *y, int64_t ldy, int64_t y_row0, int64_t d, const float *out_scale,
+                              int accumulate, gist_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Data preparation (HOST function, host pointers)
  * ------------------------------------------------------------------------- */

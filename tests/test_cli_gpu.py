@@ -219,3 +219,74 @@ def test_evaluator_block_diagonal_split_agrees(hidden):
         assert abs(ev.accuracy('val_mask') - whole.accuracy('val_mask')) < 1e-9
     with pytest.raises(ValueError):
         FullGraphEvaluator(g, dims, True, arena, dev, node_blocks=np.array([0, 200, 5000]))      # blocks > 128
+
+
+def test_block_pairs_kernel_against_float64():
+    """gist_spmm_block_pairs_f32: y (+)= scale * sum over listed block pairs of counts x features, on unequal blocks
+    (1 .. 128 rows), a row block without pairs, a column tile that is cut (d = 100), accumulate on and off."""
+    from gist_amd import hip
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(0)
+    sizes = np.array([100, 128, 1, 57, 128, 90])
+    bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n, nb = int(bounds[-1]), len(sizes)
+    pairs = [(0, 1), (0, 3), (1, 0), (1, 5), (2, 4), (4, 0), (4, 1), (4, 2), (5, 3)]          # (row block 3: none)
+    A = np.zeros((n, n))
+    imgs = np.zeros((len(pairs), 16, 128, 8), np.float32)
+    for p, (rb, cb) in enumerate(pairs):
+        c = rs.poisson(0.4, (sizes[rb], sizes[cb])).astype(np.float64)
+        c[rs.randint(0, sizes[rb]), rs.randint(0, sizes[cb])] = 256           # the largest exact count
+        A[bounds[rb]:bounds[rb + 1], bounds[cb]:bounds[cb + 1]] = c
+        for k in range(sizes[cb]):
+            imgs[p, k // 8, :sizes[rb], k % 8] = c[:, k]
+    ptr = np.zeros(nb + 1, np.int32)
+    for rb, _ in pairs:
+        ptr[rb + 1] += 1
+    ptr = np.cumsum(ptr).astype(np.int32)
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    images = t32(imgs).to(torch.bfloat16).contiguous()
+    scale = rs.rand(n).astype(np.float32) + 0.5
+    for d in (100, 64, 512):
+        x = rs.randn(n, d + 3).astype(np.float32)
+        y0 = rs.randn(n, d).astype(np.float32)
+        ref = (A @ x[:, :d].astype(np.float64)) * scale[:, None]
+        for acc in (False, True):
+            # row blocks 1 .. 4 only (a slice of the graph), y holding those rows from y_row0 = bounds[1]
+            lo, hi = 1, 5
+            y = t32(y0[bounds[lo]:bounds[hi]].copy())
+            hip.spmm_block_pairs(t32(bounds.astype(np.int32)), t32(ptr), t32(np.array([cb for _, cb in pairs], np.int32)),
+                                 images, lo, hi - lo, t32(x)[:, :d], y, int(bounds[lo]), out_scale=t32(scale),
+                                 accumulate=acc)
+            want = ref[bounds[lo]:bounds[hi]] + (y0[bounds[lo]:bounds[hi]] if acc else 0.0)
+            assert np.abs(y.cpu().numpy() - want).max() < 2e-5 * max(1.0, np.abs(want).max()), (d, acc)
+
+
+@pytest.mark.parametrize('locality', [0.8, 1.0])
+def test_evaluator_dense_block_pairs_agree(locality):
+    """A graph whose inter-part edges go mostly to a few neighbour parts (what a partition of a real graph looks like):
+    the evaluator finds the dense off-diagonal block pairs, runs them as counts x features, gathers the rest, and the
+    logits equal the one-pass evaluator's; with the threshold out of reach no pair is dense and nothing changes."""
+    from gist_amd import datasets
+    from gist_amd.engine import ParamArena, dims_for
+    from gist_amd.trainer import FullGraphEvaluator
+    dev = torch.device('cuda', 0)
+    ds = datasets.make_block_dataset('blocks', 6000, 60, 64, 5, intra_deg=20, inter_deg=24, seed=4, hub_frac=0.01,
+                                     hub_mult=8, train_frac=0.7, inter_locality=locality)
+    g = ds.g
+    dims = dims_for(64, 256, 5, 3)
+    arena = ParamArena(dims, dev, with_grads=False)
+    gen = torch.Generator().manual_seed(2)
+    arena.load([((torch.rand(o, 2 * i, generator=gen) - 0.5) * (2.0 / np.sqrt(2 * i)),
+                 (torch.rand(o, generator=gen) - 0.5) * 0.1) for (i, o) in dims])
+    ref = FullGraphEvaluator(g, dims, True, arena, dev, node_blocks=False).forward().clone()
+    for rb in (6000, 1300):
+        ev = FullGraphEvaluator(g, dims, True, arena, dev, row_block=rb, pair_min_edges=200)
+        sp = ev.split
+        assert sp['n_pairs'] >= 60 * 8 * 0.9 and sp['pair_edges'] > 0
+        assert sp['diag_edges'] + sp['pair_edges'] + sp['rest_edges'] == g.number_of_edges()
+        if locality == 1.0:
+            assert sp['rest_edges'] < 0.02 * g.number_of_edges()        # (hub rows' thin pairs only)
+        assert (ev.forward() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    ev0 = FullGraphEvaluator(g, dims, True, arena, dev, pair_min_edges=10 ** 9)
+    assert ev0.split['n_pairs'] == 0
+    assert (ev0.forward() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

@@ -139,7 +139,10 @@ def test_dense32_masks_equal_dropout_around_the_plain_call(hip, n, d):
         hip.spmm(trp, tcl, ref[:, d:], ref[:, :d], src_scale=norm, accumulate=True, row_blocks=rb, prepared=prep_t)
         hip.spmm_drop(trp, tcl, new[:, d:], new[:, :d], 2, 0.25, 5, 64, 64 + d, 2 * d, src_scale=norm,
                       accumulate=True, row_blocks=rb, prepared=prep_t)
-        assert torch.equal(new[:, :d], ref[:, :d])
+        # (to rounding: this kernel is never the step's backward form -- the widths it takes by default are not folded,
+        # gist_spmm_drop_takes -- and its mask-then-scale products are not contracted like the plain call's)
+        assert (new[:, :d] - ref[:, :d]).abs().max().item() <= 2e-6 * max(1.0, ref[:, :d].abs().max().item())
+        assert torch.equal(new[:, :d] == 0, ref[:, :d] == 0)
 
 
 def test_dense32_row_tile_groups_agree(hip):
