@@ -238,121 +238,6 @@ __global__ __launch_bounds__(256) void spmm_dense32_kernel(D32Args a) {
     }
 }
 
-// ---- off-diagonal dense blocks of a graph ordered by part (full-graph evaluation) -------------------------------
-// The same product for a LIST of column blocks per row block: Y_rb (+)= scale . sum_p C_p . X_{cb(p)}, C_p = the edge
-// counts of block pair p = (rb, cb) in the prepared image layout ([16 k chunks][128 rows][8 k] bf16).  A wave owns (row
-// block, 32 columns, half of the row tiles) and walks the row block's pairs; per pair all its operand loads are issued
-// in two batches before / under the MFMAs.  Break-even against gathering the pair's edges one by one: ~300 edges per
-// pair at D = 4096 (0.65 us of chip time per pair against 2.2 ns per gathered 16-KB row).
-struct P32Args {
-    const int32_t *bounds, *pair_ptr, *pair_cb;
-    const unsigned char *images;
-    int b0, n_row_blocks;
-    const float *x; int64_t ldx;
-    float *y; int64_t ldy; int64_t y_row0;
-    int d, n_col_pairs;
-    const float *out_scale;
-    int accumulate;
-};
-
-__global__ __launch_bounds__(256) void spmm_pairs32_kernel(P32Args a) {
-    constexpr int RT = 4, KB = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int task = blockIdx.x * 4 + wave;
-    const int per_block = 2 * a.n_col_pairs;
-    if (task >= a.n_row_blocks * per_block) return;
-    const int rbk = a.b0 + task / per_block;
-    const int rem_t = task % per_block;
-    const int grp = rem_t / a.n_col_pairs;
-    const int cp = rem_t - grp * a.n_col_pairs;
-    const int r0 = a.bounds[rbk], nloc = min(a.bounds[rbk + 1] - r0, DB_ROWS);
-    const int n_rt = (nloc + 15) >> 4;
-    const int rt0 = grp * RT, rt1 = min(rt0 + RT, n_rt);
-    const int p0 = a.pair_ptr[rbk], p1 = a.pair_ptr[rbk + 1];
-    if (rt0 >= rt1 || (p0 >= p1 && a.accumulate)) return;
-    const int col0 = cp * 32 + r, col1 = col0 + 16;
-    const int colc0 = min(col0, a.d - 1), colc1 = min(col1, a.d - 1);
-    f32x4 acc[2][RT];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = p0; p < p1; ++p) {
-        const int cb = a.pair_cb[p];
-        const int c0 = a.bounds[cb], nk = min(a.bounds[cb + 1] - c0, DB_ROWS);
-        const int n_kb = (nk + 15) >> 4;
-        const unsigned char *arow = a.images + (int64_t)p * (16 * DB_ROWS * 16) +
-                                    (int64_t)((q >> 1) * DB_ROWS + rt0 * 16 + r) * 16 + 8 * (q & 1);
-        float bv[2][KB][2][4];
-        uint2 cw[2][KB][RT];
-        auto load = [&](float (&bb)[KB][2][4], uint2 (&cc)[KB][RT], int kb0) {
-#pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                const bool on = kb0 + u < n_kb;                          // wave-uniform
-                const int kb = on ? kb0 + u : n_kb - 1;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int k = min(kb * 16 + 4 * q + s, nk - 1);
-                    const float *xr = a.x + (int64_t)(c0 + k) * a.ldx;
-                    bb[u][0][s] = xr[colc0];
-                    bb[u][1][s] = xr[colc1];
-                }
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const int tt = min(t, rt1 - rt0 - 1);
-                    const uint2 v = *reinterpret_cast<const uint2 *>(arow + (int64_t)(2 * kb * DB_ROWS + tt * 16) * 16);
-                    cc[u][t] = on ? v : make_uint2(0u, 0u);
-                }
-            }
-        };
-        auto compute = [&](const float (&bb)[KB][2][4], const uint2 (&cc)[KB][RT]) {
-#pragma unroll
-            for (int u = 0; u < KB; ++u) {
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const float k0 = __uint_as_float(cc[u][t].x << 16), k1 = __uint_as_float(cc[u][t].x & 0xffff0000u);
-                    const float k2 = __uint_as_float(cc[u][t].y << 16), k3 = __uint_as_float(cc[u][t].y & 0xffff0000u);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0, bb[u][c][0], acc[c][t], 0, 0, 0);
-                        acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, bb[u][c][1], acc[c][t], 0, 0, 0);
-                        acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k2, bb[u][c][2], acc[c][t], 0, 0, 0);
-                        acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k3, bb[u][c][3], acc[c][t], 0, 0, 0);
-                    }
-                }
-            }
-        };
-        const bool two = n_kb > KB;
-        load(bv[0], cw[0], 0);
-        if (two) load(bv[1], cw[1], KB);
-        compute(bv[0], cw[0]);
-        if (two) compute(bv[1], cw[1]);
-    }
-    // ---- epilogue: loads (scale, old y) before stores ----
-    float osc[RT][4], old[2][RT][4];
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = min((rt0 + t) * 16 + 4 * q + i, nloc - 1);
-            osc[t][i] = a.out_scale ? a.out_scale[r0 + row] : 1.f;
-            const float *yr = a.y + (int64_t)(r0 + row - a.y_row0) * a.ldy;
-            old[0][t][i] = a.accumulate ? yr[colc0] : 0.f;
-            old[1][t][i] = a.accumulate ? yr[colc1] : 0.f;
-        }
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (rt0 + t) * 16 + 4 * q + i;
-            if (rt0 + t >= rt1 || row >= nloc) continue;
-            float *yr = a.y + (int64_t)(r0 + row - a.y_row0) * a.ldy;
-            if (col0 < a.d) yr[col0] = acc[0][t][i] * osc[t][i] + old[0][t][i];
-            if (col1 < a.d) yr[col1] = acc[1][t][i] * osc[t][i] + old[1][t][i];
-        }
-}
-
 }  // namespace
 
 // Which prepared aggregations run here.  Measured on the Reddit-like batch (rocprofv3, profiles/r04_spmm_dense32.txt):
@@ -414,27 +299,3 @@ int launch_spmm_dense32(const int32_t *rowptr, const int32_t *col, const float *
 
 }  // namespace gist
 
-// Full-graph evaluation: y[g - y_row0] (+)= out_scale[g] * sum over the listed block pairs (rb, cb) of C_pair . x[rows of cb]
-// for the row blocks b0 .. b0 + n_row_blocks - 1 of a graph whose node ids are ordered by part (`bounds`).
-extern "C" int gist_spmm_block_pairs_f32(const int32_t *bounds, const int32_t *pair_ptr, const int32_t *pair_cb,
-                                         const void *images, int64_t b0, int64_t n_row_blocks, const float *x,
-                                         int64_t ldx, float *y, int64_t ldy, int64_t y_row0, int64_t d,
-                                         const float *out_scale, int accumulate, gist_stream_t stream) {
-    using namespace gist;
-    GIST_REQUIRE(n_row_blocks >= 0 && d >= 0 && b0 >= 0, "gist_spmm_block_pairs_f32: negative size");
-    if (n_row_blocks == 0 || d == 0) return GIST_OK;
-    GIST_REQUIRE(bounds && pair_ptr && pair_cb && images && x && y, "gist_spmm_block_pairs_f32: null pointer");
-    GIST_REQUIRE(ldx >= d && ldy >= d && d < (1LL << 22) && ldx < (1LL << 22) && ldy < (1LL << 22),
-                 "gist_spmm_block_pairs_f32: bad leading dimension");
-    GIST_REQUIRE(aligned8(images), "gist_spmm_block_pairs_f32: images must be 8-byte aligned");
-    P32Args a{};
-    a.bounds = bounds; a.pair_ptr = pair_ptr; a.pair_cb = pair_cb;
-    a.images = static_cast<const unsigned char *>(images);
-    a.b0 = (int)b0; a.n_row_blocks = (int)n_row_blocks; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.y_row0 = y_row0;
-    a.d = (int)d; a.n_col_pairs = (int)ceil_div(d, 32); a.out_scale = out_scale; a.accumulate = accumulate;
-    const int64_t tasks = n_row_blocks * 2 * a.n_col_pairs;
-    const int64_t grid = ceil_div(tasks, 4);
-    GIST_REQUIRE(grid <= 0x7fffffffLL, "gist_spmm_block_pairs_f32: grid too large");
-    hipLaunchKernelGGL(spmm_pairs32_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
-    return launch_status("gist_spmm_block_pairs_f32");
-}

@@ -84,6 +84,9 @@ struct MfArgs {
     const int32_t *row_blocks;
     int n_blocks, n_col_tiles, groups;
     const unsigned char *prep;       // prepared blocks (spmm_blocks_prepare_kernel) or NULL
+    const int32_t *units;            // NULL, or per workgroup unit (r0, r1, xs0, xs1): output rows [r0, r1), SOURCE rows
+                                     // [xs0, xs1) of x -- an off-diagonal block pair of a part-ordered graph (prepared
+                                     // counts, no outside neighbours: gist_spmm_block_units_f32)
     SpmmDrop dr;                     // dropout masks folded in (kernel template DROP = dr.mode)
 };
 
@@ -280,13 +283,17 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     if (unit >= total) return;
     const int grp = unit % a.groups;
     const int rbk = unit / a.groups;
-    int r0, r1;
-    if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
+    int r0, r1, xs0 = -1, xs1 = 0;
+    if (a.units) { r0 = a.units[4 * rbk]; r1 = a.units[4 * rbk + 1]; xs0 = a.units[4 * rbk + 2]; xs1 = a.units[4 * rbk + 3]; }
+    else if (a.row_blocks) { r0 = a.row_blocks[rbk]; r1 = a.row_blocks[rbk + 1]; }
     else { r0 = rbk * MF_ROWS; r1 = r0 + MF_ROWS; }
     r1 = min(r1, a.n_rows);
-    const int nrow = r1 - r0;
+    const int nrow = a.units ? min(r1 - r0, MF_ROWS) : r1 - r0;
     if (nrow <= 0) return;
     const int nloc = min(nrow, MF_ROWS);
+    if (xs0 < 0) { xs0 = r0; xs1 = r0 + nloc; }
+    const int nx = min(xs1 - xs0, MF_ROWS);          // source rows staged = k extent of the product
+    if (nx <= 0) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,16 +316,16 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     // vmcnt(0) at its join, which serialises the loads -- clamp the address, select when the value is used)
     auto load_tile = [&](int t) {
         const bool cok = t * MF_CT + 4 * cq < a.d;
-        const float *px = a.x + (int64_t)r0 * a.ldx + (cok ? t * MF_CT + 4 * cq : 0);
+        const float *px = a.x + (int64_t)xs0 * a.ldx + (cok ? t * MF_CT + 4 * cq : 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, nloc - 1) * a.ldx);
+            xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, nx - 1) * a.ldx);
     };
     auto first_loads = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ss[i] = a.src_scale ? a.src_scale[r0 + min(srow + i, nloc - 1)] : 1.f;
+        for (int i = 0; i < 4; ++i) ss[i] = a.src_scale ? a.src_scale[xs0 + min(srow + i, nx - 1)] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ss[i] = srow + i < nloc ? ss[i] : 0.f;
+        for (int i = 0; i < 4; ++i) ss[i] = srow + i < nx ? ss[i] : 0.f;
         if (ct < a.n_col_tiles) load_tile(ct);
     };
     if constexpr (PREP) {
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
         const uint4 c0 = reinterpret_cast<const uint4 *>(src)[2 * tid], c1 = reinterpret_cast<const uint4 *>(src)[2 * tid + 1];
         const int4 rm = tid < (MF_ROWS * (1 + MF_REM)) / 4 ? reinterpret_cast<const int4 *>(src + 16 * MF_ROWS * 16)[tid]
                                                            : make_int4(0, 0, 0, 0);
-        const int rpv = tid <= nloc ? a.rowptr[r0 + tid] : 0;
+        const int rpv = (tid <= nloc && a.units == nullptr) ? a.rowptr[r0 + tid] : 0;      // (units: no gathered rows)
         const float scv = (tid < nloc && a.out_scale) ? a.out_scale[r0 + tid] : 1.f;
         first_loads();
         reinterpret_cast<uint4 *>(ab)[2 * tid] = c0;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
 
     const int rr = lane & 15, kg = lane >> 4;
     const int mt0 = (wave >> 2) * 2, nt0 = (wave & 3) * 2;
-    const int n_ks = (nloc + 31) >> 5;
+    const int n_ks = (nx + 31) >> 5;
     const bool m_on = mt0 * 16 < nloc, m_two = (mt0 + 1) * 16 < nloc;
     // B fragment slots of this lane's two output column tiles
     int bslot[2];
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
             float xs[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool ok = cok && srow + i < nloc;                    // (clamped loads: select here)
+                const bool ok = cok && srow + i < nx;                      // (clamped loads: select here)
                 xs[i][0] = ok ? xv[i].x * ss[i] : 0.f; xs[i][1] = ok ? xv[i].y * ss[i] : 0.f;
                 xs[i][2] = ok ? xv[i].z * ss[i] : 0.f; xs[i][3] = ok ? xv[i].w * ss[i] : 0.f;
             }
@@ -602,7 +609,7 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
                      hipStream_t st, const SpmmDrop *dr) {
     GIST_REQUIRE(ldy < (1LL << 22) && ldx < (1LL << 22) && d < (1LL << 22),
                  "gist_spmm_csr_blocked_f32: row pitch of 2^22 floats or more");       // 32-bit offsets inside a block
-    MfArgs a;
+    MfArgs a{};
     a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
     a.n_rows = (int)n_rows; a.d = (int)d; a.out_scale = out_scale; a.src_scale = src_scale;
     a.accumulate = accumulate; a.row_blocks = row_blocks;
@@ -646,7 +653,54 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
     return launch_status("gist_spmm_csr_blocked_f32");
 }
 
+// Off-diagonal block pairs of a part-ordered graph (full-graph evaluation): unit u = (r0, r1, xs0, xs1) computes
+// y[r0 .. r1) (+)= out_scale . C_u . x[xs0 .. xs1) with C_u = the u-th prepared counts image (no outside neighbours).
+// Units of ONE launch must have disjoint output rows (the evaluator launches the j-th pair of every row block together).
+int launch_spmm_mfma_units(const int32_t *units, int64_t n_units, const void *prepared, const float *x, int64_t ldx,
+                           float *y, int64_t ldy, int64_t n_rows_y, int64_t d, const float *out_scale, int accumulate,
+                           hipStream_t st) {
+    GIST_REQUIRE(ldy < (1LL << 22) && ldx < (1LL << 22) && d < (1LL << 22),
+                 "gist_spmm_block_units_f32: row pitch of 2^22 floats or more");
+    MfArgs a{};
+    a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.n_rows = (int)n_rows_y; a.d = (int)d;
+    a.out_scale = out_scale; a.accumulate = accumulate; a.units = units;
+    a.prep = static_cast<const unsigned char *>(prepared);
+    a.n_blocks = (int)n_units;
+    a.n_col_tiles = (int)ceil_div(d, MF_CT);
+    int64_t groups = n_units > 0 ? 256 / n_units : 1;
+    if (groups < 1) groups = 1;
+    if (groups > a.n_col_tiles) groups = a.n_col_tiles;
+    a.groups = (int)groups;
+    const int64_t grid = kXcds * ceil_div(n_units * groups, kXcds);
+    if (grid > 0x7fffffffLL) { set_error("gist_spmm_block_units_f32: grid too large"); return GIST_EINVAL; }
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        const int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true, 0>), "gist_spmm_block_units_f32");
+        if (rc != GIST_OK) return rc;
+        once.done(dev);
+    }
+    hipLaunchKernelGGL((spmm_csr_mfma_kernel<true, 0>), dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    return launch_status("gist_spmm_block_units_f32");
+}
+
 }  // namespace gist
+
+extern "C" int64_t gist_spmm_block_image_bytes(void) { return gist::MF_PREP_STRIDE; }
+
+extern "C" int gist_spmm_block_units_f32(const int32_t *units, int64_t n_units, const void *images, const float *x,
+                                         int64_t ldx, float *y, int64_t ldy, int64_t n_rows_y, int64_t d,
+                                         const float *out_scale, int accumulate, gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(n_units >= 0 && d >= 0 && n_rows_y >= 0, "gist_spmm_block_units_f32: negative size");
+    if (n_units == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(units && images && x && y, "gist_spmm_block_units_f32: null pointer");
+    GIST_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d && aligned16(x) && aligned16(y) &&
+                     aligned16(images),
+                 "gist_spmm_block_units_f32: rows must be 16-byte aligned multiples of 4 floats");
+    return launch_spmm_mfma_units(units, n_units, images, x, ldx, y, ldy, n_rows_y, d, out_scale, accumulate,
+                                  as_stream(stream));
+}
 
 #ifdef MF_PROBE
 extern "C" int gist_mf_probe_read(unsigned long long *out) {

@@ -497,19 +497,19 @@ def spmm_drop_takes(mode, d, x, y, has_row_blocks):
     return bool(L.gist_spmm_drop_takes(int(mode), d, ldx, ldy, xp, yp, int(bool(has_row_blocks))))
 
 
-def spmm_block_pairs(bounds, pair_ptr, pair_cb, images, b0, n_row_blocks, x, y, y_row0, out_scale=None,
-                     accumulate=False):
-    """gist_spmm_block_pairs_f32: the listed dense off-diagonal blocks of a part-ordered graph as counts x features."""
+def spmm_block_units(units, images, x, y, out_scale=None, accumulate=False):
+    """gist_spmm_block_units_f32: per unit (r0, r1, xs0, xs1) y[r0:r1] (+)= scale * C_u @ x[xs0:xs1] on the bf16x3
+    matrix cores; units of one call have disjoint output rows."""
     L = _lib.load()
     xp, ldx = _mat(x, 'x')
     yp, ldy = _mat(y, 'y')
     d = x.shape[1]
+    nu = units.shape[0]
     with _Timed('spmm', (y.shape[0], x.shape[0], d)):
-        rc = L.gist_spmm_block_pairs_f32(_vec(bounds, 'bounds', torch.int32), _vec(pair_ptr, 'pair_ptr', torch.int32),
-                                         _vec(pair_cb, 'pair_cb', torch.int32), images.data_ptr(), int(b0),
-                                         int(n_row_blocks), xp, ldx, yp, ldy, int(y_row0), d,
-                                         _opt(out_scale, 'out_scale', torch.float32), int(bool(accumulate)), _stream())
-    _lib.check(rc, 'gist_spmm_block_pairs_f32')
+        rc = L.gist_spmm_block_units_f32(_vec(units, 'units', torch.int32, 4 * nu), nu, images.data_ptr(), xp, ldx, yp, ldy,
+                                         y.shape[0], d, _opt(out_scale, 'out_scale', torch.float32), int(bool(accumulate)),
+                                         _stream())
+    _lib.check(rc, 'gist_spmm_block_units_f32')
     return y
 
 

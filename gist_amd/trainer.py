@@ -74,8 +74,9 @@ class FullGraphEvaluator(object):
         self.split = None
         self.rest_tile = 512        # floats per column tile of the remainder's gather passes
         # Round 4: an OFF-diagonal pair of node blocks that shares at least this many edges is a dense block too and
-        # runs as counts x features on the fp32 matrix cores (gist_spmm_block_pairs_f32) instead of one gathered row
-        # per edge: 0.65 us of chip time per pair at D = 4096 against 2.2 ns per gathered edge = break-even ~300.
+        # runs as counts x features on the bf16x3 matrix cores (gist_spmm_block_units_f32: the batch kernel with the
+        # X tile taken from the COLUMN block) instead of one gathered row per edge: 0.7 us of chip time per pair at
+        # D = 4096 against 0.6-2.2 ns per gathered edge (cached neighbour parts ... uniform) = break-even ~300-1000.
         # A partition of a real graph cuts few block pairs heavily; the uniform block model cuts all pairs thinly
         # (10 edges per pair) and keeps the gathers.  0 = off.
         self.pair_min_edges = int(pair_min_edges) if os.environ.get('GIST_EVAL_PAIRS', '1') != '0' else 0
@@ -128,10 +129,11 @@ class FullGraphEvaluator(object):
                     # everything else: gathered, accumulated -- one column tile at a time, so that the slab of
                     # X a pass gathers from (N x rest_tile floats: 238 MB at Reddit's size) stays in the
                     # Infinity Cache instead of every gather going to HBM
-                    if sp['n_pairs'] > 0:      # dense off-diagonal blocks: counts x features, accumulated
-                        lo, hi = sp['block_range'][bi]
-                        hip.spmm_block_pairs(sp['bounds32'], sp['pair_ptr'], sp['pair_cb'], sp['images'], lo, hi - lo,
-                                             cur[:, :i], z[:, i:], r0, out_scale=self.norm, accumulate=True)
+                    if sp['n_pairs'] > 0:      # dense off-diagonal blocks: counts x features, accumulated --
+                        # the j-th pair of every row block of this chunk in one launch (disjoint output rows)
+                        for (a0, a1) in sp['rounds'].get(bi, []):
+                            hip.spmm_block_units(sp['units'][a0:a1], sp['images'][a0:a1], cur[:, :i], z[:, i:],
+                                                 out_scale=self.norm[r0:r1], accumulate=True)
                     ct = self.rest_tile
                     for c0 in range(0, i, ct if sp['rest_edges'] > 0 else i):
                         c1 = min(c0 + ct, i)
@@ -208,30 +210,52 @@ class FullGraphEvaluator(object):
             key = blk_of[er] * nb + blk_of[ec]
             uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
             dense = cnt >= self.pair_min_edges
+            stride = int(hip._lib.load().gist_spmm_block_image_bytes()) // 2      # bf16 elements per image
             for _ in range(2):                         # (second round only if a pair had a count above 256)
                 if not bool(dense.any()):
                     break
-                rank = torch.cumsum(dense.to(torch.int64), 0) - 1
+                n_pairs = int(dense.sum().item())
+                dk = uniq[dense]                       # sorted: row block major
+                rb_p, cb_p = dk // nb, dk % nb
+                first = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(torch.bincount(rb_p, minlength=nb), 0, out=first[1:])
+                j_p = torch.arange(n_pairs, device=dev) - first[rb_p]           # the pair's rank within its row block
+                chunk_p = rb_of_row[bd[rb_p]]                                    # row chunk of the evaluator's sweep
+                # launch order: (row chunk, rank, row block) -- the units of one launch have disjoint output rows
+                n_j = int(j_p.max().item()) + 1
+                order = torch.argsort((chunk_p * n_j + j_p) * nb + rb_p)
+                pos = torch.empty_like(order)
+                pos[order] = torch.arange(n_pairs, device=dev)
+                rank = torch.full((uniq.numel(),), -1, dtype=torch.int64, device=dev)
+                rank[dense] = pos
                 e_dense = dense[inv]
                 p_e = rank[inv][e_dense]
                 r_loc = er[e_dense] - bd[blk_of[er[e_dense]]]
                 k_loc = ec[e_dense] - bd[blk_of[ec[e_dense]]]
-                n_pairs = int(dense.sum().item())
                 flat = p_e * 16384 + ((k_loc >> 3) * 128 + r_loc) * 8 + (k_loc & 7)
-                counts = torch.bincount(flat, minlength=n_pairs * 16384)
-                big = counts.view(n_pairs, 16384).max(1).values > 256      # not exact in bf16: back to the gathers
+                counts = torch.bincount(flat, minlength=n_pairs * 16384).view(n_pairs, 16384)
+                big = counts.max(1).values > 256       # not exact in bf16: back to the gathers
                 if bool(big.any()):
-                    idx = torch.nonzero(dense).squeeze(1)[big]
+                    idx = torch.nonzero(dense).squeeze(1)[pos.argsort()[big]]
                     dense[idx] = False
                     del counts
                     continue
-                images = counts.to(torch.float32).to(torch.bfloat16).contiguous()
+                images = torch.zeros(n_pairs, stride, dtype=torch.bfloat16, device=dev)
+                images[:, :16384] = counts.to(torch.float32).to(torch.bfloat16)
                 del counts, flat
-                dk = uniq[dense]
-                pair_ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
-                torch.cumsum(torch.bincount(dk // nb, minlength=nb), 0, out=pair_ptr[1:])
-                pairs = dict(n_pairs=n_pairs, pair_edges=int(e_dense.sum().item()), images=images,
-                             pair_ptr=pair_ptr.to(torch.int32), pair_cb=(dk % nb).to(torch.int32).contiguous())
+                rb_o, cb_o, j_o, ch_o = rb_p[order], cb_p[order], j_p[order], chunk_p[order]
+                base = cut_t[ch_o]
+                units = torch.stack([bd[rb_o] - base, bd[rb_o + 1] - base, bd[cb_o], bd[cb_o + 1]], 1).to(torch.int32).contiguous()
+                # slices of `units` / `images` per (row chunk, rank)
+                keys = (ch_o * n_j + j_o).cpu().numpy()
+                cutsk = np.flatnonzero(np.diff(np.concatenate([[-1], keys, [-2]])) != 0)
+                rounds = {}
+                for a0, a1 in zip(cutsk[:-1], cutsk[1:]):
+                    rounds.setdefault(int(keys[a0]) // n_j, []).append((int(a0), int(a1)))
+                pair_ptr = first.to(torch.int32)
+                pairs = dict(n_pairs=n_pairs, pair_edges=int(e_dense.sum().item()), images=images, units=units,
+                             rounds=rounds, pair_ptr=pair_ptr, pair_cb=cb_p.to(torch.int32).contiguous(),
+                             pair_order=order)
                 rest_mask = rest_mask.clone()
                 rest_mask[sel[e_dense]] = False
                 break

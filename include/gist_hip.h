@@ -136,17 +136,19 @@ int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col,
  * kernel takes the widths whose rows are not 16-byte aligned).  Host function. */
 int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);
 
-/* Full-graph evaluation (cluster_gcn/utils.py:70-80) on a graph whose node ids are ordered by part: the edges between
- * a row block rb and a column block cb that share many edges (a dense off-diagonal block of the adjacency) as a counts x
- * features product on the fp32 matrix cores instead of one gathered row per edge.  bounds[n_blocks + 1] = the parts' node
- * boundaries (parts of at most 128 nodes); pair_ptr[n_blocks + 1] / pair_cb[n_pairs] = per row block the column blocks of
- * its listed pairs; images = per pair 32 KiB of bf16 edge counts (<= 256: exact) laid out [16][128 rows][8]: count of
- * (row r, source k) at ((k / 8) * 128 + r) * 8 + k % 8.  For row blocks b0 .. b0 + n_row_blocks - 1:
- *   y[g - y_row0, :d] (+)= out_scale[g] * sum over the pairs of C_pair . x[rows of cb, :d]      (g = global row)
- * with accumulate = 0 rows of blocks without pairs are written as zero.  Exact fp32 products and sums. */
-int gist_spmm_block_pairs_f32(const int32_t *bounds, const int32_t *pair_ptr, const int32_t *pair_cb,
-                              const void *images, int64_t b0, int64_t n_row_blocks, const float *x, int64_t ldx,
-                              float *y, int64_t ldy, int64_t y_row0, int64_t d, const float *out_scale,
+/* Full-graph evaluation (cluster_gcn/utils.py:70-80) on a graph whose node ids are ordered by part: the edges between a
+ * row block and a column block that share many edges (a dense off-diagonal block of the adjacency) as a counts x features
+ * product on the bf16x3 matrix cores (the kernel of gist_spmm_csr_prepared_f32: exact fp32 sums) instead of one gathered
+ * row per edge.  Rows must be 16-byte aligned multiples of 4 floats.  Unit u = units[4 u .. 4 u + 3] = (r0, r1, xs0, xs1):
+ *   y[r0 .. r1, :d] (+)= out_scale[r] * C_u . x[xs0 .. xs1, :d]
+ * with C_u the u-th image of `images`, each gist_spmm_block_image_bytes() long: bf16 edge counts (<= 256: exact), count of
+ * (row r, source k) at ((k / 8) * 128 + r) * 8 + k % 8, followed by zeros.  The units of one call must have disjoint
+ * output rows (<= 128 rows, <= 128 sources each): a caller with several column blocks per row block issues the j-th
+ * pair of every row block together, j = 0, 1, ...  0.7 us of chip time per unit at D = 4096 (an fp32-MFMA form with
+ * operands from memory was measured at 1.7 us per pair and removed: profiles/NEGATIVES.md). */
+int64_t gist_spmm_block_image_bytes(void);
+int gist_spmm_block_units_f32(const int32_t *units, int64_t n_units, const void *images, const float *x, int64_t ldx,
+                              float *y, int64_t ldy, int64_t n_rows_y, int64_t d, const float *out_scale,
                               int accumulate, gist_stream_t stream);
 
 /* ---------------------------------------------------------------------------

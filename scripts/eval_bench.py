@@ -4,8 +4,9 @@ THREE synthetic graphs that differ only in where a node's inter-part edges go (d
   0.0  uniformly random nodes -- every off-diagonal block pair holds ~10 edges: nothing but gathers (the worst case)
   0.8  80 % to the part's 8 neighbour parts, 20 % uniform
   1.0  all to the 8 neighbour parts
-Round 4: the evaluator runs dense off-diagonal block pairs (>= 300 edges) as counts x features on the fp32 matrix cores
-(gist_spmm_block_pairs_f32) next to the block-diagonal part (bf16x3 matrix cores) and gathers only the rest.
+Round 4: the evaluator runs dense off-diagonal block pairs (>= 300 edges) as counts x features on the bf16x3 matrix cores
+(gist_spmm_block_units_f32: the batch kernel with the X tile taken from the column block) next to the block-diagonal part and
+gathers only the rest.
 Prints one JSON line.
 
     python scripts/eval_bench.py [--localities 0,0.8,1] [--half-degree 225]
@@ -106,9 +107,9 @@ def variant(loc, first):
 
         def pairs():
             for bi, (r0, r1) in enumerate(cuts):
-                lo, hi = sp['block_range'][bi]
-                hip.spmm_block_pairs(sp['bounds32'], sp['pair_ptr'], sp['pair_cb'], sp['images'], lo, hi - lo, x, zr[:r1 - r0],
-                                     r0, out_scale=norm, accumulate=True)
+                for (a0, a1) in sp['rounds'].get(bi, []):
+                    hip.spmm_block_units(sp['units'][a0:a1], sp['images'][a0:a1], x, zr[:r1 - r0], out_scale=norm[r0:r1],
+                                         accumulate=True)
 
         def rest(ct=512):
             for bi, (r0, r1) in enumerate(cuts):
@@ -121,7 +122,7 @@ def variant(loc, first):
         mr = timeit(rest, 3) if sp['rest_edges'] else 0.0
         alg = 4.0 * (n + 1) + 4.0 * nnz + 8.0 * n * d
         r['aggregation_D4096'] = {
-            'ms_inside_blocks_bf16x3_matrix_cores': round(md, 3), 'ms_dense_pairs_fp32_matrix_cores': round(mp, 3),
+            'ms_inside_blocks_bf16x3_matrix_cores': round(md, 3), 'ms_dense_pairs_bf16x3_matrix_cores': round(mp, 3),
             'ms_rest_gather_512_float_tiles': round(mr, 3), 'ms_total': round(md + mp + mr, 3),
             'algorithmic_GB': round(alg / 1e9, 3), 'achieved_GBps': round(alg / (md + mp + mr) / 1e6, 1),
             'frac_of_8TBps': round(alg / (md + mp + mr) / 1e6 / 8000.0, 4),

@@ -39,7 +39,8 @@ int main(void) {
                         (void *)gist_timer_read, (void *)gist_class_layer_f32,
                         (void *)gist_class_dw_slabs_f32, (void *)gist_class_layer_takes,
                         (void *)gist_class_dw_slab_bytes, (void *)gist_spmm_csr_drop_prepared_f32,
-                        (void *)gist_spmm_prepared_useful, (void *)gist_spmm_block_pairs_f32};
+                        (void *)gist_spmm_prepared_useful, (void *)gist_spmm_block_units_f32,
+                        (void *)gist_spmm_block_image_bytes};
         size_t i;
         for (i = 0; i < sizeof syms / sizeof syms[0]; ++i)
             if (syms[i] == NULL) return 10;

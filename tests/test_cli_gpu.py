@@ -221,44 +221,63 @@ def test_evaluator_block_diagonal_split_agrees(hidden):
         FullGraphEvaluator(g, dims, True, arena, dev, node_blocks=np.array([0, 200, 5000]))      # blocks > 128
 
 
-def test_block_pairs_kernel_against_float64():
-    """gist_spmm_block_pairs_f32: y (+)= scale * sum over listed block pairs of counts x features, on unequal blocks
-    (1 .. 128 rows), a row block without pairs, a column tile that is cut (d = 100), accumulate on and off."""
-    from gist_amd import hip
+def test_block_units_kernel_against_float64():
+    """gist_spmm_block_units_f32: per unit y[r0:r1] (+)= scale * C_u @ x[xs0:xs1] on the bf16x3 matrix cores, on unequal
+    blocks (1 .. 128 rows / sources), output rows relative to a window of y, accumulate on and off, the largest exact
+    count (256)."""
+    from gist_amd import hip, _lib
     dev = torch.device('cuda', 0)
     rs = np.random.RandomState(0)
     sizes = np.array([100, 128, 1, 57, 128, 90])
     bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    n, nb = int(bounds[-1]), len(sizes)
-    pairs = [(0, 1), (0, 3), (1, 0), (1, 5), (2, 4), (4, 0), (4, 1), (4, 2), (5, 3)]          # (row block 3: none)
-    A = np.zeros((n, n))
-    imgs = np.zeros((len(pairs), 16, 128, 8), np.float32)
-    for p, (rb, cb) in enumerate(pairs):
-        c = rs.poisson(0.4, (sizes[rb], sizes[cb])).astype(np.float64)
-        c[rs.randint(0, sizes[rb]), rs.randint(0, sizes[cb])] = 256           # the largest exact count
-        A[bounds[rb]:bounds[rb + 1], bounds[cb]:bounds[cb + 1]] = c
-        for k in range(sizes[cb]):
-            imgs[p, k // 8, :sizes[rb], k % 8] = c[:, k]
-    ptr = np.zeros(nb + 1, np.int32)
-    for rb, _ in pairs:
-        ptr[rb + 1] += 1
-    ptr = np.cumsum(ptr).astype(np.int32)
-    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    images = t32(imgs).to(torch.bfloat16).contiguous()
+    n = int(bounds[-1])
+    stride = int(_lib.load().gist_spmm_block_image_bytes()) // 2
+    assert stride >= 16384
+    # one launch = pairs with disjoint output rows: (row block, column block)
+    launches = [[(0, 1), (1, 0), (2, 4), (4, 0), (5, 3)], [(0, 3), (1, 5), (4, 1)], [(4, 2)]]
     scale = rs.rand(n).astype(np.float32) + 0.5
-    for d in (100, 64, 512):
-        x = rs.randn(n, d + 3).astype(np.float32)
-        y0 = rs.randn(n, d).astype(np.float32)
-        ref = (A @ x[:, :d].astype(np.float64)) * scale[:, None]
-        for acc in (False, True):
-            # row blocks 1 .. 4 only (a slice of the graph), y holding those rows from y_row0 = bounds[1]
-            lo, hi = 1, 5
-            y = t32(y0[bounds[lo]:bounds[hi]].copy())
-            hip.spmm_block_pairs(t32(bounds.astype(np.int32)), t32(ptr), t32(np.array([cb for _, cb in pairs], np.int32)),
-                                 images, lo, hi - lo, t32(x)[:, :d], y, int(bounds[lo]), out_scale=t32(scale),
-                                 accumulate=acc)
-            want = ref[bounds[lo]:bounds[hi]] + (y0[bounds[lo]:bounds[hi]] if acc else 0.0)
-            assert np.abs(y.cpu().numpy() - want).max() < 2e-5 * max(1.0, np.abs(want).max()), (d, acc)
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for d in (512, 128, 260):
+        x = rs.randn(n, d + 4).astype(np.float32)
+        lo, hi = 0, n                                           # y window = all rows, then a sub-window below
+        for win in ((0, n), (int(bounds[1]), int(bounds[5]))):
+            y0 = rs.randn(win[1] - win[0], d).astype(np.float32)
+            y = t32(y0.copy())
+            ref = y0.astype(np.float64)
+            for pairs in launches:
+                pairs = [(rb, cb) for rb, cb in pairs if bounds[rb] >= win[0] and bounds[rb + 1] <= win[1]]
+                if not pairs:
+                    continue
+                imgs = np.zeros((len(pairs), stride), np.float32)
+                units = np.zeros((len(pairs), 4), np.int32)
+                for u, (rb, cb) in enumerate(pairs):
+                    c = rs.poisson(0.4, (sizes[rb], sizes[cb])).astype(np.float64)
+                    c[rs.randint(0, sizes[rb]), rs.randint(0, sizes[cb])] = 256
+                    im = np.zeros((16, 128, 8), np.float32)
+                    for k in range(sizes[cb]):
+                        im[k // 8, :sizes[rb], k % 8] = c[:, k]
+                    imgs[u, :16384] = im.ravel()
+                    units[u] = (bounds[rb] - win[0], bounds[rb + 1] - win[0], bounds[cb], bounds[cb + 1])
+                    ref[bounds[rb] - win[0]:bounds[rb + 1] - win[0]] += \
+                        (c @ x[bounds[cb]:bounds[cb + 1], :d].astype(np.float64)) * scale[bounds[rb]:bounds[rb + 1], None]
+                hip.spmm_block_units(t32(units), t32(imgs).to(torch.bfloat16).contiguous(), t32(x)[:, :d], y,
+                                     out_scale=t32(scale[win[0]:win[1]].copy()), accumulate=True)
+            assert np.abs(y.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (d, win)
+        # accumulate = 0 overwrites the unit's rows
+        rb, cb = 3, 4
+        c = rs.poisson(0.4, (sizes[rb], sizes[cb])).astype(np.float64)
+        im = np.zeros((16, 128, 8), np.float32)
+        for k in range(sizes[cb]):
+            im[k // 8, :sizes[rb], k % 8] = c[:, k]
+        img = np.zeros((1, stride), np.float32)
+        img[0, :16384] = im.ravel()
+        y = torch.full((n, d), 7.0, device=dev)
+        hip.spmm_block_units(t32(np.array([[bounds[rb], bounds[rb + 1], bounds[cb], bounds[cb + 1]]], np.int32)),
+                             t32(img).to(torch.bfloat16).contiguous(), t32(x)[:, :d], y, accumulate=False)
+        want = c @ x[bounds[cb]:bounds[cb + 1], :d].astype(np.float64)
+        got = y.cpu().numpy()
+        assert np.abs(got[bounds[rb]:bounds[rb + 1]] - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+        assert np.all(got[:bounds[rb]] == 7.0) and np.all(got[bounds[rb + 1]:] == 7.0)
 
 
 @pytest.mark.parametrize('locality', [0.8, 1.0])
