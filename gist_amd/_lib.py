@@ -88,6 +88,8 @@ SIGNATURES = {
     'gist_spmm_block_units_f32': (_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),
     'gist_spmm_prepared_useful': (_int, [_i64, _i64, _i64, _p, _p]),
     'gist_spmm_drop_takes': (_int, [_int, _i64, _i64, _i64, _p, _p, _int]),
+    'gist_gemm_dual_takes': (_int, [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p]),
+    'gist_gemm_nn_tn_dual_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _p]),
     'gist_gemm_slabs_f32': (_int, [_int, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _p]),
     'gist_ln_relu_fwd_drop_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _f, _f, _u64,
                                          _u64, _i64, _p]),
@@ -120,7 +122,7 @@ SIGNATURES = {
 
 GIST_MAX_LAYERS = 16
 TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_splits': 4,
-        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9}
+        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9, 'gemm_dual': 10}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 

@@ -99,6 +99,12 @@ int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t 
                int64_t ldc, int64_t m, int64_t n, int64_t k, void *slabs, int64_t slab_bytes, int *n_slabs,
                hipStream_t st);
 int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k);
+// gemm.hip: dz = dy . w (NN) and dW = dy^T . z (TN, slabs) in one launch of the fp32 kernel's tiles
+bool gemm_dual_takes(int64_t m, int64_t n1, int64_t k1, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz,
+                     const float *dy, const float *w, const float *z, const float *dz);
+int gemm_dual_nn_tn(const char *name, const float *dy, int64_t lddy, const float *w, int64_t ldw, float *dz,
+                    int64_t lddz, const float *z, int64_t ldz, float *dw, int64_t lddw, int64_t m, int64_t n1,
+                    int64_t k1, void *slabs, int64_t slab_bytes, int *n_slabs, hipStream_t st);
 // gemm.hip: c[m, n] (ldc) = sum of `splits` dense slabs [m][n] + bias
 int splitk_reduce(const char *name, const float *slabs, int64_t slab, int splits, const float *bias, float *c,
                   int64_t ldc, int64_t m, int64_t n, hipStream_t st);

@@ -314,8 +314,10 @@ __device__ unsigned long long g_gemm_trace[12 * 16384];
 // ALIGNED: both operands have 16-B aligned bases and leading dimensions % 4 == 0
 // (every buffer the engine allocates); otherwise the generic guarded loader runs.
 // T = block tile edge (128 or 64); 4 waves in 2x2, each wave (T/2)x(T/2) = (T/64)^2 MFMA tiles.
+// The kernel's body as a device function of (arguments, tile index, k slice): gemm_f32_kernel runs it on its own grid,
+// gemm_f32_dual_kernel (below) runs TWO products' tiles in one grid.
 template <bool A_KC, bool B_KC, bool ALIGNED, int T>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int block_x, const int block_z) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GIST_TRACE(0)
     constexpr int BK = T == 128 ? 32 : 64;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
     // ---- block -> output tile, 8x8 super-tiles per XCD ------------------------
     const int nwg = g.tiles_m * g.tiles_n;
-    const int orig = blockIdx.x;
+    const int orig = block_x;
     const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
     const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
     constexpr int GM = 8;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int bn = (L % width) / gsz;
     const int row0 = bm * T, col0 = bn * T;
 
-    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_begin = block_z * g.k_per_split;
     const int k_end = min(g.k, k_begin + g.k_per_split);
     const int n_kt = (k_end - k_begin + BK - 1) / BK;
 
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     // covers exactly the valid rows of this tile, per-lane column offset computed once (columns
     // >= n get an out-of-range offset and are dropped by the hardware range check), and the
     // row advance in a scalar offset.
-    float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride + (int64_t)row0 * g.ldc + col0;
+    float *cbase = g.c + (int64_t)block_z * g.split_stride + (int64_t)row0 * g.ldc + col0;
     const bool add_bias = g.bias != nullptr && g.split_stride == 0;
     const int rows_valid = min(g.m - row0, T);
     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -569,6 +571,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         g_gemm_trace[12 * blockIdx.x + 10] = (unsigned long long)n_kt;
     }
 #endif
+}
+
+template <bool A_KC, bool B_KC, bool ALIGNED, int T>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    gemm_f32_body<A_KC, B_KC, ALIGNED, T>(g, (int)blockIdx.x, (int)blockIdx.z);
+}
+
+// Two INDEPENDENT products in one launch (round 4): the backward of a hidden layer needs dZ = dY . W (NN) and
+// dW = dY^T . Z (TN, k split into slabs for the optimiser) from the same dY; at the per-rank widths each of them fills
+// a fraction of the chip for 10-22 us (128-512 tiles of 64 x 64, one 32 x 32 MFMA tile per wave), and one after the
+// other they cost their sum.  Workgroups [0, n1) run the first product's tiles, the rest the second's (tile index and
+// k slice flattened into blockIdx.x); both are the fp32 kernel's own body, so the results are bit-identical to the
+// two separate launches.
+template <int T>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dual_kernel(GemmArgs g1, GemmArgs g2, int n1, int tiles1, int tiles2) {
+    const int b = (int)blockIdx.x;
+    if (b < n1) gemm_f32_body<true, false, true, T>(g1, b % tiles1, b / tiles1);
+    else gemm_f32_body<false, false, true, T>(g2, (b - n1) % tiles2, (b - n1) / tiles2);
 }
 
 // C[m,n] = sum_s slab_s[m,n] + bias[n]; slabs are dense [m][n].
@@ -750,6 +770,71 @@ static int launch_gemm(const char *name, const float *a, int64_t lda, const floa
     return launch_status(name);
 }
 
+// dz[m, n1] = dy[m, k1] . w[k1, n1]  (NN)   and   dW[k1, n1] = dy[m, k1]^T . z[m, n1]  (TN: k = m rows, left as
+// *n_slabs dense slabs [k1][n1] at `slabs` for the consumer, or written to dw when one slice) in ONE launch.
+// Taken (gemm_dual_takes) when both run on the fp32 kernel's 64 x 64 tiles anyway and together fit ~one round of the
+// chip's workgroup slots: the per-rank widths <= 512 and config 2.
+static bool dual_shapes_ok(int64_t m, int64_t n1, int64_t k1, int *splits_out) {
+    if (m <= 0 || n1 <= 0 || k1 <= 0 || (int)tune(GIST_TUNE_GEMM_DUAL) == 1) return false;
+    if (tune(GIST_TUNE_GEMM_TILE) != 0.0 || tune(GIST_TUNE_GEMM_SPLITS) != 0.0) return false;
+    if (h3_eligible(m, n1, k1) || b3_eligible(m, n1, k1) || h3_eligible(k1, n1, m) || b3_eligible(k1, n1, m)) return false;
+    const GemmCfg c1 = choose_cfg(m, n1, k1), c2 = choose_cfg(k1, n1, m, true);
+    if (c1.tile != 64 || c2.tile != 64 || c1.splits != 1) return false;
+    const int64_t blocks = ceil_div(m, 64) * ceil_div(n1, 64) + ceil_div(k1, 64) * ceil_div(n1, 64) * c2.splits;
+    if (blocks > 1280) return false;           // (2 workgroups per CU resident: beyond ~2.5 rounds each product fills the chip alone)
+    if (splits_out) *splits_out = c2.splits;
+    return true;
+}
+
+bool gemm_dual_takes(int64_t m, int64_t n1, int64_t k1, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz,
+                     const float *dy, const float *w, const float *z, const float *dz) {
+    return dual_shapes_ok(m, n1, k1, nullptr) && lddy % 4 == 0 && ldw % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 &&
+           lddy >= k1 && ldw >= n1 && ldz >= n1 && lddz >= n1 && lddy < (1LL << 22) && ldw < (1LL << 22) &&
+           ldz < (1LL << 22) && lddz < (1LL << 22) && m < (1LL << 31) && aligned16(dy) && aligned16(w) && aligned16(z) &&
+           aligned16(dz);
+}
+
+int gemm_dual_nn_tn(const char *name, const float *dy, int64_t lddy, const float *w, int64_t ldw, float *dz,
+                    int64_t lddz, const float *z, int64_t ldz, float *dw, int64_t lddw, int64_t m, int64_t n1,
+                    int64_t k1, void *slabs, int64_t slab_bytes, int *n_slabs, hipStream_t st) {
+    int splits = 1;
+    if (!dual_shapes_ok(m, n1, k1, &splits) || !gemm_dual_takes(m, n1, k1, lddy, ldw, ldz, lddz, dy, w, z, dz)) {
+        set_error("%s: shape not taken (gist_gemm_dual_takes)", name);
+        return GIST_EINVAL;
+    }
+    if (!dw || !n_slabs || lddw < n1) { set_error("%s: bad dW / n_slabs", name); return GIST_EINVAL; }
+    GemmArgs g1{}, g2{};
+    g1.a = dy; g1.lda = lddy; g1.b = w; g1.ldb = ldw; g1.bias = nullptr; g1.c = dz; g1.ldc = lddz;
+    g1.m = (int)m; g1.n = (int)n1; g1.k = (int)k1; g1.setprio = 1;
+    g1.k_per_split = (int)(ceil_div(k1, 64) * 64); g1.split_stride = 0;
+    g1.tiles_m = (int)ceil_div(m, 64); g1.tiles_n = (int)ceil_div(n1, 64);
+    g2.a = dy; g2.lda = lddy; g2.b = z; g2.ldb = ldz; g2.bias = nullptr; g2.setprio = 1;
+    g2.m = (int)k1; g2.n = (int)n1; g2.k = (int)m;
+    while (splits > 1 && (slabs == nullptr || slab_bytes < (int64_t)splits * k1 * n1 * 4)) splits >>= 1;
+    g2.k_per_split = (int)(ceil_div(ceil_div(m, 64), splits) * 64);
+    splits = (int)ceil_div(m, g2.k_per_split > 0 ? g2.k_per_split : 1);
+    if (splits < 1) splits = 1;
+    if (splits == 1) { g2.c = dw; g2.ldc = lddw; g2.split_stride = 0; }
+    else { g2.c = static_cast<float *>(slabs); g2.ldc = n1; g2.split_stride = k1 * n1; }
+    g2.tiles_m = (int)ceil_div(k1, 64); g2.tiles_n = (int)ceil_div(n1, 64);
+    constexpr int T = 64, BK = 64;
+    constexpr size_t smem = (size_t)2 * (Img<T, BK>::KC + Img<T, BK>::MC) * sizeof(float);   // (KC == MC: either body fits)
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f32_dual_kernel<64>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return GIST_ELAUNCH; }
+        once.done(dev);
+    }
+    const int tiles1 = g1.tiles_m * g1.tiles_n, tiles2 = g2.tiles_m * g2.tiles_n;
+    const int n1b = tiles1;
+    hipLaunchKernelGGL((gemm_f32_dual_kernel<64>), dim3((unsigned)(n1b + tiles2 * splits)), dim3(256), smem, st, g1, g2,
+                       n1b, tiles1, tiles2);
+    *n_slabs = splits;
+    return launch_status(name);
+}
+
 void gemm_f32_choice(int64_t m, int64_t n, int64_t k, int *tile, int *splits) {
     const GemmCfg c = choose_cfg(m, n, k);
     *tile = c.tile;
@@ -788,6 +873,23 @@ int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t 
 }
 
 }  // namespace gist
+
+extern "C" int gist_gemm_dual_takes(int64_t m, int64_t n, int64_t k, int64_t lddy, int64_t ldw, int64_t ldz,
+                                    int64_t lddz, const float *dy, const float *w, const float *z, const float *dz) {
+    return gist::gemm_dual_takes(m, n, k, lddy, ldw, ldz, lddz, dy, w, z, dz) ? 1 : 0;
+}
+
+extern "C" int gist_gemm_nn_tn_dual_f32(const float *dy, int64_t lddy, const float *w, int64_t ldw, float *dz,
+                                        int64_t lddz, const float *z, int64_t ldz, float *dw, int64_t lddw, int64_t m,
+                                        int64_t n, int64_t k, void *slabs, int64_t slab_bytes, int32_t *n_slabs,
+                                        gist_stream_t stream) {
+    GIST_REQUIRE(dy && w && dz && z && dw && n_slabs, "gist_gemm_nn_tn_dual_f32: null pointer");
+    int ns = 1;
+    const int rc = gist::gemm_dual_nn_tn("gist_gemm_nn_tn_dual_f32", dy, lddy, w, ldw, dz, lddz, z, ldz, dw, lddw, m, n, k,
+                                         slabs, slab_bytes, &ns, gist::as_stream(stream));
+    *n_slabs = ns;
+    return rc;
+}
 
 extern "C" int gist_gemm_slabs_f32(int layout, const float *a, int64_t lda, const float *b, int64_t ldb,
                                    const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,

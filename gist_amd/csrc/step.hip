@@ -765,7 +765,24 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
             continue;
         }
-        if (cls_fused && k == L1 - 1) {
+        // dZ_k and dW_k of a narrow hidden layer read the same dY_k: one launch of the fp32 kernel's tiles for both
+        // (gist_gemm_nn_tn_dual_f32) when the mask of dZ_k is the reverse aggregation's business anyway
+        bool dual_done = false;
+        if (defer && k > 0 && k < L1 - 1 && db_done && (!drop || bwd_fold[k]) &&
+            gemm_dual_takes(n, 2 * l.n_in, l.n_out, lddy, 2 * l.n_in, l.ldz, 2 * l.n_in, dy, l.W, l.Z, p->dZ)) {
+            Scope sc(p->timer, 1, n, 4 * l.n_in, l.n_out, st);
+            int ns = 1;
+            GIST_TRY(gemm_dual_nn_tn("gist_sage_step", dy, lddy, l.W, 2 * l.n_in, p->dZ, 2 * l.n_in, l.Z, l.ldz, l.dW,
+                                     2 * l.n_in, n, 2 * l.n_in, l.n_out, fl.dw_slabs[k], fl.dw_bytes[k], &ns, st));
+            if (ns > 1) {
+                gist_grad_segment &g = segs[n_segs++];
+                g.begin = l.dW - p->grads; g.end = g.begin + l.n_out * 2 * l.n_in;
+                g.src = fl.dw_slabs[k]; g.stride = l.n_out * 2 * l.n_in; g.n_src = ns;
+            }
+            dual_done = true;
+        }
+        if (dual_done) {
+        } else if (cls_fused && k == L1 - 1) {
             db_done = true;      // (dZ and the bias chunks came with the loss)
         } else if (k > 0) {      // dZ with its dropout mask (or the mask left to the reverse aggregation)
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
@@ -776,7 +793,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                         chunk_db ? fl.partials[k] : nullptr, st));
             db_done = db_done || chunk_db;
         }
-        {
+        if (!dual_done) {
             Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
             if (cls_fused && k == L1 - 1) {
                 int32_t ns = 1;

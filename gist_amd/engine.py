@@ -589,18 +589,28 @@ class SageEngine(object):
                     hip.spmm(b.t_rowptr, b.t_col, dz[:, i:], dz[:, :i], src_scale=b.norm,
                              accumulate=True, row_blocks=b.row_blocks, prepared=pb if blocked else None)
                 continue
+            dual_done = False
             if k > 0:
                 dz = self.dZ[:n * 2 * i].view(n, 2 * i)
                 bwd_fold = (self.fuse and drop and k < self.L1 - 1 and
                             hip.spmm_drop_takes(2, i, dz[:, i:], dz[:, :i], blocked))
                 p_here = self.p_drop if (drop and not bwd_fold) else 0.0
                 off = self._drop_offsets[k] if drop else 0
-                if defer and k == self.L1 - 1:
+                # gist_sage_step: dZ_k and dW_k of a narrow hidden layer in one launch (gist_gemm_nn_tn_dual_f32)
+                if (defer and k < self.L1 - 1 and db_done and p_here == 0.0 and
+                        hip.gemm_dual_takes(dy, A.W[k], z, dz)):
+                    ns = hip.gemm_nn_tn_dual(dy, A.W[k], dz, z, A.dW[k], fb['dw'][k])
+                    if ns > 1:
+                        self._segments.append((goff(A.dW[k]), goff(A.dW[k]) + o * 2 * i, fb['dw'][k], o * 2 * i, ns))
+                    dual_done = True
+                elif defer and k == self.L1 - 1:
                     hip.gemm_nn_dropout_colsum_(dy, A.W[k], dz, p_here, self.seed, off, fb['partials'][k])
                     db_done = True
                 else:
                     hip.gemm_nn_dropout_(dy, A.W[k], dz, p_here, self.seed, off)
-            if defer and fb['dw'][k] is not None:
+            if dual_done:
+                pass
+            elif defer and fb['dw'][k] is not None:
                 ns = hip.gemm_slabs('tn', dy, z, None, A.dW[k], fb['dw'][k])
                 if ns > 1:
                     self._segments.append((goff(A.dW[k]), goff(A.dW[k]) + o * 2 * i, fb['dw'][k], o * 2 * i, ns))

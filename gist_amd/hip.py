@@ -556,6 +556,37 @@ def spmm_drop(rowptr, col, x, y, mode, p, seed, y_offset, src_offset, mask_ld, o
     return y
 
 
+def gemm_dual_takes(dy, w, z, dz):
+    """Does gist_gemm_nn_tn_dual_f32 take this hidden layer's backward (dy [m, k], w [k, n], z [m, n], dz [m, n])?"""
+    L = _lib.load()
+    yp, lddy = _mat(dy, 'dy')
+    wp, ldw = _mat(w, 'w')
+    zp, ldz = _mat(z, 'z')
+    dp, lddz = _mat(dz, 'dz')
+    return bool(L.gist_gemm_dual_takes(dy.shape[0], w.shape[1], dy.shape[1], lddy, ldw, ldz, lddz, yp, wp, zp, dp))
+
+
+def gemm_nn_tn_dual(dy, w, dz, z, dw, slabs):
+    """gist_gemm_nn_tn_dual_f32: dz = dy @ w and dW = dy.T @ z (slabs) in one launch; returns the slab count."""
+    import ctypes
+    L = _lib.load()
+    yp, lddy = _mat(dy, 'dy')
+    wp, ldw = _mat(w, 'w')
+    zp, ldz = _mat(z, 'z')
+    dp, lddz = _mat(dz, 'dz')
+    gp, lddw = _mat(dw, 'dw')
+    m, k = dy.shape
+    n = w.shape[1]
+    ns = ctypes.c_int32(0)
+    with _Timed('gemm', ('nn+tn', m, 2 * n, k)):
+        rc = L.gist_gemm_nn_tn_dual_f32(yp, lddy, wp, ldw, dp, lddz, zp, ldz, gp, lddw, m, n, k,
+                                        slabs.data_ptr() if slabs is not None else None,
+                                        slabs.numel() * slabs.element_size() if slabs is not None else 0,
+                                        ctypes.byref(ns), _stream())
+    _lib.check(rc, 'gist_gemm_nn_tn_dual_f32')
+    return int(ns.value)
+
+
 def gemm_slabs(layout, a, b, bias, c, slabs):
     """gist_gemm_slabs_f32: layout 'nt' (c = a @ b.T + bias), 'nn' (c = a @ b), 'tn' (c = a.T @ b).
     Returns the slab count (1: c is final)."""

@@ -253,7 +253,8 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_SPMM_KERNEL 7   /* blocked SpMM: 1 = LDS gather kernel, 2 = block-dense bf16x3 MFMA kernel, 3 = fp32 block-dense kernel at every width (prepared calls) */
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
 #define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off) */
-#define GIST_TUNE_COUNT 10
+#define GIST_TUNE_GEMM_DUAL 10    /* backward of a narrow hidden layer: 1 = dZ and dW as two launches (gist_gemm_nn_tn_dual_f32 off) */
+#define GIST_TUNE_COUNT 11
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
 
@@ -365,6 +366,22 @@ int64_t gist_class_dw_slab_bytes(int64_t n_rows, int64_t n_classes, int64_t k);
 int gist_class_dw_slabs_f32(const float *d_logits, int64_t ldg, const float *z, int64_t ldz,
                             float *slabs, int64_t slab_bytes, int32_t *n_slabs, int64_t n_rows,
                             int64_t n_classes, int64_t k, gist_stream_t stream);
+
+/* The two products of a hidden layer's backward that read the same gradient, in ONE launch (round 4):
+ *   dz[m, n] = dy[m, k] . w[k, n]                       (autograd of nn.Linear wrt its input, modules.py:233)
+ *   dW[k, n] = dy[m, k]^T . z[m, n]                     (wrt its weight; reduction over the m rows)
+ * dW is left as *n_slabs dense fp32 slabs [k][n] at `slabs` for the consumer to sum in slab order
+ * (gist_adam_segments_f32), or written to dw when *n_slabs = 1.  Both run the fp32 kernel's own 64 x 64 tiles
+ * (v_mfma_f32_32x32x2_f32), so the results equal gist_gemm_nn_f32 / gist_gemm_slabs_f32 bit for bit; what the call
+ * removes is the second launch: at the per-rank widths either product fills a fraction of the chip for 10-22 us.
+ * gist_gemm_dual_takes: 1 if the shapes are taken (both products small enough that they share the chip: at most
+ * 1280 workgroups together; 16-byte aligned operands, leading dimensions % 4 == 0; neither large enough for a
+ * split-operand kernel). */
+int gist_gemm_dual_takes(int64_t m, int64_t n, int64_t k, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz,
+                         const float *dy, const float *w, const float *z, const float *dz);
+int gist_gemm_nn_tn_dual_f32(const float *dy, int64_t lddy, const float *w, int64_t ldw, float *dz, int64_t lddz,
+                             const float *z, int64_t ldz, float *dw, int64_t lddw, int64_t m, int64_t n, int64_t k,
+                             void *slabs, int64_t slab_bytes, int32_t *n_slabs, gist_stream_t stream);
 
 /* out[j] = sum_i g[i, j], deterministic two-stage reduction.
  * `partials` must hold gist_colsum_partials(n_rows) * d floats.

@@ -40,7 +40,8 @@ int main(void) {
                         (void *)gist_class_dw_slabs_f32, (void *)gist_class_layer_takes,
                         (void *)gist_class_dw_slab_bytes, (void *)gist_spmm_csr_drop_prepared_f32,
                         (void *)gist_spmm_prepared_useful, (void *)gist_spmm_block_units_f32,
-                        (void *)gist_spmm_block_image_bytes};
+                        (void *)gist_spmm_block_image_bytes, (void *)gist_gemm_dual_takes,
+                        (void *)gist_gemm_nn_tn_dual_f32};
         size_t i;
         for (i = 0; i < sizeof syms / sizeof syms[0]; ++i)
             if (syms[i] == NULL) return 10;

@@ -276,7 +276,10 @@ def _native_vs_op_by_op(n_layers, use_ln, p_drop, n_feats, n_hidden):
             # (round 4: the class layer's projection and dZ are ONE launch -- gist_class_layer_f32 -- where it is taken)
             k_cls, c_cls = 2 * dims[-1][0], dims[-1][1]
             cls_fused = k_cls % 64 == 0 and k_cls <= 1024 and c_cls <= 48
-            assert len(rec) == 4 * (5 * len(dims) - 2 - (1 if cls_fused else 0))
+            # (and dZ + dW of a narrow hidden layer are ONE launch -- gist_gemm_nn_tn_dual_f32 -- where the shapes are
+            # taken: up to len(dims) - 2 records fewer per step)
+            full = 4 * (5 * len(dims) - 2 - (1 if cls_fused else 0))
+            assert full - 4 * max(len(dims) - 2, 0) <= len(rec) <= full, (len(rec), full)
             assert all(ms > 0 for ms, *_ in rec)
             eng.disable_timer()
         results.append((eng.arena.params.clone(), torch.stack(losses)))

@@ -515,3 +515,43 @@ def test_blocked_aggregation_only_with_locality(hip):
         opt = O.new_opt_state(params)
         ref, _, _ = O.train_step(b[0], b[1], b[2], b[3], b[4], b[5], params, opt, True, 0.01)
         assert abs(float(loss.item()) - float(ref)) < 1e-4
+
+
+@pytest.mark.parametrize('m,n,k', [(2046, 1024, 512), (1140, 1024, 512), (2046, 512, 256), (300, 192, 96), (2046, 2048, 1024)])
+def test_gemm_nn_tn_dual_equals_the_two_launches(hip, m, n, k):
+    """gist_gemm_nn_tn_dual_f32 (dz = dy . w and dW = dy^T . z as slabs, ONE launch of the fp32 kernel's tiles) against
+    gist_gemm_nn_f32 and gist_gemm_slabs_f32 on the fp32 kernel: bit for bit, slab by slab; shapes the call does not take
+    are refused."""
+    from gist_amd import _lib
+    L = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(m + n)
+    dy = torch.randn(m, k, device=DEV, generator=gen)
+    w = torch.randn(k, n, device=DEV, generator=gen)
+    z = torch.randn(m, n, device=DEV, generator=gen)
+    dz, dz_ref = torch.zeros(m, n, device=DEV), torch.zeros(m, n, device=DEV)
+    dw, dw_ref = torch.zeros(k, n, device=DEV), torch.zeros(k, n, device=DEV)
+    nb = max(int(L.gist_gemm_workspace_bytes(k, n, m)), 32 * k * n * 4)
+    slabs, slabs_ref = torch.zeros(nb // 4, device=DEV), torch.zeros(nb // 4, device=DEV)
+    takes = hip.gemm_dual_takes(dy, w, z, dz)
+    assert takes == ((m, n, k) != (2046, 2048, 1024))          # (1536 workgroups: each product fills the chip alone)
+    if not takes:
+        with pytest.raises(Exception):
+            hip.gemm_nn_tn_dual(dy, w, dz, z, dw, slabs)
+        return
+    prev = hip.gemm_mode()
+    hip.gemm_mode('f32')
+    try:
+        ns = hip.gemm_nn_tn_dual(dy, w, dz, z, dw, slabs)
+        hip.gemm_nn(dy, w, dz_ref)
+        ns_ref = hip.gemm_slabs('tn', dy, z, None, dw_ref, slabs_ref)
+    finally:
+        hip.gemm_mode(prev)
+    assert torch.equal(dz, dz_ref)
+    assert ns == ns_ref
+    if ns > 1:
+        assert torch.equal(slabs[:ns * k * n], slabs_ref[:ns * k * n])
+    else:
+        assert torch.equal(dw, dw_ref)
+    ref = dy.double().t() @ z.double()
+    got = slabs[:ns * k * n].view(ns, k, n).double().sum(0) if ns > 1 else dw.double()
+    assert (got - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
