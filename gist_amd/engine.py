@@ -298,6 +298,25 @@ class SageEngine(object):
             raise RuntimeError('gist_amd: gist_extract_parts_batch timed out at its grid barrier; '
                                'the batches extracted since the last check are invalid')
 
+    def check_extract_deferred(self):
+        """The same check without draining the queue: raises for the error word copied out at the PREVIOUS call (its
+        copy has long completed), then starts an asynchronous copy of the current word into pinned host memory."""
+        if self._extract_scratch is None:
+            return
+        pend = getattr(self, '_extract_pending', None)
+        if pend is not None:
+            host, ev = pend
+            ev.synchronize()
+            if int(host[0].item()) != 0:
+                raise RuntimeError('gist_amd: gist_extract_parts_batch timed out at its grid barrier; '
+                                   'the batches extracted since the last check are invalid')
+        else:
+            host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        host.copy_(self._extract_scratch[1:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._extract_pending = (host, ev)
+
     def enable_timer(self, capacity):
         """HIP-event timing of every SpMM/GEMM issued by the native step (gist_timer_*)."""
         from . import _lib

@@ -307,6 +307,9 @@ def train(ist_model, args, cluster_iterator, evaluator=None, log=print):
                 if run_eval or last:                                     # :431-450
                     sync_dev()
                     total_time += time.time() - start_time
+                    for m in models:                 # (the device is idle: every extraction so far was complete)
+                        if m.engine is not None:
+                            m.engine.check_extract()
                     run_eval = False
                     events.append('eval')
                     if is_rank0 and evaluator is not None:

@@ -213,50 +213,76 @@ class EngineClusterIter(ClusterIter):
         sub-GCNs trained in one process share one extracted batch)."""
         hip.gather_rows(self.batcher.feat, batch.ids, engine.z0_left(batch.n))
 
-    def _upload_epoch(self):
-        used = self.par_li[:self.max * self.batch_size]
-        sizes = np.array([len(p) for p in used], np.int64)
+    def _host_epoch_tables(self):
+        """Everything the device needs for one epoch, computed on the HOST from the (already shuffled) part order,
+        vectorised: the epoch's node ids, per batch its row offsets and the row ranges of its parts (cut at 128 rows:
+        the LDS-staged / block-dense aggregations take one block at a time), and -- for the one-launch extraction --
+        per part the batch it belongs to this epoch and its first row there."""
+        mx, bs = self.max, self.batch_size
+        used = self.par_li[:mx * bs]
+        sizes = np.fromiter((len(p) for p in used), np.int64, len(used))
         ids = np.concatenate(used).astype(np.int32) if len(used) else np.zeros(0, np.int32)
-        off = np.zeros(self.max + 1, np.int64)
-        per_batch = sizes.reshape(self.max, self.batch_size).sum(1) if self.max else sizes[:0]
+        per_batch = sizes.reshape(mx, bs).sum(1) if mx else sizes[:0]
+        off = np.zeros(mx + 1, np.int64)
         np.cumsum(per_batch, out=off[1:])
-        self._epoch_ids = torch.from_numpy(ids).to(self.g.device, non_blocking=False)
-        self._offsets = off
-        # locality blocks of every batch (row ranges of its METIS parts, cut at 128 rows: the
-        # LDS-staged aggregation stages one block's feature tile at a time), uploaded with the ids
-        blocks, boff = [], np.zeros(self.max + 1, np.int64)
-        for i in range(self.max):
-            edges, pos = [0], 0
-            for sz in sizes[i * self.batch_size:(i + 1) * self.batch_size]:
-                sz = int(sz)
-                for c in range(0, sz, 128):
-                    edges.append(pos + min(c + 128, sz))
-                pos += sz
-            blocks.append(np.asarray(edges, np.int32))
-            boff[i + 1] = boff[i] + len(edges)
-        self._epoch_blocks = torch.from_numpy(
-            np.concatenate(blocks) if blocks else np.zeros(0, np.int32)).to(self.g.device)
-        self._block_offsets = boff
-        # which batch of this epoch each part belongs to, and the batch row of its first node
-        self._part_tables = None
+        # first row of every used part inside its batch
+        first = np.cumsum(sizes) - sizes - np.repeat(off[:-1], bs)
+        # blocks: a part of sz rows gives ceil(sz / 128) block ends first + min(128 (j + 1), sz); every batch's list starts with 0
+        nblk = (sizes + 127) // 128
+        part_rep = np.repeat(np.arange(len(used)), nblk)
+        j_in = np.arange(int(nblk.sum())) - np.repeat(np.cumsum(nblk) - nblk, nblk)
+        ends = first[part_rep] + np.minimum(128 * (j_in + 1), sizes[part_rep])
+        per_batch_blocks = nblk.reshape(mx, bs).sum(1) if mx else nblk[:0]
+        boff = np.zeros(mx + 1, np.int64)
+        np.cumsum(per_batch_blocks + 1, out=boff[1:])                   # + the leading 0 of every batch
+        blocks = np.zeros(int(boff[-1]), np.int32)
+        dst = np.arange(ends.shape[0]) + np.repeat(np.arange(mx), per_batch_blocks) + 1
+        blocks[dst] = ends
+        tab = None
         if self._node_part is not None:
-            n_parts = len(self.par_li) + 1
-            tab = np.full((n_parts, 2), -1, np.int32)
-            row = 0
-            for s_, p in enumerate(used):
-                j = s_ // self.batch_size
-                if s_ % self.batch_size == 0:
-                    row = 0
-                if len(p):
-                    pid = int(self._part_of_host[p[0]])
-                    tab[pid, 0], tab[pid, 1] = j, row
-                row += len(p)
-            self._part_tables = torch.from_numpy(tab).to(self.g.device)
+            tab = np.full((len(self.par_li) + 1, 2), -1, np.int32)
+            nz = np.flatnonzero(sizes > 0)
+            firsts = np.fromiter((used[i][0] for i in nz), np.int64, len(nz))
+            pid = self._part_of_host[firsts]
+            tab[pid, 0] = (nz // bs).astype(np.int32)
+            tab[pid, 1] = first[nz].astype(np.int32)
+        return ids, off, blocks, boff, tab
+
+    def _upload_epoch(self):
+        """ONE asynchronous host-to-device copy per epoch from a pinned staging buffer into the epoch's own set of
+        device buffers (two sets, alternating: the previous epoch's last batches may still be executing).  No
+        synchronisation: the pageable-memory copy this replaces waited for the whole queue, and the GPU then sat idle
+        through ~3 ms of Python loops -- 30-65 us per step of an epoch of 75 (the gap between a step's kernel time and
+        ms_per_step in the round-3 profiles)."""
+        ids, off, blocks, boff, tab = self._host_epoch_tables()
+        dev = self.g.device
+        n_ids, n_blk = ids.shape[0], blocks.shape[0]
+        n_tab = 0 if tab is None else tab.size
+        total = n_ids + n_blk + n_tab
+        par = getattr(self, '_epoch_parity', 0) ^ 1
+        self._epoch_parity = par
+        bufs = getattr(self, '_epoch_bufs', None)
+        if bufs is None:
+            bufs = self._epoch_bufs = [None, None]
+        if bufs[par] is None or bufs[par][0].numel() < total:
+            cap = total + total // 8 + 64
+            bufs[par] = (torch.empty(cap, dtype=torch.int32).pin_memory(),
+                         torch.empty(cap, dtype=torch.int32, device=dev))
+        host, devbuf = bufs[par]
+        hv = host.numpy()
+        hv[:n_ids] = ids
+        hv[n_ids:n_ids + n_blk] = blocks
+        if n_tab:
+            hv[n_ids + n_blk:total] = tab.ravel()
+        devbuf[:total].copy_(host[:total], non_blocking=True)
+        self._epoch_ids = devbuf[:n_ids]
+        self._offsets = off
+        self._epoch_blocks = devbuf[n_ids:n_ids + n_blk]
+        self._block_offsets = boff
+        self._part_tables = devbuf[n_ids + n_blk:total].view(-1, 2) if n_tab else None
 
     def __iter__(self):
         self.n = 0
-        if self.engine is not None:
-            self.engine.check_extract()          # (last epoch's one-launch extractions all met their barrier)
         self._upload_epoch()
         return self
 
@@ -276,7 +302,11 @@ class EngineClusterIter(ClusterIter):
                 batch.parts = (self._node_part, self._part_tables, self.n)
             self.n += 1
             return batch
-        if self.engine is not None:          # every batch of the epoch that just ended was extracted completely
-            self.engine.check_extract()
+        if self.engine is not None:
+            # every batch of an epoch must have been extracted completely (gist_extract_parts_batch's error word).  The
+            # word of the epoch that just ended is copied to the host asynchronously and inspected at the NEXT epoch end
+            # (no queue drain per epoch); engine.check_extract() -- a synchronising read -- closes a run: the trainers
+            # and bench.py call it before they report anything
+            self.engine.check_extract_deferred()
         random.shuffle(self.par_li)
         raise StopIteration

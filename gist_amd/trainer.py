@@ -325,6 +325,7 @@ class ClusterGCNTrainer(object):
         loss = self.train_epoch()
         torch.cuda.synchronize(self.device)
         self.total_time += time.time() - t0
+        self.engine.check_extract()      # (outside the timed interval; the device is idle here anyway)
         return loss
 
     def evaluate(self, mask_name):
