@@ -258,7 +258,10 @@ class EngineClusterIter(ClusterIter):
         dev = self.g.device
         n_ids, n_blk = ids.shape[0], blocks.shape[0]
         n_tab = 0 if tab is None else tab.size
-        total = n_ids + n_blk + n_tab
+        # (every piece starts on a 16-byte boundary: the kernels read the part table as 8-byte pairs)
+        o_blk = (n_ids + 3) // 4 * 4
+        o_tab = (o_blk + n_blk + 3) // 4 * 4
+        total = o_tab + n_tab
         par = getattr(self, '_epoch_parity', 0) ^ 1
         self._epoch_parity = par
         bufs = getattr(self, '_epoch_bufs', None)
@@ -271,15 +274,15 @@ class EngineClusterIter(ClusterIter):
         host, devbuf = bufs[par]
         hv = host.numpy()
         hv[:n_ids] = ids
-        hv[n_ids:n_ids + n_blk] = blocks
+        hv[o_blk:o_blk + n_blk] = blocks
         if n_tab:
-            hv[n_ids + n_blk:total] = tab.ravel()
+            hv[o_tab:total] = tab.ravel()
         devbuf[:total].copy_(host[:total], non_blocking=True)
         self._epoch_ids = devbuf[:n_ids]
         self._offsets = off
-        self._epoch_blocks = devbuf[n_ids:n_ids + n_blk]
+        self._epoch_blocks = devbuf[o_blk:o_blk + n_blk]
         self._block_offsets = boff
-        self._part_tables = devbuf[n_ids + n_blk:total].view(-1, 2) if n_tab else None
+        self._part_tables = devbuf[o_tab:total].view(-1, 2) if n_tab else None
 
     def __iter__(self):
         self.n = 0

@@ -11,7 +11,7 @@ def last_json(path, key='{"metric"'):
 
 
 def short(name):
-    return re.sub(r'^void ', '', name).split('(')[0]
+    return re.sub(r'^void ', '', name.replace('(anonymous namespace)::', '')).split('(')[0]
 
 
 def clean(path):
@@ -64,7 +64,7 @@ for sub, what in (('h1024', '--n-hidden 1024'), ('h512', '--n-hidden 512'), ('cf
     if os.path.exists(seq):
         txt += ['', 'The step launch by launch (scripts/step_seq.py on the same trace: median duration of every launch in stream '
                 'order; blank names = kernels in an anonymous namespace: the fused class layer `class_layer_kernel` [grid n/16 x 256] '
-                'and its `class_dw_kernel` [grid K/64 x n/128]):', '', '```'] + open(seq).read().rstrip().split('\n') + ['```']
+                'and its `class_dw_kernel` [grid K/64 x n/128]; `gemm_f32_dual_kernel` = dZ and dW of a hidden layer in one launch):', '', '```'] + open(seq).read().rstrip().split('\n') + ['```']
     open(os.path.join(P, '%s_step_kernels_%s.md' % (TAG, sub)), 'w').write('\n'.join(txt) + '\n')
 
 
@@ -159,10 +159,12 @@ md = ['# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
       'Per kernel of the step, medians over its dispatches.  wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave-cycles parked at s_waitcnt / '
       's_barrier: memory latency and barriers), issue-stall share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, active share = SQ_ACTIVE_INST_ANY / '
       'SQ_WAVE_CYCLES; MFMA occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); fabric read = 2 x FETCH_SIZE (gfx950 '
-      'correction).  The targets of the round-3 review for these steps (0.25 / 0.30 ms) were missed: every kernel here is a chain of three to '
-      'five DEPENDENT memory round trips with 1-6 us of arithmetic -- wave-cycles are 60-90 % parked waiting, the matrix pipe is 2-25 % busy, '
-      'and a launch costs 5-10 us whatever it computes (the fp32 block-dense aggregation, 1 us of MFMA time at D = 256, takes 8.6-11.6 us: '
-      'profiles/r04_spmm_dense32.txt).', '']
+      'correction).  The targets of the round-3 review for these steps (0.25 / 0.30 ms) were missed, and these counters say where the time of '
+      'each launch goes: the kernels that move data (extraction, LayerNorm, Adam, the LDS-gather aggregation) have 46-86 % of their '
+      'wave-cycles parked at s_waitcnt / s_barrier -- chains of dependent memory round trips, not bandwidth (fabric reads of 4-35 MB in '
+      '7-20 us = 0.6-2 TB/s); the projections are issue-stalled on the matrix pipe (57-69 %) at an occupancy of 0.32-0.59 of the fp32 MFMA '
+      'peak -- 128-1024 tiles of 64 x 64 are one to four rounds of one 32 x 32 MFMA tile per SIMD, and a launch has its ramp and tail whatever it '
+      'computes.', '']
 for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2')):
     f = os.path.join(F, 'pmc_sq_' + sub, 't_counter_collection.csv')
     if not os.path.exists(f):
