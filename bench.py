@@ -92,7 +92,7 @@ def parse():
                     help='wall-time bound (s) of the all-cores oracle sample; the 1-thread sample gets half')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='skip HIP-event bracketing of SpMM/GEMM launches')
-    ap.add_argument('--timing-every', type=int, default=8,
+    ap.add_argument('--timing-every', type=int, default=16,
                     help='bracket the SpMM/GEMM launches of every N-th timed step with HIP events '
                          '(an event pair per launch serialises kernel boundaries: ~80 us/step '
                          'when every step is instrumented, i.e. it would depress `value`)')
