@@ -39,8 +39,6 @@
 // ~8 us = conversion 2.5 (VALU-bound: 16 waves x ~250 instructions) + MFMA 1 + barriers 2 + result
 // tile 0.5 + stores 2 (the chip's 256 workgroups store in step: 9 TB/s bursts).  One workgroup per CU
 // (136 KiB of LDS) cannot overlap those phases; the HBM floor of the call is 15 us.
-#include <type_traits>
-
 #include "common.h"
 
 namespace gist {
@@ -105,14 +103,13 @@ __device__ __forceinline__ void mf_barrier() {
 
 // v += sum over the listed source rows (ids in lanes 0 .. cnt-1 of `ids`) of scale . x[id][gc .. gc+3],
 // in list order, for the lanes with `mine`; 4 row reads in flight
-template <int NF = 4>
 __device__ __forceinline__ void mf_gather(const float *x, int64_t ldx, const float *src_scale, int gc,
                                           bool mine, int ids, int cnt, float4 &v) {
-    for (int j0 = 0; j0 < cnt; j0 += NF) {
-        float4 rv[NF];
-        float rs[NF];
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+        float4 rv[4];
+        float rs[4];
 #pragma unroll
-        for (int t = 0; t < NF; ++t) {
+        for (int t = 0; t < 4; ++t) {
             const bool on = j0 + t < cnt;                          // wave-uniform
             const int g = __builtin_amdgcn_readlane(ids, (j0 + t) & 63);
             rs[t] = 0.f;
@@ -123,7 +120,7 @@ __device__ __forceinline__ void mf_gather(const float *x, int64_t ldx, const flo
             }
         }
 #pragma unroll
-        for (int t = 0; t < NF; ++t) {
+        for (int t = 0; t < 4; ++t) {
             v.x = fmaf(rs[t], rv[t].x, v.x); v.y = fmaf(rs[t], rv[t].y, v.y);
             v.z = fmaf(rs[t], rv[t].z, v.z); v.w = fmaf(rs[t], rv[t].w, v.w);
         }
@@ -131,12 +128,11 @@ __device__ __forceinline__ void mf_gather(const float *x, int64_t ldx, const flo
 }
 
 // every neighbour of one row, CSR order
-template <int NF = 4>
 __device__ __forceinline__ void mf_gather_row(const MfArgs &a, int e0, int e1, int lane, int gc, bool mine,
                                               float4 &v) {
     for (int base = e0; base < e1; base += 64) {
         const int ids = base + lane < e1 ? a.col[base + lane] : 0;
-        mf_gather<NF>(a.x, a.ldx, a.src_scale, gc, mine, ids, min(64, e1 - base), v);
+        mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, min(64, e1 - base), v);
     }
 }
 
@@ -548,450 +544,6 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     }
 }
 
-// ---- prepared blocks: producer and consumer waves (round 4) ---------------------------------------------------
-// What holds the kernel above at 28-31 us per D = 4096 call (the bytes take 12 at the rate the memory system
-// reaches) is not any one phase but their ORDER inside a wave: a wave's vector-memory operations complete in issue
-// order, so the first outside-neighbour gather (or old-y read) of a tile's epilogue waits for the next tile's
-// prefetch, the next conversion waits for the epilogue, four barriers a tile stop all 16 waves, and with 128-column
-// tiles a workgroup gets 3 or 2 of them (2.5 on average).  Here the two streams are separated:
-//   waves 8-15 PRODUCE: they own the tile loads -- two tiles in flight, nothing else in their memory queue -- and
-//              turn tile u + 1 into the bf16x3 X^T image while
-//   waves 0-7  CONSUME tile u: counts . X^T with the counts in REGISTERS (a wave multiplies the same two 16-row tiles
-//              of a block in every column tile: 8 fragments loaded once per block from the prepared image, so the
-//              image is not in LDS at all), result tile -> LDS -> rows: outside neighbours (four rows at a time, one
-//              per 16-lane group, a row's list walked by its own lane group: one memory round trip per list
-//              POSITION instead of one per row), x out_scale (+ y), store.
-// Two images (2 x 48 KiB, 64-column tiles, XOR swizzle instead of padding) and two barriers per tile: A | B | A ...
-//   phase A(s): consumers multiply image[(s - 1) & 1] and write the result tile; producers convert tile s into image[s & 1]
-//   phase B(s): consumers finish the rows of tile s - 1; producers issue the loads of tile s + 2
-// A workgroup per CU walks a CONTIGUOUS range of (block, tile) units -- all units / all workgroups, e.g. 1280 / 256 = 5
-// each at D = 4096 -- and re-reads a block's counts when its range crosses into the next block.
-//   X^T piece: [k chunk 16][column & 3][(column >> 2) ^ 4 (column & 3)][8 k] bf16 -- a thread stages four adjacent
-//   columns of four rows; the 16 lanes of a row group write 16 different 16-byte slots of one [column & 3] plane
-//   (8 bytes each, the neighbouring row group the other 8), the 16 lanes of a B fragment read slots whose index
-//   mod 16 is (tile ^ (n & 3), n >> 2): all different -- conflict-free both ways.
-constexpr int M2_CT = 64;
-constexpr int M2_THREADS = 1024;
-constexpr int M2_CW = 8;                                         // consumer waves (0..7); producers 8..15
-constexpr int M2_CHUNK_SLOTS = 64;
-constexpr int M2_PIECE = 16 * M2_CHUNK_SLOTS * 16;               // 16 KiB
-constexpr int M2_IMG = 3 * M2_PIECE;                             // one X^T image
-constexpr int M2_YT_PITCH = 68;                                  // floats
-constexpr int M2_YT_OFF = 2 * M2_IMG;                            // fp32 result tile [128][68]
-constexpr int M2_RP_OFF = M2_YT_OFF + MF_ROWS * M2_YT_PITCH * 4; // int rowptr[132]
-constexpr int M2_REMC_OFF = M2_RP_OFF + 132 * 4;                 // int rem_cnt[128]
-constexpr int M2_REM_OFF = M2_REMC_OFF + MF_ROWS * 4;            // int rem_col[128][8]
-constexpr int M2_SC_OFF = M2_REM_OFF + MF_ROWS * MF_REM * 4;     // float out_scale[128]
-constexpr int M2_LDS_BYTES = M2_SC_OFF + MF_ROWS * 4;
-static_assert(M2_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
-
-// the rows of unit-block `rbk`: output rows [r0, r0 + nrow), staged rows nloc, source rows [xs0, xs0 + nx)
-struct M2Block { int r0, nrow, nloc, xs0, nx; };
-// (the descriptors are read through the constant address space: uniform index -> s_load, counted in lgkmcnt; as
-// global loads they are vector-memory operations, and waiting for one means waiting for every tile load before it)
-typedef const __attribute__((address_space(4))) int32_t *m2_cptr;
-__device__ __forceinline__ m2_cptr m2_const(const int32_t *p) { return (m2_cptr)(uintptr_t)p; }
-__device__ __forceinline__ M2Block m2_block(const MfArgs &a, int rbk) {
-    M2Block k;
-    int r1, xs0 = -1, xs1 = 0;
-    if (a.units) {
-        m2_cptr un = m2_const(a.units);
-        k.r0 = un[4 * rbk]; r1 = un[4 * rbk + 1]; xs0 = un[4 * rbk + 2]; xs1 = un[4 * rbk + 3];
-    } else if (a.row_blocks) {
-        m2_cptr rb = m2_const(a.row_blocks);
-        k.r0 = rb[rbk]; r1 = rb[rbk + 1];
-    } else { k.r0 = rbk * MF_ROWS; r1 = k.r0 + MF_ROWS; }
-    r1 = min(r1, a.n_rows);
-    k.nrow = max(a.units ? min(r1 - k.r0, MF_ROWS) : r1 - k.r0, 0);
-    k.nloc = min(k.nrow, MF_ROWS);
-    if (xs0 < 0) { xs0 = k.r0; xs1 = k.r0 + k.nloc; }
-    k.xs0 = xs0;
-    k.nx = max(min(xs1 - xs0, MF_ROWS), 0);
-    if (k.nx == 0) k.xs0 = 0;              // (an empty block: loads clamp to row 0 of x, everything is masked)
-    return k;
-}
-
-#ifdef MF_PROBE      // (scripts/spmm_pc_phases.py) workgroup 0: consumer wave 0 -> slots 2 + 4 s + i, producer wave 8 -> 32 + 4 s + i
-#define M2_STAMP(base, s_, i) do { if (blockIdx.x == 0 && (threadIdx.x & 511) == 0 && (s_) < 7) \
-        g_mf_probe[(base) + 4 * (s_) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define M2_STAMP(base, s_, i) do { } while (0)
-#endif
-
-// The rows of a finished tile: eight per wave (ALL 16 waves: in phase B the producers have nothing else to do), two
-// passes of four rows, one row per 16-lane group.  m2_rows_issue sends every load of both passes -- old y and the
-// first two outside neighbours of each row (a 16-lane group reads ITS row's list; a row with fewer re-reads a cached
-// row) -- m2_rows_finish consumes them: one memory round trip per tile instead of one per row with an outside
-// neighbour.  A producer issues these BEFORE its tile loads and finishes AFTER: operations complete in issue order,
-// so it waits for the rows' loads with the tile loads still in flight.
-struct M2Rows {
-    int cnt[2];
-    float4 g0[2], g1[2], yo[2];
-    float s0[2], s1[2];
-};
-__device__ __forceinline__ void m2_rows_issue(const MfArgs &a, const M2Block &k, const unsigned char *mf_smem, int wave,
-                                              int rsel, int gcc, bool live, M2Rows &R) {
-    const int32_t *rem_cnt = reinterpret_cast<const int32_t *>(mf_smem + M2_REMC_OFF);
-    const int32_t *rem_col = reinterpret_cast<const int32_t *>(mf_smem + M2_REM_OFF);
-    const bool has_ss = a.src_scale != nullptr;
-    const float *ssp = has_ss ? a.src_scale : a.x;      // (no branch around a load)
-    const int ldx32 = (int)a.ldx, ldy32 = (int)a.ldy;
-    const float *yblk = a.y + (int64_t)k.r0 * a.ldy;
-#pragma unroll
-    for (int pq = 0; pq < 2; ++pq) {
-        const int r = 8 * wave + 4 * pq + rsel;
-        const int cnt = (live && r < k.nloc) ? rem_cnt[r] : 0;      // (the same in the 16 lanes of a group)
-        R.cnt[pq] = cnt;
-        const int id0 = cnt > 0 ? rem_col[r * MF_REM] : k.xs0;
-        const int id1 = cnt > 1 ? rem_col[r * MF_REM + 1] : k.xs0;
-        const float w0 = ssp[has_ss ? id0 : 0], w1 = ssp[has_ss ? id1 : 0];
-        R.g0[pq] = *reinterpret_cast<const float4 *>(a.x + (int64_t)id0 * ldx32 + gcc);
-        R.g1[pq] = *reinterpret_cast<const float4 *>(a.x + (int64_t)id1 * ldx32 + gcc);
-        R.s0[pq] = w0;                                   // (selected against 1 in m2_rows_finish: a select here would
-        R.s1[pq] = w1;                                   // wait for the load)
-        R.yo[pq] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (a.accumulate) {                                  // (uniform branch; rows clamped into the block)
-#pragma unroll
-        for (int pq = 0; pq < 2; ++pq)
-            R.yo[pq] = *reinterpret_cast<const float4 *>(
-                yblk + (uint32_t)(min(8 * wave + 4 * pq + rsel, max(k.nloc - 1, 0)) * ldy32 + gcc));
-    }
-}
-template <int DROP>
-__device__ __forceinline__ void m2_rows_finish(const MfArgs &a, const M2Block &k, const unsigned char *mf_smem, int wave,
-                                               int lane, int gc, bool colok, bool live, const M2Rows &R) {
-    const float *yt = reinterpret_cast<const float *>(mf_smem + M2_YT_OFF);
-    const int32_t *rp = reinterpret_cast<const int32_t *>(mf_smem + M2_RP_OFF);
-    const int32_t *rem_col = reinterpret_cast<const int32_t *>(mf_smem + M2_REM_OFF);
-    const float *sc = reinterpret_cast<const float *>(mf_smem + M2_SC_OFF);
-    const int rsel = lane >> 4, cq = lane & 15;
-    const int gcc = colok ? gc : 0;
-    const bool has_ss = a.src_scale != nullptr;
-    const float *ssp = has_ss ? a.src_scale : a.x;
-    const int ldx32 = (int)a.ldx, ldy32 = (int)a.ldy;
-    float *yblk = a.y + (int64_t)k.r0 * a.ldy;
-    const uint64_t dyb = a.dr.y_base + (uint64_t)k.r0 * (uint64_t)a.dr.ld;
-    const int dld = (int)a.dr.ld;
-#pragma unroll
-    for (int pq = 0; pq < 2; ++pq) {
-        int r = 8 * wave + 4 * pq + rsel;
-        asm volatile("" : "+v"(r));                      // (opaque: keeps the row products out of loop-invariant registers)
-        const bool rok = live && r < k.nloc;
-        float4 v = *reinterpret_cast<const float4 *>(yt + r * M2_YT_PITCH + 4 * cq);
-        const float s = sc[r];
-        const int cnt = R.cnt[pq];
-        const float w0 = has_ss ? R.s0[pq] : 1.f, w1 = has_ss ? R.s1[pq] : 1.f;
-        if (cnt > 0) {                                   // (per lane: a row without the neighbour keeps its value bit for bit)
-            v.x = fmaf(w0, R.g0[pq].x, v.x); v.y = fmaf(w0, R.g0[pq].y, v.y);
-            v.z = fmaf(w0, R.g0[pq].z, v.z); v.w = fmaf(w0, R.g0[pq].w, v.w);
-        }
-        if (cnt > 1) {
-            v.x = fmaf(w1, R.g1[pq].x, v.x); v.y = fmaf(w1, R.g1[pq].y, v.y);
-            v.z = fmaf(w1, R.g1[pq].z, v.z); v.w = fmaf(w1, R.g1[pq].w, v.w);
-        }
-        // longer lists (rare): positions 2 .. 7, the four rows of the pass together
-        int maxc = cnt;
-        maxc = max(maxc, __shfl_xor(maxc, 16));
-        maxc = max(maxc, __shfl_xor(maxc, 32));
-        maxc = __builtin_amdgcn_readfirstlane(maxc);
-        for (int j = 2; j < maxc; ++j) {
-            const bool on = j < cnt;
-            const int g = on ? rem_col[r * MF_REM + (j & (MF_REM - 1))] : k.xs0;
-            const float w = ssp[has_ss ? g : 0];
-            const float4 rv = *reinterpret_cast<const float4 *>(a.x + (int64_t)g * ldx32 + gcc);
-            const float rs = has_ss ? w : 1.f;
-            if (on) {
-                v.x = fmaf(rs, rv.x, v.x); v.y = fmaf(rs, rv.y, v.y);
-                v.z = fmaf(rs, rv.z, v.z); v.w = fmaf(rs, rv.w, v.w);
-            }
-        }
-        // rows that left the dense product (more than 8 outside neighbours, a count > 256): gathered in full
-        const unsigned long long slow = __ballot(cnt < 0);
-        if (slow != 0ULL) {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                if (((slow >> (16 * h)) & 1ULL) == 0ULL) continue;         // wave-uniform
-                const int rh = 8 * wave + 4 * pq + h;
-                const bool mine = colok && rsel == h;
-                if (mine) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                mf_gather_row<2>(a, rp[rh], rp[rh + 1], lane, gc, mine, v);
-            }
-        }
-        if (colok && rok) {
-            float4 o = make_float4(fmaf(s, v.x, R.yo[pq].x), fmaf(s, v.y, R.yo[pq].y), fmaf(s, v.z, R.yo[pq].z),
-                                   fmaf(s, v.w, R.yo[pq].w));
-            if constexpr (DROP == 1) drop_f4(o, dyb + (uint32_t)(r * dld + gc), a.dr);
-            *reinterpret_cast<float4 *>(yblk + (uint32_t)(r * ldy32 + gc)) = o;
-        }
-    }
-    // rows of an oversized block beyond the 128 staged ones: gathered in full, four rows per pass
-    if (live) {
-        for (int rb = MF_ROWS + 4 * wave; rb < k.nrow; rb += 4 * (M2_THREADS / 64)) {
-            float4 vo = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                if (rb + h >= k.nrow) continue;                            // wave-uniform
-                mf_gather_row<2>(a, a.rowptr[k.r0 + rb + h], a.rowptr[k.r0 + rb + h + 1], lane, gc, colok && rsel == h, vo);
-            }
-            const int r = rb + rsel;
-            if (colok && r < k.nrow) {
-                float *yp = a.y + (int64_t)(k.r0 + r) * a.ldy + gc;
-                const uint64_t yi = a.dr.y_base + (uint64_t)(k.r0 + r) * (uint64_t)a.dr.ld + (uint64_t)gc;
-                float4 yo = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.accumulate) yo = *reinterpret_cast<const float4 *>(yp);
-                const float s = a.out_scale ? a.out_scale[k.r0 + r] : 1.f;
-                float4 o = make_float4(fmaf(s, vo.x, yo.x), fmaf(s, vo.y, yo.y), fmaf(s, vo.z, yo.z), fmaf(s, vo.w, yo.w));
-                if constexpr (DROP == 1) drop_f4(o, yi, a.dr);
-                *reinterpret_cast<float4 *>(yp) = o;
-            }
-        }
-    }
-}
-
-template <int DROP>
-__global__ __launch_bounds__(M2_THREADS) void spmm_csr_mfma_pc_kernel(MfArgs a, int n_units) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
-    MF_STAMP(0);
-    // this workgroup's units [u0, u1) of the (block, column tile) sequence
-    const int u0 = (int)((int64_t)blockIdx.x * n_units / gridDim.x);
-    const int u1 = (int)((int64_t)(blockIdx.x + 1) * n_units / gridDim.x);
-    const int n_mine = u1 - u0;
-    const int n_slots = (n_mine + 2) & ~1;              // units + 1, rounded up to even; the same in every wave
-    // (block, tile) of a unit advance by increments: an integer division, even of uniform values, is vector code, and a
-    // block's rows would then be fetched by VECTOR loads -- waited for with vmcnt(0), i.e. with the prefetch
-    const int b_first = __builtin_amdgcn_readfirstlane(u0 / a.n_col_tiles);
-    const int t_first = __builtin_amdgcn_readfirstlane(u0 % a.n_col_tiles);
-    struct Cur { int b, t, j; };                        // unit u0 + j = (block b, tile t); stays on the last unit
-    auto advance = [&](Cur &c) {
-        if (c.j + 1 < n_mine) {
-            ++c.j;
-            if (++c.t == a.n_col_tiles) { c.t = 0; ++c.b; }
-        }
-    };
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rsel = lane >> 4, cq = lane & 15;
-
-    if (wave >= M2_CW) {
-        // =========================== producers ===========================
-        const int pw = wave - M2_CW;
-        const int srow = 16 * pw + 4 * rsel;            // rows srow .. srow + 3, columns 4 cq .. 4 cq + 3 of a tile
-        float4 xv[2][4];
-        float ss[2][4];
-        // (no branch around a vector load: a branch's join costs a conservative s_waitcnt vmcnt(0), i.e. the prefetch)
-        const bool has_ss = a.src_scale != nullptr;
-        const float *ssp = has_ss ? a.src_scale : a.x;
-        Cur lc{b_first, t_first, 0}, cc{b_first, t_first, 0}, rc{b_first, t_first, 0};      // load, conversion, row cursors
-        // (a block's descriptor is fetched when a cursor ENTERS the block: a scalar load and its wait in every slot was
-        // most of what the producers' phase B took)
-        M2Block lk = m2_block(a, b_first), ck = lk, rk = lk;
-        int lkb = b_first, ckb = b_first, rkb = b_first;
-        auto load_unit = [&](auto set_c) {              // the load cursor's unit -> register set; advance
-            constexpr int q = decltype(set_c)::value;
-            if (lc.b != lkb) { lk = m2_block(a, lc.b); lkb = lc.b; }
-            const M2Block k = lk;
-            const int t = lc.t;
-            advance(lc);
-            const bool cok = t * M2_CT + 4 * cq < a.d;
-            const float *px = a.x + (int64_t)k.xs0 * a.ldx + (cok ? t * M2_CT + 4 * cq : 0);
-            const int ldx32 = (int)a.ldx;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = min(srow + i, max(k.nx - 1, 0));
-                xv[q][i] = *reinterpret_cast<const float4 *>(px + (uint32_t)(row * ldx32));
-                ss[q][i] = ssp[has_ss ? k.xs0 + row : 0];      // (selected against 1 at the conversion: a select here waits)
-            }
-        };
-        auto convert = [&](auto set_c) {                // the set's tile (the conversion cursor's unit) -> image[set]
-            constexpr int q_ = decltype(set_c)::value;
-            unsigned char *xt = mf_smem + q_ * M2_IMG;
-            if (cc.b != ckb) { ck = m2_block(a, cc.b); ckb = cc.b; }
-            const M2Block k = ck;
-            const bool cok = cc.t * M2_CT + 4 * cq < a.d;
-            advance(cc);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                uint32_t w[3][2];
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const float4 va = xv[q_][2 * pr], vb = xv[q_][2 * pr + 1];
-                    const float ea = jj == 0 ? va.x : jj == 1 ? va.y : jj == 2 ? va.z : va.w;
-                    const float eb = jj == 0 ? vb.x : jj == 1 ? vb.y : jj == 2 ? vb.z : vb.w;
-                    const float sa = has_ss ? ss[q_][2 * pr] : 1.f, sb = has_ss ? ss[q_][2 * pr + 1] : 1.f;
-                    float x0 = (cok && srow + 2 * pr < k.nx) ? ea * sa : 0.f;         // (clamped loads: select here)
-                    float x1 = (cok && srow + 2 * pr + 1 < k.nx) ? eb * sb : 0.f;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const mf_bf16x2 pk = __builtin_convertvector(mf_f32x2{x0, x1}, mf_bf16x2);
-                        const uint32_t u = __builtin_bit_cast(uint32_t, pk);
-                        w[q][pr] = u;
-                        x0 -= __builtin_bit_cast(float, u << 16);
-                        x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
-                    }
-                }
-                unsigned char *dst = xt + ((2 * pw + (rsel >> 1)) * M2_CHUNK_SLOTS + jj * 16 + (cq ^ (4 * jj))) * 16 +
-                                     (rsel & 1) * 8;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    *reinterpret_cast<uint2 *>(dst + q * M2_PIECE) = make_uint2(w[q][0], w[q][1]);
-            }
-        };
-        using C0 = std::integral_constant<int, 0>;
-        using C1 = std::integral_constant<int, 1>;
-        load_unit(C0{});
-        load_unit(C1{});
-        int lists_of = b_first;                         // the block whose lists are in LDS (as the consumers keep it)
-        auto slot = [&](auto set_c, int sidx) {
-            const int c = sidx - 1;                      // rows of tile c = s - 1 are finished in this slot
-            const bool live = c >= 0 && c < n_mine;
-            if (c >= 1) advance(rc);
-            if (rc.b != rkb) { rk = m2_block(a, rc.b); rkb = rc.b; }
-            const M2Block k = rk;
-            const int gc = rc.t * M2_CT + 4 * cq;
-            const bool colok = gc < a.d;
-            // the rows' loads go out in phase A, under the conversion, unless the consumers are only now writing the
-            // block's lists (first tile of a block: phase B then)
-            const bool early = live && rc.b == lists_of;
-            if (live) lists_of = rc.b;
-            M2Rows R;
-            mf_barrier();                                // ---- phase A(s): tile s -> image[s & 1]
-            M2_STAMP(32, sidx, 0);
-            if (early) m2_rows_issue(a, k, mf_smem, wave, rsel, colok ? gc : 0, live, R);
-            convert(set_c);
-            M2_STAMP(32, sidx, 1);
-            mf_barrier();                                // ---- phase B(s): rows of tile s - 1, then the loads of tile s + 2
-            M2_STAMP(32, sidx, 2);
-            if (!early) m2_rows_issue(a, k, mf_smem, wave, rsel, colok ? gc : 0, live, R);
-            load_unit(set_c);
-            m2_rows_finish<DROP>(a, k, mf_smem, wave, lane, gc, colok, live, R);
-            M2_STAMP(32, sidx, 3);
-        };
-        for (int sidx = 0; sidx < n_slots; sidx += 2) {
-            slot(C0{}, sidx);
-            slot(C1{}, sidx + 1);
-        }
-        return;
-    }
-
-    // =========================== consumers ===========================
-    float *yt = reinterpret_cast<float *>(mf_smem + M2_YT_OFF);
-    int32_t *rp = reinterpret_cast<int32_t *>(mf_smem + M2_RP_OFF);
-    float *sc = reinterpret_cast<float *>(mf_smem + M2_SC_OFF);
-    const int mt0 = (wave >> 1) * 2, nt0 = (wave & 1) * 2;      // output row tiles mt0, mt0 + 1; column tiles nt0, nt0 + 1
-    mf_bf16x8 av[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) av[mi][ks][e] = (__bf16)0.f;
-    int cur_blk = -1;
-    M2Block k{};
-    // a block's counts (this wave's 32 rows, all 128 k) -> registers; outside neighbours, row pointers, scales -> LDS
-    auto enter_block = [&](int rbk) {
-        cur_blk = rbk;
-        k = m2_block(a, rbk);
-        const unsigned char *src = a.prep + (int64_t)rbk * MF_PREP_STRIDE;
-        int tq = tid;                                    // (opaque: the lane's offsets are not worth registers across the tile loop)
-        asm volatile("" : "+v"(tq));
-        const int rr_ = tq & 15, kg_ = (tq >> 4) & 3;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                av[mi][ks] = *reinterpret_cast<const mf_bf16x8 *>(src + ((ks * 4 + kg_) * MF_ROWS + (mt0 + mi) * 16 + rr_) * 16);
-        if (tq < (MF_ROWS * (1 + MF_REM)) / 4)
-            reinterpret_cast<int4 *>(mf_smem + M2_REMC_OFF)[tq] = reinterpret_cast<const int4 *>(src + 16 * MF_ROWS * 16)[tq];
-        if (tq <= k.nloc) rp[tq] = a.units == nullptr ? a.rowptr[k.r0 + tq] : 0;
-        if (tq < MF_ROWS) sc[tq] = (tq < k.nloc && a.out_scale) ? a.out_scale[k.r0 + tq] : 1.f;
-        // the counts have landed before this path joins the other: otherwise the compiler guards every MFMA of EVERY tile
-        // with a wait that, on the other path, is a wait for the rows' loads issued just before
-        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
-    };
-    enter_block(b_first);                                // (under the producers' first loads; visible after slot 0's barriers)
-    Cur uc{b_first, t_first, 0};                         // the unit consumed in slot s is u0 + s - 1
-    auto slot = [&](int sidx) {
-        const int c = sidx - 1;
-        const bool live = c >= 0 && c < n_mine;          // (uniform)
-        if (c >= 1) advance(uc);
-        const int rbk = uc.b, ct = uc.t;
-        const int gc = ct * M2_CT + 4 * cq;
-        const bool colok = gc < a.d;
-        const bool fresh = live && rbk != cur_blk;       // the block's counts and lists are loaded in this slot:
-        const bool early = live && !fresh;               // (lists last read in phase B(s - 1), next read in phase B(s))
-        M2Rows R;
-        mf_barrier();                                    // ---- phase A(s)
-        M2_STAMP(2, sidx, 0);
-        if (early) m2_rows_issue(a, k, mf_smem, wave, rsel, colok ? gc : 0, live, R);      // (under the MFMAs)
-        if (fresh) enter_block(rbk);
-        if (live) {
-            const unsigned char *xt = mf_smem + (c & 1) * M2_IMG;
-            // (lane-dependent offsets are recomputed per tile from an opaque copy of the lane id: kept across the loop
-            // they were spilled, and a scratch reload waits for every load issued before it -- the rows' loads)
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int rr = ln & 15, kg = ln >> 4;
-            int bslot[2];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int n = (nt0 + ni) * 16 + rr;
-                bslot[ni] = ((n & 3) * 16 + ((n >> 2) ^ (4 * (n & 3)))) * 16;
-            }
-            const int n_ks = (k.nx + 31) >> 5;
-            const bool m_on = mt0 * 16 < k.nloc, m_two = (mt0 + 1) * 16 < k.nloc;
-            mf_f32x4 acc[2][2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
-            if (m_on) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < n_ks) {
-                        // (one column tile at a time: 12 registers of fragments instead of 24 -- the rows' loads are in
-                        // flight beside them; per accumulator the order of the products is unchanged)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            mf_bf16x8 bv[3];
-#pragma unroll
-                            for (int q = 0; q < 3; ++q)
-                                bv[q] = *reinterpret_cast<const mf_bf16x8 *>(
-                                    xt + q * M2_PIECE + (ks * 4 + kg) * (M2_CHUNK_SLOTS * 16) + bslot[ni]);
-#pragma unroll
-                            for (int q = 0; q < 3; ++q) {
-                                acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][ks], bv[q], acc[0][ni], 0, 0, 0);
-                                if (m_two)
-                                    acc[1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][ks], bv[q], acc[1][ni], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
-            // accumulators -> fp32 result tile (C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        yt[((mt0 + mi) * 16 + 4 * kg + e) * M2_YT_PITCH + (nt0 + ni) * 16 + rr] = acc[mi][ni][e];
-        }
-        M2_STAMP(2, sidx, 1);
-        mf_barrier();                                    // ---- phase B(s): this wave's eight rows of the tile
-        M2_STAMP(2, sidx, 2);
-        if (!early) m2_rows_issue(a, k, mf_smem, wave, rsel, colok ? gc : 0, live, R);
-        m2_rows_finish<DROP>(a, k, mf_smem, wave, lane, gc, colok, live, R);
-    };
-    for (int sidx = 0; sidx < n_slots; ++sidx) {
-        slot(sidx);
-        M2_STAMP(2, sidx, 3);
-    }
-}
-
 // One workgroup per block: its counts image and outside-neighbour lists -> memory, for every aggregation
 // over the same graph and blocks (gist_spmm_blocks_prepare).
 __global__ __launch_bounds__(MF_THREADS) void spmm_blocks_prepare_kernel(MfArgs a, const int32_t *rowptr2,
@@ -1023,23 +575,6 @@ static int mf_set_lds(const void *kernel, const char *name) {
         return GIST_ELAUNCH;
     }
     return GIST_OK;
-}
-
-static int m2_set_lds(const void *kernel, const char *name) {
-    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS_BYTES);
-    if (e != hipSuccess) {
-        set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-        return GIST_ELAUNCH;
-    }
-    return GIST_OK;
-}
-// workgroups of the producer / consumer kernel: one per CU, each with a contiguous range of (block, tile) units
-// (tuning hook spmm_split: the number of workgroups)
-static unsigned m2_grid(int64_t n_units) {
-    const int forced = (int)tune(GIST_TUNE_SPMM_SPLIT);
-    int64_t g = forced > 0 ? forced : 256;
-    if (g > n_units) g = n_units;
-    return (unsigned)(g < 1 ? 1 : g);
 }
 
 int64_t spmm_blocks_bytes(int64_t n_blocks) { return n_blocks > 0 ? n_blocks * (int64_t)MF_PREP_STRIDE : 0; }
@@ -1085,6 +620,15 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
     GIST_REQUIRE(mode == 0 || mode == 1, "gist_spmm_csr_drop_f32: the matrix-core kernel carries the forward mask only");
     const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, MF_ROWS);
     a.n_blocks = (int)nb;
+    a.n_col_tiles = (int)ceil_div(d, MF_CT);
+    // one workgroup per CU at a time: as many column groups per block as fill the chip once
+    int64_t groups = nb > 0 ? 256 / nb : 1;
+    if (groups < 1) groups = 1;
+    if (groups > a.n_col_tiles) groups = a.n_col_tiles;
+    a.groups = (int)groups;
+    const int64_t total = nb * groups;
+    const int64_t grid = kXcds * ceil_div(total, kXcds);
+    if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
@@ -1096,34 +640,8 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
             const int rc = mf_set_lds(k, "gist_spmm_csr_blocked_f32");
             if (rc != GIST_OK) return rc;
         }
-        const void *k2[2] = {reinterpret_cast<const void *>(&spmm_csr_mfma_pc_kernel<0>),
-                             reinterpret_cast<const void *>(&spmm_csr_mfma_pc_kernel<1>)};
-        for (const void *k : k2) {
-            const int rc = m2_set_lds(k, "gist_spmm_csr_blocked_f32");
-            if (rc != GIST_OK) return rc;
-        }
         once.done(dev);
     }
-    if (prepared && (int)tune(GIST_TUNE_SPMM_KERNEL) == 5) {      // (hook 5: the producer / consumer kernel; measured, not the default)
-        a.n_col_tiles = (int)ceil_div(d, M2_CT);
-        const int64_t n_units = nb * a.n_col_tiles;
-        if (n_units > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
-        const unsigned grid2 = m2_grid(n_units);
-        if (mode == 1)
-            hipLaunchKernelGGL((spmm_csr_mfma_pc_kernel<1>), dim3(grid2), dim3(M2_THREADS), M2_LDS_BYTES, st, a, (int)n_units);
-        else
-            hipLaunchKernelGGL((spmm_csr_mfma_pc_kernel<0>), dim3(grid2), dim3(M2_THREADS), M2_LDS_BYTES, st, a, (int)n_units);
-        return launch_status("gist_spmm_csr_blocked_f32");
-    }
-    a.n_col_tiles = (int)ceil_div(d, MF_CT);
-    // one workgroup per CU at a time: as many column groups per block as fill the chip once
-    int64_t groups = nb > 0 ? 256 / nb : 1;
-    if (groups < 1) groups = 1;
-    if (groups > a.n_col_tiles) groups = a.n_col_tiles;
-    a.groups = (int)groups;
-    const int64_t total = nb * groups;
-    const int64_t grid = kXcds * ceil_div(total, kXcds);
-    if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
 #define MF_GO(P, D)                                                                                             \
     hipLaunchKernelGGL((spmm_csr_mfma_kernel<P, D>), dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a)
     if (prepared) {
@@ -1148,21 +666,6 @@ int launch_spmm_mfma_units(const int32_t *units, int64_t n_units, const void *pr
     a.out_scale = out_scale; a.accumulate = accumulate; a.units = units;
     a.prep = static_cast<const unsigned char *>(prepared);
     a.n_blocks = (int)n_units;
-    static DeviceOnce once;
-    int dev;
-    if (once.needed(&dev)) {
-        int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true, 0>), "gist_spmm_block_units_f32");
-        if (rc == GIST_OK) rc = m2_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_pc_kernel<0>), "gist_spmm_block_units_f32");
-        if (rc != GIST_OK) return rc;
-        once.done(dev);
-    }
-    if ((int)tune(GIST_TUNE_SPMM_KERNEL) == 5) {
-        a.n_col_tiles = (int)ceil_div(d, M2_CT);
-        const int64_t n_tu = n_units * a.n_col_tiles;
-        if (n_tu > 0x7fffffffLL) { set_error("gist_spmm_block_units_f32: grid too large"); return GIST_EINVAL; }
-        hipLaunchKernelGGL((spmm_csr_mfma_pc_kernel<0>), dim3(m2_grid(n_tu)), dim3(M2_THREADS), M2_LDS_BYTES, st, a, (int)n_tu);
-        return launch_status("gist_spmm_block_units_f32");
-    }
     a.n_col_tiles = (int)ceil_div(d, MF_CT);
     int64_t groups = n_units > 0 ? 256 / n_units : 1;
     if (groups < 1) groups = 1;
@@ -1170,6 +673,13 @@ int launch_spmm_mfma_units(const int32_t *units, int64_t n_units, const void *pr
     a.groups = (int)groups;
     const int64_t grid = kXcds * ceil_div(n_units * groups, kXcds);
     if (grid > 0x7fffffffLL) { set_error("gist_spmm_block_units_f32: grid too large"); return GIST_EINVAL; }
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        const int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_csr_mfma_kernel<true, 0>), "gist_spmm_block_units_f32");
+        if (rc != GIST_OK) return rc;
+        once.done(dev);
+    }
     hipLaunchKernelGGL((spmm_csr_mfma_kernel<true, 0>), dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
     return launch_status("gist_spmm_block_units_f32");
 }
