@@ -625,6 +625,8 @@ def main():
         engine = ist_model.engine
         dims = ist_model.sub_dims
     it.bind(engine)                  # (the kept-split workspace is sized for either split mode)
+    # the timed loop only reads the loss: let a step's optimiser launch extract the next batch of the epoch as well
+    engine.prefetch = os.environ.get('GIST_BENCH_PREFETCH', '1') != '0'
     hip.gemm_mode(args.gemm_mode)
     lr = 0.01
     native = engine.plan is not None

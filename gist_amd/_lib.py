@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class GistLibraryError(RuntimeError):
@@ -118,6 +118,9 @@ SIGNATURES = {
                                         _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _f, _u64, _u64, _i64, _p,
                                         _p]),
     'gist_sage_step': (_int, [_p, _p, _i64, _u64, _f, _f, _f, _f, _f, _i64, _int, _p]),
+    'gist_sage_step_extracts_next': (_int, [_p, _i64, _int]),
+    'gist_adam_segments_extract_f32': (_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _i64, _p, _i64, _i64,
+                                              _p, _p, _p]),
 }
 
 GIST_MAX_LAYERS = 16
@@ -125,6 +128,8 @@ TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_
         'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9, 'gemm_dual': 10}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
+GIST_STEP_EXTRACT_NEXT = 4
+GIST_STEP_PREEXTRACTED = 8
 
 
 class LayerDesc(ctypes.Structure):
@@ -152,7 +157,20 @@ class StepPlan(ctypes.Structure):
                 ('fuse', _i32), ('hsrc', _p * GIST_MAX_LAYERS), ('ld_hsrc', _i64 * GIST_MAX_LAYERS),
                 ('col_partials', _p), ('fused_workspace', _p), ('fused_workspace_bytes', _i64),
                 ('node_part', _p), ('part_slot', _p),
-                ('batch_index', _i32), ('extract_scratch', _p)]
+                ('batch_index', _i32), ('extract_scratch', _p),
+                ('next_ids', _p), ('next_n', _i64), ('next_batch_index', _i32), ('next_drop_offset', _u64)]
+
+
+class ExtractPartsDesc(ctypes.Structure):
+    """struct gist_extract_parts_desc (include/gist_hip.h)."""
+    _fields_ = [('g_rowptr', _p), ('g_col', _p), ('g_t_rowptr', _p), ('g_t_col', _p),
+                ('ids', _p), ('n', _i64), ('n_max', _i64),
+                ('node_part', _p), ('part_slot', _p), ('batch', _i32),
+                ('rowptr', _p), ('col', _p), ('t_rowptr', _p), ('t_col', _p), ('col_capacity', _i64), ('norm', _p),
+                ('feat', _p), ('ld_feat', _i64), ('n_feat', _i64), ('z0', _p), ('ldz0', _i64),
+                ('labels_all', _p), ('labels', _p),
+                ('x0', _p), ('ldx0', _i64), ('p', _f), ('seed', _u64), ('offset', _u64), ('mask_ld', _i64),
+                ('scratch', _p)]
 
 
 class GradSegment(ctypes.Structure):

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "adam_body.h"
 
 namespace gist {
 
@@ -755,18 +756,6 @@ __global__ __launch_bounds__(256) void xent_grad_kernel(
     if (lane == 0) row_nll[row] = on ? -((lr[lab] - mx) - logf(se)) : 0.f;
 }
 
-// loss = inv_count * sum_i row_nll[i] by one 256-thread workgroup, fixed-order tree (deterministic);
-// shared by xent_loss_kernel and the finishing block of adam_segments_kernel
-__device__ __forceinline__ void loss_reduce_256(const float *__restrict__ row_nll, int n_rows,
-                                                float inv_count, float *__restrict__ loss, float *red) {
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n_rows; i += 256) s += row_nll[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_count;
-}
-
 __global__ __launch_bounds__(256) void xent_loss_kernel(const float *__restrict__ row_nll,
                                                         int n_rows, float inv_count,
                                                         float *__restrict__ loss) {
@@ -795,125 +784,16 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
     }
 }
 
-// Adam over the arena with DEFERRED gradient reductions (gist_adam_segments_f32): inside a listed
-// segment [begin, end) the gradient of element i is not grads[i] but the sum of n_src arrays
-// src[s * stride + (i - begin)] -- the split-K slabs of a weight-gradient projection, or the per-row-chunk
-// column sums of a bias gradient -- formed here (and written back to grads) instead of by a reduce launch
-// of its own.  A workgroup owns 1024 consecutive elements; the segments that touch its range are found
-// once per workgroup (uniform), so outside them the loop is adam_kernel's.
-//   * slab segments (few sources): summed inline in source order, four loads in flight;
-//   * chunk-sum segments (`ded`: many sources, few elements -- a bias gradient in 16-row chunks): the
-//     arena workgroups skip them and DEDICATED workgroups take 64 elements each, four threads per element
-//     over the sources q, q + 4, ... (eight loads in flight), the four partial sums added in q order
-//     (chunk_sum4: the order gist_colsum_chunks_f32 uses too) -- a thread that walked 128 chunks for each
-//     of its 4 elements set the kernel's duration (76 us at h = 512 against 6 for the plain kernel).
-// One more workgroup reduces the step's loss when row_nll != NULL.
-constexpr int kAdamMaxSegs = 2 * GIST_MAX_LAYERS;
-struct AdamSegs {
-    int n;
-    int n_src[kAdamMaxSegs];
-    int ded_first[kAdamMaxSegs];      // first dedicated workgroup of the segment (-1: inline)
-    int n_ded;                         // dedicated workgroups in total
-    int64_t begin[kAdamMaxSegs], end[kAdamMaxSegs], stride[kAdamMaxSegs];
-    const float *src[kAdamMaxSegs];
-};
-
-// sum over sources q, q + 4, q + 8, ... in ascending order (q = 0..3)
-__device__ __forceinline__ float chunk_partial4(const float *__restrict__ src, int64_t stride, int n_src, int q) {
-    float acc = 0.f;
-    int k = q;
-    for (; k + 28 < n_src; k += 32) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(k + 4 * u) * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += t[u];
-    }
-    for (; k < n_src; k += 4) acc += src[(int64_t)k * stride];
-    return acc;
-}
-
-__device__ __forceinline__ void adam_update(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
-                                            int64_t i, float gv, float beta1, float beta2, float eps, float wd,
-                                            float step_size, float inv_bc2_sqrt) {
-    const float pv = p[i];
-    if (wd != 0.f) gv = fmaf(wd, pv, gv);
-    const float mv = m[i] + (1.f - beta1) * (gv - m[i]);        // lerp_ like torch
-    const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
-    m[i] = mv;
-    v[i] = vv;
-    const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
-    p[i] = pv - step_size * (mv / denom);
-}
-
-__global__ __launch_bounds__(256) void adam_segments_kernel(
-    float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
-    float beta1, float beta2, float eps, float wd, float step_size, float inv_bc2_sqrt, AdamSegs segs,
-    const float *__restrict__ row_nll, int n_loss_rows, float inv_count, float *__restrict__ loss) {
+// Adam over the arena with DEFERRED gradient reductions (gist_adam_segments_f32): device code in adam_body.h.
+// One 256-thread workgroup per virtual block; the last workgroup reduces the step's loss when row_nll != NULL.
+__global__ __launch_bounds__(256) void adam_segments_kernel(AdamArgs A) {
     __shared__ float red[4];
-    __shared__ float part[3][64];
-    const int64_t n_chunks = (n + 1023) / 1024;
-    if ((int64_t)blockIdx.x >= n_chunks) {
-        const int idx = (int)((int64_t)blockIdx.x - n_chunks);
-        if (idx >= segs.n_ded) {
-            if (row_nll != nullptr) loss_reduce_256(row_nll, n_loss_rows, inv_count, loss, red);
-            return;
-        }
-        int sg = -1;                                       // uniform: the segment this workgroup serves
-        for (int s = 0; s < segs.n; ++s)                   // (the last one that starts at or before idx)
-            if (segs.ded_first[s] >= 0 && segs.ded_first[s] <= idx &&
-                (sg < 0 || segs.ded_first[s] > segs.ded_first[sg]))
-                sg = s;
-        if (sg < 0) return;
-        const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-        const int64_t i = segs.begin[sg] + (int64_t)(idx - segs.ded_first[sg]) * 64 + e;
-        const bool live = i < segs.end[sg];
-        float acc = 0.f;
-        if (live) acc = chunk_partial4(segs.src[sg] + (i - segs.begin[sg]), segs.stride[sg], segs.n_src[sg], q);
-        if (q > 0) part[q - 1][e] = acc;
-        __syncthreads();
-        if (q == 0 && live) {
-            const float gv = ((acc + part[0][e]) + part[1][e]) + part[2][e];
-            g[i] = gv;
-            adam_update(p, m, v, i, gv, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-        }
+    const int64_t n_blocks = adam_arena_blocks(A.n) + A.segs.n_ded;
+    if ((int64_t)blockIdx.x >= n_blocks) {
+        if (A.row_nll != nullptr) loss_reduce_256(A.row_nll, A.n_loss_rows, A.inv_count, A.loss, red);
         return;
     }
-    const int64_t lo = (int64_t)blockIdx.x * 1024;
-    const int64_t hi = lo + 1024 < n ? lo + 1024 : n;
-    unsigned touch = 0;                                   // uniform: segments intersecting [lo, hi)
-    for (int s = 0; s < segs.n; ++s)
-        if (segs.begin[s] < hi && segs.end[s] > lo) touch |= 1u << s;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = lo + threadIdx.x + 256 * u;
-        if (i >= hi) break;
-        float gv;
-        int sg = -1;
-        for (unsigned t = touch; t; t &= t - 1) {
-            const int s = __builtin_ctz(t);
-            if (i >= segs.begin[s] && i < segs.end[s]) sg = s;
-        }
-        if (sg >= 0) {
-            if (segs.ded_first[sg] >= 0) continue;        // a dedicated workgroup owns this element
-            const float *src = segs.src[sg] + (i - segs.begin[sg]);
-            const int64_t stride = segs.stride[sg];
-            const int ns = segs.n_src[sg];
-            float acc = 0.f;
-            int k = 0;
-            for (; k + 4 <= ns; k += 4) {                 // source order, four loads in flight
-                const float t0 = src[(int64_t)k * stride], t1 = src[(int64_t)(k + 1) * stride];
-                const float t2 = src[(int64_t)(k + 2) * stride], t3 = src[(int64_t)(k + 3) * stride];
-                acc += t0; acc += t1; acc += t2; acc += t3;
-            }
-            for (; k < ns; ++k) acc += src[(int64_t)k * stride];
-            gv = acc;
-            g[i] = acc;
-        } else {
-            gv = g[i];
-        }
-        adam_update(p, m, v, i, gv, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-    }
+    adam_virtual_block(A, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1295,48 +1175,67 @@ extern "C" int gist_adam_f32(float *param, const float *grad, float *exp_avg, fl
     return launch_status("gist_adam_f32");
 }
 
+namespace gist {
+int adam_segments_args(const char *name, float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                       const gist_grad_segment *segments, int64_t n_segments, const float *row_loss,
+                       int64_t n_loss_rows, int64_t loss_count, float *loss, AdamArgs *out) {
+    GIST_REQUIRE(n >= 0, "%s: n < 0", name);
+    GIST_REQUIRE(n_segments >= 0 && n_segments <= kAdamMaxSegs, "%s: too many segments", name);
+    GIST_REQUIRE(n_segments == 0 || segments != nullptr, "%s: null segments", name);
+    GIST_REQUIRE(row_loss == nullptr || (loss != nullptr && loss_count > 0 && n_loss_rows >= 0 &&
+                                         n_loss_rows < (1LL << 31)),
+                 "%s: bad loss arguments", name);
+    GIST_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), "%s: null pointer", name);
+    GIST_REQUIRE(step >= 1, "%s: step is 1-based", name);
+    AdamArgs A{};
+    AdamSegs &sg = A.segs;
+    for (int64_t i = 0; i < n_segments; ++i) {
+        const gist_grad_segment &q = segments[i];
+        if (q.src == nullptr || q.end <= q.begin) continue;
+        GIST_REQUIRE(q.begin >= 0 && q.end <= n && q.n_src >= 1 && q.stride >= q.end - q.begin,
+                     "%s: bad segment %d", name, (int)i);
+        for (int j = 0; j < sg.n; ++j)
+            GIST_REQUIRE(q.end <= sg.begin[j] || q.begin >= sg.end[j], "%s: overlapping segments", name);
+        sg.begin[sg.n] = q.begin; sg.end[sg.n] = q.end; sg.stride[sg.n] = q.stride;
+        sg.n_src[sg.n] = q.n_src; sg.src[sg.n] = q.src;
+        // many sources, few elements (a bias gradient in row chunks): dedicated blocks of 64 elements
+        sg.ded_first[sg.n] = -1;
+        if (q.n_src > 16 && q.end - q.begin <= 65536) {
+            sg.ded_first[sg.n] = sg.n_ded;
+            sg.n_ded += (int)ceil_div(q.end - q.begin, 64);
+        }
+        ++sg.n;
+    }
+    // bias corrections in double on the host, like torch's python scalar math
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    A.p = param; A.g = grad; A.m = exp_avg; A.v = exp_avg_sq; A.n = n;
+    A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.wd = weight_decay;
+    A.step_size = (float)((double)lr / bc1);
+    A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    A.row_nll = row_loss; A.n_loss_rows = (int)n_loss_rows;
+    A.inv_count = row_loss ? 1.0f / (float)loss_count : 0.f;
+    A.loss = loss;
+    GIST_REQUIRE(adam_arena_blocks(n) + sg.n_ded < (1LL << 31) - 2, "%s: arena too large", name);
+    *out = A;
+    return GIST_OK;
+}
+}  // namespace gist
+
 extern "C" int gist_adam_segments_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
                                       int64_t n, float lr, float beta1, float beta2, float eps,
                                       float weight_decay, int64_t step, const gist_grad_segment *segments,
                                       int64_t n_segments, const float *row_loss, int64_t n_loss_rows,
                                       int64_t loss_count, float *loss, gist_stream_t stream) {
-    GIST_REQUIRE(n >= 0, "gist_adam_segments_f32: n < 0");
-    GIST_REQUIRE(n_segments >= 0 && n_segments <= gist::kAdamMaxSegs, "gist_adam_segments_f32: too many segments");
-    GIST_REQUIRE(n_segments == 0 || segments != nullptr, "gist_adam_segments_f32: null segments");
-    GIST_REQUIRE(row_loss == nullptr || (loss != nullptr && loss_count > 0 && n_loss_rows >= 0 &&
-                                         n_loss_rows < (1LL << 31)),
-                 "gist_adam_segments_f32: bad loss arguments");
+    gist::AdamArgs A;
+    const int rc = gist::adam_segments_args("gist_adam_segments_f32", param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                                            eps, weight_decay, step, segments, n_segments, row_loss, n_loss_rows,
+                                            loss_count, loss, &A);
+    if (rc != GIST_OK) return rc;
     if (n == 0 && row_loss == nullptr) return GIST_OK;
-    GIST_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), "gist_adam_segments_f32: null pointer");
-    GIST_REQUIRE(step >= 1, "gist_adam_segments_f32: step is 1-based");
-    gist::AdamSegs sg{};
-    for (int64_t i = 0; i < n_segments; ++i) {
-        const gist_grad_segment &q = segments[i];
-        if (q.src == nullptr || q.end <= q.begin) continue;
-        GIST_REQUIRE(q.begin >= 0 && q.end <= n && q.n_src >= 1 && q.stride >= q.end - q.begin,
-                     "gist_adam_segments_f32: bad segment %d", (int)i);
-        for (int j = 0; j < sg.n; ++j)
-            GIST_REQUIRE(q.end <= sg.begin[j] || q.begin >= sg.end[j], "gist_adam_segments_f32: overlapping segments");
-        sg.begin[sg.n] = q.begin; sg.end[sg.n] = q.end; sg.stride[sg.n] = q.stride;
-        sg.n_src[sg.n] = q.n_src; sg.src[sg.n] = q.src;
-        // many sources, few elements (a bias gradient in row chunks): dedicated workgroups of 64 elements
-        sg.ded_first[sg.n] = -1;
-        if (q.n_src > 16 && q.end - q.begin <= 65536) {
-            sg.ded_first[sg.n] = sg.n_ded;
-            sg.n_ded += (int)gist::ceil_div(q.end - q.begin, 64);
-        }
-        ++sg.n;
-    }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    const int64_t chunks = gist::ceil_div(n, 1024);
-    GIST_REQUIRE(chunks < (1LL << 31) - 2, "gist_adam_segments_f32: arena too large");
-    hipLaunchKernelGGL(gist::adam_segments_kernel, dim3((unsigned)(chunks + sg.n_ded + (row_loss ? 1 : 0))), dim3(256), 0,
-                       gist::as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
-                       weight_decay, step_size, inv_bc2_sqrt, sg, row_loss, (int)n_loss_rows,
-                       row_loss ? 1.0f / (float)loss_count : 0.f, loss);
+    const int64_t blocks = gist::adam_arena_blocks(n) + A.segs.n_ded + (row_loss ? 1 : 0);
+    hipLaunchKernelGGL(gist::adam_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, gist::as_stream(stream), A);
     return gist::launch_status("gist_adam_segments_f32");
 }
 

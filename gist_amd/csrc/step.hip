@@ -364,6 +364,27 @@ static int step_spmm(const gist_step_plan *p, const int32_t *rowptr, const int32
     return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale, accumulate, s);
 }
 
+constexpr int64_t kPrefetchMaxParams = 6LL << 20;
+// can the next batch (plan->next_*) be extracted by gist_extract_parts_batch's kernel?
+static bool next_parts_ok(const gist_step_plan *p, bool fuse) {
+    return fuse && p->node_part && p->part_slot && p->extract_scratch && p->next_ids && p->next_batch_index >= 0 &&
+           p->next_n > 0 && p->next_n <= p->n_max && gist_extract_parts_supported(p->n_max) == 1;
+}
+
+extern "C" int gist_sage_step_extracts_next(const gist_step_plan *p, int64_t n, int flags) {
+    if (p == nullptr || !(flags & GIST_STEP_TRAIN) || n <= 0) return 0;
+    const bool fuse = p->fuse != 0 && n <= p->n_max;
+    if (!fuse || p->col_partials == nullptr || !aligned16(p->col_partials)) return 0;
+    const FusedLayout fl = fused_layout(p, static_cast<char *>(p->fused_workspace), p->col_partials);
+    const bool defer = p->fused_workspace == nullptr ? fl.bytes == 0
+                                                     : (aligned16(p->fused_workspace) && fl.bytes <= p->fused_workspace_bytes);
+    // (beside a LARGE optimiser pass the extraction's 1024-thread workgroups cost more than they hide: each holds half a
+    // CU's wave slots for the ~20 us of its look-back chain -- 233 against 199 + 21 us at 38.8 M parameters, 32 against
+    // 16 + 21 at 1.2 M; measured break-even between 3.3 M and 38.8 M)
+    if (p->n_params > kPrefetchMaxParams) return 0;
+    return defer && next_parts_ok(p, fuse) ? 1 : 0;
+}
+
 extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64_t n,
                               uint64_t drop_offset, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int64_t adam_step, int flags,
@@ -415,7 +436,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         plain[k] = !h3.layer[k].on && !b3.layer[k].on;
         // forward: dropout([h | ah]) written by the producers, the aggregation reads hsrc[k]
         fwd_fold[k] = fuse && drop && plain[k] && p->hsrc[k] != nullptr && (offs[k] & 1) == 0 &&
-                      (k > 0 || (flags & GIST_STEP_EXTRACT)) &&
+                      (k > 0 || (flags & (GIST_STEP_EXTRACT | GIST_STEP_PREEXTRACTED))) &&
                       p->ld_hsrc[k] >= l.n_in &&
                       spmm_drop_takes(1, l.n_in, p->ld_hsrc[k], l.ldz, p->hsrc[k], l.Z + l.n_in, blocked ? p->row_blocks : nullptr);
         // backward: the mask of dZ_k applied by the reverse aggregation as it reads dZ_k
@@ -837,7 +858,28 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
         }
     }
-    if (defer)
+    if (defer && (flags & GIST_STEP_EXTRACT_NEXT) && next_parts_ok(p, fuse) && p->n_params <= kPrefetchMaxParams) {
+        // the optimiser and the NEXT batch's extraction in one grid: nothing reads the batch buffers any more.  Layer 0's
+        // mask goes into the next batch's feature gather under the rule the next call applies to itself (fwd_fold[0])
+        const gist_layer_desc &l0 = p->layer[0];
+        const bool fold0 = fuse && drop && plain[0] && p->hsrc[0] != nullptr && (p->next_drop_offset & 1) == 0 &&
+                           p->ld_hsrc[0] >= l0.n_in &&
+                           spmm_drop_takes(1, l0.n_in, p->ld_hsrc[0], l0.ldz, p->hsrc[0], l0.Z + l0.n_in,
+                                           blocked ? p->row_blocks : nullptr);
+        gist_extract_parts_desc x{};
+        x.g_rowptr = p->g_rowptr; x.g_col = p->g_col; x.g_t_rowptr = p->g_t_rowptr; x.g_t_col = p->g_t_col;
+        x.ids = p->next_ids; x.n = p->next_n; x.n_max = p->n_max;
+        x.node_part = p->node_part; x.part_slot = p->part_slot; x.batch = p->next_batch_index;
+        x.rowptr = p->rowptr; x.col = p->col; x.t_rowptr = p->t_rowptr; x.t_col = p->t_col;
+        x.col_capacity = p->col_capacity; x.norm = p->norm;
+        x.feat = p->feat; x.ld_feat = p->ld_feat; x.n_feat = l0.n_in; x.z0 = l0.Z; x.ldz0 = l0.ldz;
+        x.labels_all = p->labels_all; x.labels = p->labels;
+        x.x0 = fold0 ? p->hsrc[0] : nullptr; x.ldx0 = p->ld_hsrc[0]; x.p = p->p_drop; x.seed = p->seed;
+        x.offset = p->next_drop_offset; x.mask_ld = 2 * l0.n_in; x.scratch = p->extract_scratch;
+        GIST_TRY(gist_adam_segments_extract_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
+                                                beta2, eps, weight_decay, adam_step, segs, n_segs, p->row_loss, n, n,
+                                                p->loss, &x, s));
+    } else if (defer)
         GIST_TRY(gist_adam_segments_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
                                         beta2, eps, weight_decay, adam_step, segs, n_segs, p->row_loss, n, n,
                                         p->loss, s));

@@ -12,6 +12,7 @@
 // Integer work, bit exact against the oracle.  Bound: HBM/L2 reads of the selected
 // adjacency rows, 2 x 4 B per full-graph edge of the batch rows.
 #include "common.h"
+#include "adam_body.h"
 
 namespace gist {
 
@@ -274,7 +275,9 @@ struct PartsArgs {
 constexpr int kStash = 256;
 constexpr int kPartsWaves = 16;
 
-__global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsArgs a) {
+// workgroup (bx, by) of a (gx, 3) grid of 16-wave workgroups (extract_parts_kernel; adam_extract_kernel below runs
+// the same workgroups in one grid with the optimiser's)
+__device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const int bx, const int by, const int gx) {
     __shared__ int32_t stash[kPartsWaves][kStash];
     __shared__ int wcnt[kPartsWaves];
     __shared__ int wbase;
@@ -284,12 +287,12 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
     // the look-back below waits for the chunks BEFORE this one, so chunk numbers must follow the order in which
     // workgroups actually started, and HIP promises no dispatch order.  One returning atomic per workgroup; the
     // workgroup that draws the last ticket puts the counter back to zero for the next (stream-ordered) launch.
-    int tile = (int)blockIdx.x;
-    if (blockIdx.y < 2) {
+    int tile = bx;
+    if (by < 2) {
         if (threadIdx.x == 0) {
-            unsigned long long *tk = a.tickets + blockIdx.y;
+            unsigned long long *tk = a.tickets + by;
             const unsigned long long t = __hip_atomic_fetch_add(tk, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1 == (unsigned long long)gridDim.x)
+            if (t + 1 == (unsigned long long)gx)
                 __hip_atomic_store(tk, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_tile = (int)t;
         }
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
         tile = s_tile;
     }
     const int i = tile * kPartsWaves + wave;
-    if (blockIdx.y == 2) {                                   // ---- features + label of row i
+    if (by == 2) {                                   // ---- features + label of row i
         if (i >= a.n) return;
         const int v = a.ids[i];
         const float *__restrict__ s = a.feat + (int64_t)v * a.ld_feat;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
         if (lane == 0 && a.labels_all) a.labels[i] = a.labels_all[v];
         return;
     }
-    const int which = blockIdx.y;
+    const int which = by;
     const int32_t *rowptr = a.p.rowptr[which], *col = a.p.col[which];
     const int2 *node_part = reinterpret_cast<const int2 *>(a.node_part);
     const int2 *part_slot = reinterpret_cast<const int2 *>(a.part_slot);
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
     // counter.  Device-scope read-modify-writes on one address complete at ~0.1-0.3 us each on this
     // multi-die part: 260 arrivals took 26 us, 1030 took 340; device-scope FENCES write back and
     // invalidate the XCD's whole L2, which the gather workgroups keep dirty: 206 us.)
-    unsigned long long *slots = a.slots + (int64_t)which * gridDim.x;
+    unsigned long long *slots = a.slots + (int64_t)which * gx;
     __syncthreads();
     if (threadIdx.x == 0) {
         int t = 0;
@@ -446,6 +449,46 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
             wp += __popcll(m);
         }
     }
+}
+
+__global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsArgs a) {
+    extract_parts_block(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// The optimiser and the NEXT batch's extraction in one grid (gist_adam_segments_extract_f32).  Once the backward pass
+// is done nothing reads the batch buffers any more, and the next batch depends on nothing the step computes: its 3 gx
+// extraction workgroups (dispatched first: their look-back chain is latency, 21 us for ~2000 rows) run beside the
+// optimiser's (memory), instead of in front of the next step's first aggregation.  1024-thread workgroups: an
+// optimiser workgroup runs four of adam_body.h's virtual blocks; the last workgroup reduces the loss.
+__global__ __launch_bounds__(64 * kPartsWaves) void adam_extract_kernel(PartsArgs a, int gx, AdamArgs A) {
+    __shared__ float red[4];
+    const int n_ex = 3 * gx;
+    if ((int)blockIdx.x < n_ex) {
+        extract_parts_block(a, (int)blockIdx.x % gx, (int)blockIdx.x / gx, gx);
+        return;
+    }
+    // the optimiser's workgroups in the order of their own latency: the dedicated blocks (chunk sums walked source by
+    // source: the longest chains) and the loss first, so that they start with the extraction; the arena's blocks
+    // (bandwidth) fill in behind them as slots come free
+    int64_t w = (int64_t)blockIdx.x - n_ex;
+    const int64_t n_arena = adam_arena_blocks(A.n);
+    const int64_t ded_wg = (A.segs.n_ded + 3) / 4;
+    const int quarter = threadIdx.x >> 8;
+    if (w < ded_wg) {
+        const int64_t d = 4 * w + quarter;
+        if (d < A.segs.n_ded) adam_virtual_block(A, n_arena + d, threadIdx.x & 255);
+        return;
+    }
+    w -= ded_wg;
+    if (A.row_nll != nullptr) {
+        if (w == 0) {
+            loss_reduce_256(A.row_nll, A.n_loss_rows, A.inv_count, A.loss, red);
+            return;
+        }
+        --w;
+    }
+    const int64_t vb = 4 * w + quarter;
+    if (vb < n_arena) adam_virtual_block(A, vb, threadIdx.x & 255);
 }
 
 // dst[i, :] = src[ids[i], :]; one wave per row
@@ -740,6 +783,45 @@ extern "C" int gist_extract_parts_supported(int64_t n_max) {
     return n_max > 0 && n_max < (1LL << 31) - 64 ? 1 : 0;
 }
 
+// checks a descriptor and turns it into the kernel's arguments (a fresh launch epoch each time)
+static int parts_args(const char *name, const gist_extract_parts_desc &x, PartsArgs *out) {
+    GIST_REQUIRE(x.n > 0 && x.n <= x.n_max && x.n_max < (1LL << 31) - 8, "%s: bad n", name);
+    GIST_REQUIRE(x.g_rowptr && x.g_col && x.g_t_rowptr && x.g_t_col && x.ids && x.node_part && x.part_slot && x.rowptr &&
+                     x.col && x.t_rowptr && x.t_col && x.norm && x.feat && x.z0 && x.scratch,
+                 "%s: null pointer", name);
+    GIST_REQUIRE(aligned8(x.node_part) && aligned8(x.part_slot), "%s: tables must be 8-byte aligned", name);
+    GIST_REQUIRE(x.n_feat > 0 && x.ld_feat >= x.n_feat && x.ldz0 >= x.n_feat && x.n_feat < (1LL << 31),
+                 "%s: bad feature shape", name);
+    GIST_REQUIRE(x.col_capacity >= 0 && x.batch >= 0, "%s: bad capacity / batch index", name);
+    GIST_REQUIRE(aligned8(x.scratch), "%s: scratch must be 8-byte aligned", name);
+    GIST_REQUIRE(gist_extract_parts_supported(x.n_max) == 1, "%s: bad n_max", name);
+    // launch epochs: process-wide, never 0 (a zeroed scratch matches no launch), never reused
+    static std::atomic<unsigned long long> g_epoch{0};
+    const unsigned long long epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) + 1) & ((1ULL << 33) - 1);
+    GIST_REQUIRE(epoch != 0, "%s: launch counter exhausted", name);
+    PartsArgs a{};
+    a.p.rowptr[0] = x.g_rowptr; a.p.col[0] = x.g_col; a.p.sub_rowptr[0] = x.rowptr; a.p.sub_col[0] = x.col;
+    a.p.rowptr[1] = x.g_t_rowptr; a.p.col[1] = x.g_t_col; a.p.sub_rowptr[1] = x.t_rowptr; a.p.sub_col[1] = x.t_col;
+    a.ids = x.ids; a.n = (int)x.n; a.n_max = (int)x.n_max;
+    a.node_part = x.node_part; a.part_slot = x.part_slot;
+    a.batch = x.batch; a.capacity = x.col_capacity; a.norm = x.norm;
+    a.error = static_cast<unsigned long long *>(x.scratch) + 1;
+    a.tickets = static_cast<unsigned long long *>(x.scratch) + 2;
+    a.slots = static_cast<unsigned long long *>(x.scratch) + 4;
+    a.epoch = epoch;
+    a.feat = x.feat; a.ld_feat = x.ld_feat; a.d = (int)x.n_feat; a.z0 = x.z0; a.ldz0 = x.ldz0;
+    a.labels_all = x.labels_all; a.labels = x.labels;
+    a.drop = 0;
+    if (x.x0 != nullptr) {
+        GIST_REQUIRE(x.ldx0 >= x.n_feat && x.mask_ld >= x.n_feat && x.p >= 0.f && x.p < 1.f, "%s: bad dropout arguments", name);
+        a.drop = 1;
+        a.gd.x0 = x.x0; a.gd.ldx0 = x.ldx0; a.gd.p = x.p; a.gd.scale = x.p > 0.f ? 1.0f / (1.0f - x.p) : 1.f;
+        a.gd.sm = x.seed * 0x9E3779B97F4A7C15ULL; a.gd.offset = x.offset; a.gd.mask_ld = x.mask_ld;
+    }
+    *out = a;
+    return GIST_OK;
+}
+
 extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *g_col,
                                         const int32_t *g_t_rowptr, const int32_t *g_t_col,
                                         const int32_t *ids, int64_t n, int64_t n_max,
@@ -749,41 +831,40 @@ extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *
                                         int64_t n_feat, float *z0, int64_t ldz0, const int32_t *labels_all,
                                         int32_t *labels, float *x0, int64_t ldx0, float p, uint64_t seed,
                                         uint64_t offset, int64_t mask_ld, void *scratch, gist_stream_t stream) {
-    GIST_REQUIRE(n > 0 && n <= n_max && n_max < (1LL << 31) - 8, "gist_extract_parts_batch: bad n");
-    GIST_REQUIRE(g_rowptr && g_col && g_t_rowptr && g_t_col && ids && node_part && part_slot && rowptr && col &&
-                     t_rowptr && t_col && norm && feat && z0 && scratch,
-                 "gist_extract_parts_batch: null pointer");
-    GIST_REQUIRE(aligned8(node_part) && aligned8(part_slot), "gist_extract_parts_batch: tables must be 8-byte aligned");
-    GIST_REQUIRE(n_feat > 0 && ld_feat >= n_feat && ldz0 >= n_feat && n_feat < (1LL << 31),
-                 "gist_extract_parts_batch: bad feature shape");
-    GIST_REQUIRE(col_capacity >= 0 && batch >= 0, "gist_extract_parts_batch: bad capacity / batch index");
-    GIST_REQUIRE(aligned8(scratch), "gist_extract_parts_batch: scratch must be 8-byte aligned");
-    GIST_REQUIRE(gist_extract_parts_supported(n_max) == 1, "gist_extract_parts_batch: bad n_max");
-    // launch epochs: process-wide, never 0 (a zeroed scratch matches no launch), never reused
-    static std::atomic<unsigned long long> g_epoch{0};
-    const unsigned long long epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) + 1) & ((1ULL << 33) - 1);
-    GIST_REQUIRE(epoch != 0, "gist_extract_parts_batch: launch counter exhausted");
-    PartsArgs a{};
-    a.p.rowptr[0] = g_rowptr; a.p.col[0] = g_col; a.p.sub_rowptr[0] = rowptr; a.p.sub_col[0] = col;
-    a.p.rowptr[1] = g_t_rowptr; a.p.col[1] = g_t_col; a.p.sub_rowptr[1] = t_rowptr; a.p.sub_col[1] = t_col;
-    a.ids = ids; a.n = (int)n; a.n_max = (int)n_max;
-    a.node_part = node_part; a.part_slot = part_slot;
-    a.batch = batch; a.capacity = col_capacity; a.norm = norm;
-    a.error = static_cast<unsigned long long *>(scratch) + 1;
-    a.tickets = static_cast<unsigned long long *>(scratch) + 2;
-    a.slots = static_cast<unsigned long long *>(scratch) + 4;
-    a.epoch = epoch;
-    a.feat = feat; a.ld_feat = ld_feat; a.d = (int)n_feat; a.z0 = z0; a.ldz0 = ldz0;
-    a.labels_all = labels_all; a.labels = labels;
-    a.drop = 0;
-    if (x0 != nullptr) {
-        GIST_REQUIRE(ldx0 >= n_feat && mask_ld >= n_feat && p >= 0.f && p < 1.f,
-                     "gist_extract_parts_batch: bad dropout arguments");
-        a.drop = 1;
-        a.gd.x0 = x0; a.gd.ldx0 = ldx0; a.gd.p = p; a.gd.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
-        a.gd.sm = seed * 0x9E3779B97F4A7C15ULL; a.gd.offset = offset; a.gd.mask_ld = mask_ld;
-    }
+    gist_extract_parts_desc x{};
+    x.g_rowptr = g_rowptr; x.g_col = g_col; x.g_t_rowptr = g_t_rowptr; x.g_t_col = g_t_col;
+    x.ids = ids; x.n = n; x.n_max = n_max; x.node_part = node_part; x.part_slot = part_slot; x.batch = batch;
+    x.rowptr = rowptr; x.col = col; x.t_rowptr = t_rowptr; x.t_col = t_col; x.col_capacity = col_capacity; x.norm = norm;
+    x.feat = feat; x.ld_feat = ld_feat; x.n_feat = n_feat; x.z0 = z0; x.ldz0 = ldz0;
+    x.labels_all = labels_all; x.labels = labels;
+    x.x0 = x0; x.ldx0 = ldx0; x.p = p; x.seed = seed; x.offset = offset; x.mask_ld = mask_ld; x.scratch = scratch;
+    PartsArgs a;
+    const int rc = parts_args("gist_extract_parts_batch", x, &a);
+    if (rc != GIST_OK) return rc;
     hipLaunchKernelGGL(extract_parts_kernel, dim3((unsigned)ceil_div(n, kPartsWaves), 3),
                        dim3(64 * kPartsWaves), 0, as_stream(stream), a);
     return launch_status("gist_extract_parts_batch");
+}
+
+extern "C" int gist_adam_segments_extract_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                                              int64_t n, float lr, float beta1, float beta2, float eps,
+                                              float weight_decay, int64_t step, const gist_grad_segment *segments,
+                                              int64_t n_segments, const float *row_loss, int64_t n_loss_rows,
+                                              int64_t loss_count, float *loss, const gist_extract_parts_desc *next,
+                                              gist_stream_t stream) {
+    GIST_REQUIRE(next != nullptr, "gist_adam_segments_extract_f32: null descriptor");
+    gist::AdamArgs A;
+    int rc = gist::adam_segments_args("gist_adam_segments_extract_f32", param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                                      beta2, eps, weight_decay, step, segments, n_segments, row_loss, n_loss_rows,
+                                      loss_count, loss, &A);
+    if (rc != GIST_OK) return rc;
+    PartsArgs a;
+    rc = parts_args("gist_adam_segments_extract_f32", *next, &a);
+    if (rc != GIST_OK) return rc;
+    const int64_t gx = ceil_div(next->n, kPartsWaves);
+    const int64_t blocks = 3 * gx + ceil_div((int64_t)A.segs.n_ded, 4) + (row_loss ? 1 : 0) +
+                           ceil_div(gist::adam_arena_blocks(n), 4);
+    GIST_REQUIRE(blocks < (1LL << 31), "gist_adam_segments_extract_f32: grid too large");
+    hipLaunchKernelGGL(adam_extract_kernel, dim3((unsigned)blocks), dim3(64 * kPartsWaves), 0, as_stream(stream), a, (int)gx, A);
+    return launch_status("gist_adam_segments_extract_f32");
 }

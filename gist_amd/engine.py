@@ -83,7 +83,7 @@ class ParamArena(object):
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
     __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
-                 'row_blocks', 'batcher', 'parts', 'z0_dropped')
+                 'row_blocks', 'batcher', 'parts', 'z0_dropped', 'next_info')
 
     def __init__(self):
         self.ready = True
@@ -95,6 +95,7 @@ class Batch(object):
         self.row_blocks = None      # int32 [n_blocks + 1]: row ranges of the batch's METIS parts
         self.batcher = None         # set on lazy batches: who extracts them
         self.parts = None           # (node_part [N, 2], part_slot [parts, 2], batch index) -- sampler
+        self.next_info = None       # (ids, batch index) of the batch that follows in the same epoch -- sampler
 
 
 class ClusterBatcher(object):
@@ -119,6 +120,9 @@ class ClusterBatcher(object):
         self.t_col = torch.zeros(self.nnz_max, **i32)
         self.norm = torch.zeros(self.n_max, dtype=torch.float32, device=dev)
         self.lab = torch.zeros(self.n_max, **i32)
+        # what a step's optimiser launch extracted into these buffers for the NEXT step (SageEngine.prefetch):
+        # (part_slot table, batch index, rows, ids pointer, dropout offset) or None
+        self.prefetched = None
 
     def lazy(self, ids):
         """Describe the batch WITHOUT launching anything: the native step driver
@@ -142,6 +146,7 @@ class ClusterBatcher(object):
         n = ids.numel()
         if n > self.n_max:
             raise ValueError('gist_amd: batch of %d rows exceeds n_max=%d' % (n, self.n_max))
+        self.prefetched = None      # (the buffers are overwritten)
         g = self.g
         rp, trp = self.rowptr[:n + 1], self.t_rowptr[:n + 1]
         if drop is not None:
@@ -204,6 +209,11 @@ class SageEngine(object):
                 self.H[k] = torch.zeros(self.n_max, ld, **f32)
         self._fused = None          # op-by-op path's own slabs / chunk sums (lazy)
         self._extract_scratch = None    # barrier ticket + counts of the one-launch extraction
+        # True: a training step's optimiser launch also extracts the NEXT batch of the epoch into the batch buffers
+        # (gist_adam_segments_extract_f32).  For loops that only use the loss: labels, CSR and Z[0] of the batch just
+        # stepped are gone when train_step returns.  The trainers and bench.py set it; off by default
+        self.prefetch = False
+        self._prefetch_refused = None
         self._segments = []
         self._logit_slabs_n = 1
         self.plan = None
@@ -356,15 +366,26 @@ class SageEngine(object):
         import ctypes
         from . import _lib
         L = _lib.load()
-        flags = (_lib.GIST_STEP_TRAIN if train else 0) | (0 if b.ready else _lib.GIST_STEP_EXTRACT)
         off = self.drop_calls
+        ids_ptr = b.ids.data_ptr() if b.ids is not None else None
+        # was this batch extracted beside the previous step's optimiser launch (self.prefetch)?
+        batcher = b.batcher
+        pre = batcher.prefetched if batcher is not None else None
+        if batcher is not None:
+            batcher.prefetched = None
+        pre_ok = (pre is not None and train and not b.ready and b.parts is not None and
+                  pre == (b.parts[1].data_ptr(), int(b.parts[2]), b.n, ids_ptr, off))
+        flags = (_lib.GIST_STEP_TRAIN if train else 0)
+        if pre_ok:
+            flags |= _lib.GIST_STEP_PREEXTRACTED
+        elif not b.ready:
+            flags |= _lib.GIST_STEP_EXTRACT
         if train and self.p_drop > 0.0:
             for (i, o) in self.dims:
                 numel = b.n * 2 * i
                 self.drop_calls += numel + (numel & 1)
         if train:
             self.arena.step += 1
-        ids_ptr = b.ids.data_ptr() if b.ids is not None else None
         rb = b.row_blocks
         if rb is not None and rb.numel() > 1:
             self.plan.row_blocks, self.plan.n_row_blocks = rb.data_ptr(), rb.numel() - 1
@@ -389,9 +410,25 @@ class SageEngine(object):
         else:
             P.node_part = P.part_slot = P.extract_scratch = None
             P.batch_index = -1
+        # the NEXT batch of the epoch, extracted beside this step's optimiser launch (GIST_STEP_EXTRACT_NEXT): only
+        # for callers that promise not to look at the batch buffers (labels, CSR, Z[0]) after a training step
+        nxt = None
+        P.next_ids, P.next_n, P.next_batch_index, P.next_drop_offset = None, 0, -1, 0
+        if (self.prefetch and self._prefetch_refused is not True and train and batcher is not None
+                and b.next_info is not None and P.node_part is not None and b.row_blocks is not None):
+            nids, nj = b.next_info
+            P.next_ids, P.next_n, P.next_batch_index = nids.data_ptr(), nids.numel(), int(nj)
+            P.next_drop_offset = self.drop_calls          # (= `off` of the next training step)
+            if L.gist_sage_step_extracts_next(ctypes.byref(self.plan), b.n, flags):
+                flags |= _lib.GIST_STEP_EXTRACT_NEXT
+                nxt = (P.part_slot, int(nj), nids.numel(), nids.data_ptr(), self.drop_calls)
+            else:
+                self._prefetch_refused = True      # (a property of the plan: un-fused, or an arena too large to gain)
         rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
                               eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())
         _lib.check(rc, 'gist_sage_step')
+        if batcher is not None:
+            batcher.prefetched = nxt
         if not b.ready and train and self.fuse and self.p_drop > 0.0 and self.H[0] is not None:
             b.z0_dropped = True      # (layer 0's mask went into the feature gather: Batch contract)
         b.ready = True

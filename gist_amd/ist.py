@@ -261,6 +261,11 @@ def train(ist_model, args, cluster_iterator, evaluator=None, log=print):
     Returns total_time, per-site per-iteration device losses, accuracies, event log."""
     models = list(ist_model) if isinstance(ist_model, (list, tuple)) else [ist_model]
     local = len(models) > 1
+    # one sub-GCN per process (the distributed run): a step's optimiser launch may extract the next batch of the epoch
+    # beside it -- the loop only reads the loss.  Several sub-GCNs in one process share the extracted batch: not then
+    for m in models:
+        if m.engine is not None:
+            m.engine.prefetch = not local
     comm = models[0].comm
     multi = (not local) and comm.world_size() > 1
     is_rank0 = models[0].rank == 0

@@ -303,6 +303,9 @@ class EngineClusterIter(ClusterIter):
                                                       int(self._block_offsets[self.n + 1])]
             if self._part_tables is not None:
                 batch.parts = (self._node_part, self._part_tables, self.n)
+                if self.n + 1 < self.max:      # the batch that follows in this epoch (SageEngine.prefetch)
+                    a2, b2 = int(self._offsets[self.n + 1]), int(self._offsets[self.n + 2])
+                    batch.next_info = (self._epoch_ids[a2:b2], self.n + 1)
             self.n += 1
             return batch
         if self.engine is not None:

@@ -306,6 +306,7 @@ class ClusterGCNTrainer(object):
         if init_params is not None:
             self.engine.arena.load(init_params)
         self.it.bind(self.engine)
+        self.engine.prefetch = True      # (train_epoch only reads the loss of a step)
         self.lr, self.wd = lr, weight_decay
         self.use_layernorm = use_layernorm
         self.g_host = g

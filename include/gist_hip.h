@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 11 */
+int gist_abi_version(void);   /* currently 12 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -533,6 +533,28 @@ int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *g_col,
                              float *x0, int64_t ldx0, float p, uint64_t seed, uint64_t offset,
                              int64_t mask_ld, void *scratch, gist_stream_t stream);
 
+/* gist_extract_parts_batch's arguments as a structure, and the optimiser launch that ALSO extracts the next batch
+ * (round 4): gist_adam_segments_f32 and gist_extract_parts_batch(*next) in ONE grid -- after the backward pass nothing
+ * reads the batch buffers, and the next batch depends on nothing the step computes, so its extraction (21 us of
+ * dependent memory round trips for ~2000 rows) runs beside the optimiser instead of in front of the next step.  Same
+ * results as the two calls.  Same reference call sites (sampler.py:85-93 / optimizer.step()). */
+typedef struct gist_extract_parts_desc {
+    const int32_t *g_rowptr, *g_col, *g_t_rowptr, *g_t_col;
+    const int32_t *ids; int64_t n, n_max;
+    const int32_t *node_part, *part_slot; int32_t batch;
+    int32_t *rowptr, *col, *t_rowptr, *t_col; int64_t col_capacity; float *norm;
+    const float *feat; int64_t ld_feat, n_feat; float *z0; int64_t ldz0;
+    const int32_t *labels_all; int32_t *labels;
+    float *x0; int64_t ldx0; float p; uint64_t seed, offset; int64_t mask_ld;
+    void *scratch;
+} gist_extract_parts_desc;
+int gist_adam_segments_extract_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                                   int64_t n, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int64_t step,
+                                   const struct gist_grad_segment *segments, int64_t n_segments,
+                                   const float *row_loss, int64_t n_loss_rows, int64_t loss_count, float *loss,
+                                   const gist_extract_parts_desc *next, gist_stream_t stream);
+
 /* dst[i, 0:d] = src[ids[i], 0:d]  -- the ndata['feat'] gather of g.subgraph
  * (partition_utils.py:23) written straight into the left half of layer 0's
  * [h | ah] buffer (ldd). */
@@ -670,6 +692,14 @@ typedef struct gist_step_plan {
     const int32_t *node_part, *part_slot;
     int32_t batch_index;
     void *extract_scratch;
+    /* GIST_STEP_EXTRACT_NEXT (round 4): the NEXT batch of the same epoch (same node_part / part_slot tables), extracted
+     * into the batch buffers beside this step's optimiser launch (gist_adam_segments_extract_f32), with layer 0's
+     * dropout mask at next_drop_offset (= the drop_offset of the next call) folded in under the rules of this call.
+     * The next call then passes GIST_STEP_PREEXTRACTED instead of GIST_STEP_EXTRACT. */
+    const int32_t *next_ids;
+    int64_t next_n;
+    int32_t next_batch_index;
+    uint64_t next_drop_offset;
 } gist_step_plan;
 
 /* Bytes of fused_workspace / floats of col_partials the plan's shapes need.  Host functions. */
@@ -703,6 +733,8 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
 
 #define GIST_STEP_EXTRACT 1   /* build the batch from ids (else: batch buffers already valid) */
 #define GIST_STEP_TRAIN 2     /* dropout on, backward + Adam (else: forward + loss only)      */
+#define GIST_STEP_EXTRACT_NEXT 4   /* TRAIN only: also extract plan->next_* (gist_sage_step_extracts_next says whether this call can) */
+#define GIST_STEP_PREEXTRACTED 8   /* TRAIN only: the batch buffers hold THIS batch, extracted by the previous call's EXTRACT_NEXT */
 
 /* One iteration of the reference's training loop on the batch whose node ids (in the
  * training graph) are ids[0..n): induced subgraph + feature/label gather
@@ -720,6 +752,10 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
 int gist_sage_step(const gist_step_plan *plan, const int32_t *ids, int64_t n,
                    uint64_t drop_offset, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t adam_step, int flags, gist_stream_t stream);
+/* 1 if gist_sage_step(plan, ., n, ., flags | GIST_STEP_EXTRACT_NEXT) extracts plan->next_* beside its optimiser launch
+ * (a fused TRAIN step on a union-of-parts batch whose optimiser is gist_adam_segments_f32, next_n <= n_max); 0 if the
+ * flag would be ignored.  Host function. */
+int gist_sage_step_extracts_next(const gist_step_plan *plan, int64_t n, int flags);
 
 #ifdef __cplusplus
 }
