@@ -392,6 +392,10 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     GIST_REQUIRE(p != nullptr, "gist_sage_step: null plan");
     GIST_REQUIRE(p->n_layers >= 1 && p->n_layers <= GIST_MAX_LAYERS, "gist_sage_step: bad n_layers");
     GIST_REQUIRE(n > 0, "gist_sage_step: empty batch");
+    GIST_REQUIRE(!((flags & GIST_STEP_EXTRACT) && (flags & GIST_STEP_PREEXTRACTED)),
+                 "gist_sage_step: GIST_STEP_EXTRACT and GIST_STEP_PREEXTRACTED exclude each other");
+    GIST_REQUIRE(!(flags & (GIST_STEP_EXTRACT_NEXT | GIST_STEP_PREEXTRACTED)) || (flags & GIST_STEP_TRAIN),
+                 "gist_sage_step: GIST_STEP_EXTRACT_NEXT / GIST_STEP_PREEXTRACTED belong to training steps");
     const int L1 = p->n_layers;
     hipStream_t st = as_stream(s);
     ActiveTimer active(p->timer);

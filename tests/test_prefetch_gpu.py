@@ -156,3 +156,20 @@ def test_fused_optimiser_and_extraction_launch_equals_the_two_calls():
         assert torch.equal(a, b)
     assert int(outs[0][7][-1].item()) > 0 and float(outs[0][1].abs().sum().item()) > 0
     eng.check_extract()
+
+
+def test_step_flags_are_checked():
+    """GIST_STEP_PREEXTRACTED with GIST_STEP_EXTRACT, or either prefetch flag on a forward-only call: refused."""
+    import ctypes
+    from gist_amd import _lib, hip
+    L = _lib.load()
+    eng, it = _engine(0.2, 2, 302, 512)
+    b = next(iter(it))
+    eng.train_step(b, 0.01, 5e-4)
+    torch.cuda.synchronize()
+    args = (ctypes.byref(eng.plan), b.ids.data_ptr(), b.n, 0, 0.01, 0.9, 0.999, 1e-8, 0.0, 1)
+    for flags in (_lib.GIST_STEP_TRAIN | _lib.GIST_STEP_EXTRACT | _lib.GIST_STEP_PREEXTRACTED,
+                  _lib.GIST_STEP_EXTRACT | _lib.GIST_STEP_EXTRACT_NEXT, _lib.GIST_STEP_PREEXTRACTED):
+        assert L.gist_sage_step(*args, flags, hip._stream()) < 0
+    assert L.gist_sage_step_extracts_next(ctypes.byref(eng.plan), b.n, _lib.GIST_STEP_EXTRACT) == 0      # (not a training step)
+    torch.cuda.synchronize()
