@@ -473,11 +473,12 @@ def shared_dataset(name, local_rank, world, wait_s=600.0):
             (lambda: datasets.amazon_synth(seed=1))
     if world == 1:
         return build(), time.time() - t0, 'built, N=1'
-    tag = 'gist_bench_%s_%s' % (name, os.environ.get('MASTER_PORT', '0'))
+    tag = _shared_tag(name)
     root = os.environ.get('GIST_BENCH_SHM', '/dev/shm')
     d = os.path.join(root, tag)
     done = os.path.join(d, 'DONE')
     if local_rank == 0:
+        _drop_stale_shared(root)
         ds = build()
         tmp = d + '.tmp%d' % os.getpid()
         os.makedirs(tmp, exist_ok=True)
@@ -495,10 +496,28 @@ def shared_dataset(name, local_rank, world, wait_s=600.0):
     return datasets.load_arrays(d), time.time() - t0, 'loaded'
 
 
+def _shared_tag(name):
+    # one directory per LAUNCH: the ranks of a launch share MASTER_PORT and their parent (the launcher / the elastic
+    # agent), so a directory left behind by a run that died (same port, DONE present) is never mistaken for this one's
+    return 'gist_bench_%s_%s_%d' % (name, os.environ.get('MASTER_PORT', '0'), os.getppid())
+
+
+def _drop_stale_shared(root, older_than_s=1800.0):
+    """Directories of launches that never got to drop_shared_dataset hold 0.5-1.5 GB of memory each."""
+    import shutil
+    try:
+        for fn in os.listdir(root):
+            path = os.path.join(root, fn)
+            if fn.startswith('gist_bench_') and os.path.isdir(path) and os.stat(path).st_uid == os.getuid() \
+                    and time.time() - os.stat(path).st_mtime > older_than_s:
+                shutil.rmtree(path, ignore_errors=True)
+    except OSError:
+        pass
+
+
 def drop_shared_dataset(name):
     import shutil
-    tag = 'gist_bench_%s_%s' % (name, os.environ.get('MASTER_PORT', '0'))
-    shutil.rmtree(os.path.join(os.environ.get('GIST_BENCH_SHM', '/dev/shm'), tag), ignore_errors=True)
+    shutil.rmtree(os.path.join(os.environ.get('GIST_BENCH_SHM', '/dev/shm'), _shared_tag(name)), ignore_errors=True)
 
 
 def main():
@@ -561,6 +580,10 @@ def main():
     if world > 1:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
+    # (every rank has loaded its copy of the node's dataset by now -- the all-gather above is the first collective after
+    # the load: the /dev/shm directory can go, instead of holding 0.5-1.5 GB until the end of a run that may not get there)
+    if world > 1 and local_rank == 0:
+        drop_shared_dataset(args.dataset)
     keys = [json.dumps(i, sort_keys=True) for i in idents]
     devices_distinct = len(set(keys)) == world and all(i for i in idents)
     if world > 1 and not shared_gpu and not devices_distinct:
@@ -1021,8 +1044,6 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if local_rank == 0:
-            drop_shared_dataset(args.dataset)
         dist.destroy_process_group()
     wd.phase('done', None)
 

@@ -176,3 +176,38 @@ def test_rank_rendezvous_times_out_with_an_error_line():
     lines = _error_lines(r.stdout)
     assert len(lines) == 1 and lines[0]['value'] is None and lines[0].get('phase') == 'rendezvous', lines
     assert time.time() - t0 < 300
+
+
+def test_dataset_arrays_round_trip_and_launch_tag(tmp_path, monkeypatch):
+    """One synthetic graph per node: what local rank 0 writes for the other ranks (datasets.save_arrays) loads back bit
+    for bit, and the directory's name is per LAUNCH (port + parent process), so a directory left by a run that died is
+    not this launch's; stale ones are removed."""
+    import importlib.util
+    import os
+    import time
+    import numpy as np
+    from gist_amd import datasets
+    ds = datasets.toy(seed=3, n=600, n_blocks=6, n_feats=17, n_classes=4, train_frac=0.7)
+    d = tmp_path / 'one'
+    d.mkdir()
+    datasets.save_arrays(ds, str(d))
+    back = datasets.load_arrays(str(d))
+    assert back.num_classes == ds.num_classes and back.name == ds.name
+    for k in ('rowptr', 'col', 't_rowptr', 't_col'):
+        assert np.array_equal(getattr(back.g, k).numpy(), getattr(ds.g, k).numpy())
+    assert sorted(back.g.ndata) == sorted(ds.g.ndata)
+    for k in ds.g.ndata:
+        assert np.array_equal(back.g.ndata[k].numpy(), ds.g.ndata[k].numpy())
+    assert len(back.par_li) == len(ds.par_li) and all(np.array_equal(a, b) for a, b in zip(back.par_li, ds.par_li))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv('MASTER_PORT', '29123')
+    tag = bench._shared_tag('reddit-synth')
+    assert tag == 'gist_bench_reddit-synth_29123_%d' % os.getppid()
+    stale, fresh = tmp_path / 'gist_bench_x_1_2', tmp_path / 'gist_bench_x_1_3'
+    stale.mkdir(); fresh.mkdir()
+    old = time.time() - 7200
+    os.utime(str(stale), (old, old))
+    bench._drop_stale_shared(str(tmp_path))
+    assert not stale.exists() and fresh.exists() and d.exists()
