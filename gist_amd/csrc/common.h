@@ -92,7 +92,7 @@ int b3_dual_split(const B3Dual &d, hipStream_t st);
 int64_t b3_slab_bytes(int64_t m, int64_t n, int64_t k);   // fp32 slabs of a split-K call (0: one k slice)
 int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
                      int64_t ldc, int64_t m, int64_t n, int64_t k, float *slabs, int64_t slab_bytes,
-                     hipStream_t st, int *deferred = nullptr, bool b_rows_are_k = false);
+                     hipStream_t st, int *deferred = nullptr);
 // gemm.hip: gist_gemm_{nt,nn,tn}_f32 (layout 0, 1, 2) whose split-K partial sums stay as dense slabs
 // [*n_slabs][m][n] at `slabs` for the consumer to sum in slab order (+ bias); *n_slabs = 1: c is final
 int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, float *c,

@@ -62,19 +62,6 @@ constexpr int B3_KT_BYTES = B3_BK * 6;                 // 192 B of one row per k
 constexpr int B3_A_BYTES = B3_TM * B3_KT_BYTES;        // 24 KiB
 constexpr int B3_B_BYTES = B3_TN * B3_KT_BYTES;        // 12 KiB
 constexpr int B3_BUF_BYTES = B3_A_BYTES + B3_B_BYTES;
-// B read TRANSPOSED from a row-form operand (B_TR, the dZ projection: B = W^T from W's own split, no transposed copy of
-// W): a k tile is 32 ROWS of the operand x 128 columns = 768 bytes per row in the row form's byte order, one DMA
-// instruction of 1 KiB per row (its first o(r) and last 16 - o(r) slots carry nothing), fragments by ds_read_b64_tr_b16.
-constexpr int B3_BT_ROW = 1024;
-constexpr int B3_BT_BYTES = B3_BK * B3_BT_ROW;          // 32 KiB
-constexpr int B3_BUF_BYTES_BT = B3_A_BYTES + B3_BT_BYTES;
-static_assert(B3_STAGES * B3_BUF_BYTES_BT <= 160 * 1024, "LDS budget of one CU");
-typedef short b3_s16x4 __attribute__((ext_vector_type(4)));
-// Where row r of a transposed tile starts inside its 1-KiB slot, in 16-byte units.  A 32-lane half of a transposing read
-// touches 8 rows (r & 3 = 0..3, two k groups 8 rows apart) x two 16-byte pieces 48 bytes apart (the two 8-column chunks of
-// an MFMA tile, three pieces per chunk): the 8 x {o, o + 3} must be 16 different bank groups mod 16, and adding 3 walks
-// Z_16 in ONE cycle, so taking every other edge of that cycle -- o = 0, 6, 12, 2, 8, 14, 4, 10 -- is the matching.
-__host__ __device__ constexpr int b3_bt_shift(int r) { return (6 * ((r & 3) + 4 * ((r >> 3) & 1))) & 15; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t b3_pack(__bf16 lo, __bf16 hi) {
@@ -185,7 +172,6 @@ struct B3Args {
     int tiles_m, tiles_n;
     int kt_per_split;                    // k tiles per blockIdx.y (even); split s writes c + s * split_stride
     int64_t split_stride;
-    int kb_rows;                         // B_TR: rows of the row-form operand b (= k of the product); ldb = its pitch
 };
 
 // DMA instruction `inst` of an image: slot L = 64 (inst % 3) + lane of 16-row slab inst / 3; slot
@@ -230,9 +216,7 @@ __device__ __forceinline__ void b3_dma_image(const char *base, const uint32_t (&
 __device__ unsigned long long g_b3_clock[2 * 4096];
 #endif
 
-template <bool B_TR>
 __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
-    constexpr int BUF = B_TR ? B3_BUF_BYTES_BT : B3_BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) char b3_smem[];
     constexpr int NI = 4, NJ = 4;                 // 16-row slabs per wave: 64 x 64 wave tile
     const int nwg = g.tiles_m * g.tiles_n;
@@ -268,40 +252,13 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     constexpr int DA = B3_TM / 16 * 3 / NWAVES, DB = B3_TN / 16 * 3 / NWAVES;
     uint32_t offA[DA], offB[DB];
     b3_dma_offsets<DA>(g.lda, g.m, row0, DA * wave, lane, offA);
-    if constexpr (!B_TR) b3_dma_offsets<DB>(g.ldb, g.n, col0, DB * wave, lane, offB);
+    b3_dma_offsets<DB>(g.ldb, g.n, col0, DB * wave, lane, offB);
     const char *originA = reinterpret_cast<const char *>(g.a) + (int64_t)row0 * g.lda * 6 + (int64_t)kt0 * B3_KT_BYTES;
-    const char *originB = B_TR ? reinterpret_cast<const char *>(g.b) + (int64_t)col0 * 6
-                               : reinterpret_cast<const char *>(g.b) + (int64_t)col0 * g.ldb * 6 + (int64_t)kt0 * B3_KT_BYTES;
-    // B_TR: wave w stages rows 4 w .. 4 w + 3 of a k tile, one instruction each; lane L of row r carries 16-byte unit
-    // L - o(r) of the row's 48 (clamped into the row's pitch; what lands outside [o, o + 48) is never read)
-    constexpr int DBT = B3_BK / NWAVES;
-    uint32_t offBT[DBT];
-    if constexpr (B_TR) {
-        const int units = min(48, (int)((g.ldb - col0) / 8) * 3);      // 16-byte units of this row that exist
-#pragma unroll
-        for (int i = 0; i < DBT; ++i) {
-            const int u = lane - b3_bt_shift(DBT * wave + i);
-            // (a lane without a unit points past the descriptor's extent: no request goes out for it, and no branch)
-            offBT[i] = (u >= 0 && u < units) ? (uint32_t)(u * 16) : 0x80000000u;
-        }
-    }
-    const uint32_t ldb_bytes = (uint32_t)g.ldb * 6u;
+    const char *originB = reinterpret_cast<const char *>(g.b) + (int64_t)col0 * g.ldb * 6 + (int64_t)kt0 * B3_KT_BYTES;
     auto dma = [&](int buf, int kt) {
-        char *sa = b3_smem + buf * BUF;
+        char *sa = b3_smem + buf * B3_BUF_BYTES;
         b3_dma_image<DA>(originA + (int64_t)kt * B3_KT_BYTES, offA, sa, DA * wave);
-        if constexpr (!B_TR) {
-            b3_dma_image<DB>(originB + (int64_t)kt * B3_KT_BYTES, offB, sa + B3_A_BYTES, DB * wave);
-        } else {
-            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(originB), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < DBT; ++i) {
-                const int r = DBT * wave + i;
-                const int krow = min((kt0 + kt) * B3_BK + r, g.kb_rows - 1);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rsrc, (__attribute__((address_space(3))) void *)(sa + B3_A_BYTES + r * B3_BT_ROW), 16, offBT[i],
-                    (uint32_t)krow * ldb_bytes, 0, 0);
-            }
-        }
+        b3_dma_image<DB>(originB + (int64_t)kt * B3_KT_BYTES, offB, sa + B3_A_BYTES, DB * wave);
     };
 
     // fragment addresses: chunk c = 3 kg + piece of row rr of slab s sits at slot
@@ -314,30 +271,10 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
         const int in_slab = (rr * 12 + (c ^ ((rr >> 3) << 1))) * 16;
 #pragma unroll
         for (int st = 0; st < B3_STAGES; ++st) {
-            fa[st][p] = b3_smem + st * BUF + wm * NI * 3072 + in_slab;
-            fb[st][p] = b3_smem + st * BUF + B3_A_BYTES + wn * NJ * 3072 + in_slab;
+            fa[st][p] = b3_smem + st * B3_BUF_BYTES + wm * NI * 3072 + in_slab;
+            fb[st][p] = b3_smem + st * B3_BUF_BYTES + B3_A_BYTES + wn * NJ * 3072 + in_slab;
         }
     }
-    // B_TR: lane 4 q + pp of k group kg supplies row 8 kg + 4 h + q, columns 4 pp .. 4 pp + 3 of the 16-column tile j:
-    // unit o(row) + 3 (chunk of the column) + piece of the row's slot, 8 bytes per lane; h, j and the piece are immediates
-    const char *fbt[B3_STAGES];
-    {
-        const int q = (lane & 15) >> 2, pp = lane & 3;
-        const int brow = 8 * kg + q;
-        const int unit0 = b3_bt_shift(brow) + 3 * (wn * (2 * NJ) + (pp >> 1));
-#pragma unroll
-        for (int st = 0; st < B3_STAGES; ++st)
-            fbt[st] = b3_smem + st * BUF + B3_A_BYTES + brow * B3_BT_ROW + unit0 * 16 + (pp & 1) * 8;
-    }
-    auto read_bt = [&](int st, int j, int p) -> bf16x8 {
-        const char *a0 = fbt[st] + j * 96 + p * 16;
-        const b3_s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) b3_s16x4 *)(a0));
-        const b3_s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) b3_s16x4 *)(a0 + 4 * B3_BT_ROW));
-        typedef short b3_s16x8 __attribute__((ext_vector_type(8)));
-        const b3_s16x8 v = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        return __builtin_bit_cast(bf16x8, v);
-    };
 
     // One barrier per k step, in the MIDDLE of the step.  Terms in the order
     //   a2.b1  a3.b1 | a2.b2  a1.b1 | a1.b2  a1.b3        (16 MFMAs each; pieces 1-based as above)
@@ -357,10 +294,7 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     auto read_head = [&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if constexpr (B_TR) b[j][0] = read_bt(st, j, 0);
-            else b[j][0] = *reinterpret_cast<const bf16x8 *>(fb[st][0] + j * 3072);
-        }
+        for (int j = 0; j < NJ; ++j) b[j][0] = *reinterpret_cast<const bf16x8 *>(fb[st][0] + j * 3072);
 #pragma unroll
         for (int i = 0; i < NI; ++i) a[i][1] = *reinterpret_cast<const bf16x8 *>(fa[st][1] + i * 3072);
 #pragma unroll
@@ -369,17 +303,11 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     auto read_rest = [&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if constexpr (B_TR) b[j][1] = read_bt(st, j, 1);
-            else b[j][1] = *reinterpret_cast<const bf16x8 *>(fb[st][1] + j * 3072);
-        }
+        for (int j = 0; j < NJ; ++j) b[j][1] = *reinterpret_cast<const bf16x8 *>(fb[st][1] + j * 3072);
 #pragma unroll
         for (int i = 0; i < NI; ++i) a[i][0] = *reinterpret_cast<const bf16x8 *>(fa[st][0] + i * 3072);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if constexpr (B_TR) b[j][2] = read_bt(st, j, 2);
-            else b[j][2] = *reinterpret_cast<const bf16x8 *>(fb[st][2] + j * 3072);
-        }
+        for (int j = 0; j < NJ; ++j) b[j][2] = *reinterpret_cast<const bf16x8 *>(fb[st][2] + j * 3072);
     };
     constexpr int pa[6] = {1, 2, 1, 0, 0, 0};
     constexpr int pb[6] = {0, 0, 1, 0, 1, 2};
@@ -488,9 +416,6 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
         }
 }
 
-template __global__ void gemm_b3_kernel<false>(B3Args);
-template __global__ void gemm_b3_kernel<true>(B3Args);
-
 // ---- host side ------------------------------------------------------------------------------------
 int64_t b3_kpad(int64_t k) { return ceil_div(k, 2 * B3_BK) * (2 * B3_BK); }      // an even number of k tiles
 
@@ -571,15 +496,12 @@ int b3_dual_split(const B3Dual &d, hipStream_t st) {
 
 int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, const float *bias, float *c,
                      int64_t ldc, int64_t m, int64_t n, int64_t k, float *slabs, int64_t slab_bytes,
-                     hipStream_t st, int *deferred, bool b_rows_are_k) {
+                     hipStream_t st, int *deferred) {
     static DeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_b3_kernel<false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_b3_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, B3_STAGES * B3_BUF_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_b3_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, B3_STAGES * B3_BUF_BYTES_BT);
         if (e != hipSuccess) {
             set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
             return GIST_ELAUNCH;
@@ -590,15 +512,10 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
         set_error("%s: leading dimension of the output >= 2^21 elements on the bf16x3 path", name);
         return GIST_EINVAL;
     }
-    B3Args g{};
+    B3Args g;
     const int64_t kpad = b3_kpad(k);
     g.a = sa; g.lda = kpad; g.b = sb; g.ldb = kpad; g.bias = bias; g.c = c; g.ldc = ldc;
     g.m = (int)m; g.n = (int)n; g.kpad = (int)kpad;
-    g.kb_rows = (int)k;
-    if (b_rows_are_k) {      // b = the ROW form of an operand [k][n]: pitch kpad(n), read transposed
-        g.ldb = b3_kpad(n);
-        if (g.ldb * 6 * k >= (1LL << 32)) { set_error("%s: operand of 4 GiB or more on the transposed-read path", name); return GIST_EINVAL; }
-    }
     g.tiles_m = (int)ceil_div(m, B3_TM);
     g.tiles_n = (int)ceil_div(n, B3_TN);
     const int64_t n_kt = kpad / B3_BK;
@@ -609,12 +526,8 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
     g.split_stride = 0;
     if (splits > 1) { g.c = slabs; g.ldc = n; g.split_stride = m * n; g.bias = nullptr; }
     const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel (+ slab sum)
-    if (b_rows_are_k)
-        hipLaunchKernelGGL(gemm_b3_kernel<true>, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits),
-                           dim3(B3_THREADS), B3_STAGES * B3_BUF_BYTES_BT, st, g);
-    else
-        hipLaunchKernelGGL(gemm_b3_kernel<false>, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits),
-                           dim3(B3_THREADS), B3_STAGES * B3_BUF_BYTES, st, g);
+    hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits),
+                       dim3(B3_THREADS), B3_STAGES * B3_BUF_BYTES, st, g);
     int rc = launch_status(name);
     // deferred: the caller's consumer sums the slabs (slab s at slabs + s m n, in slab order); bias must be null
     if (deferred) *deferred = splits;
@@ -644,18 +557,9 @@ int b3_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda,
     };
     int rc = split(a_kc, a, lda, m, sa);
     if (rc != GIST_OK) return rc;
-    // B given as [k][n] (NN, TN): its ROW form (k rows of kpad(n)), read transposed by the kernel -- no transposed split
-    const bool bt = !b_kc && (int)tune(GIST_TUNE_B3_TR) == 2 && b3_kpad(n) * 6 * k < (1LL << 32) &&      // (measured 12 % slower: opt-in)
-                    k * b3_kpad(n) <= n * kpad;      // (the workspace was sized for [n][kpad(k)])
-    if (bt) {
-        B3Dual d{};
-        d.src = b; d.ld = ldb; d.rows = k; d.cols = n; d.dst_r = sb;
-        rc = b3_dual_split(d, st);
-    } else {
-        rc = split(b_kc, b, ldb, n, sb);
-    }
+    rc = split(b_kc, b, ldb, n, sb);
     if (rc != GIST_OK) return rc;
-    rc = b3_gemm_presplit(name, sa, sb, bias, c, ldc, m, n, k, slabs, b3_slab_bytes(m, n, k), st, nullptr, bt);
+    rc = b3_gemm_presplit(name, sa, sb, bias, c, ldc, m, n, k, slabs, b3_slab_bytes(m, n, k), st, nullptr);
     return rc == GIST_OK ? 1 : rc;
 }
 

@@ -254,8 +254,7 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
 #define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off) */
 #define GIST_TUNE_GEMM_DUAL 10    /* backward of a narrow hidden layer: 1 = dZ and dW as two launches (gist_gemm_nn_tn_dual_f32 off) */
-#define GIST_TUNE_B3_TR 11       /* bf16x3 GEMM with B given as [k][n]: 2 = B's row form read transposed (ds_read_b64_tr_b16 variant; measured slower, off) */
-#define GIST_TUNE_COUNT 12
+#define GIST_TUNE_COUNT 11
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
 

@@ -236,32 +236,3 @@ def test_bf16x3_split_k_equals_one_slice(hip, form, m, n, k):
     e_one = ((y_one[rows].double() - ref).abs() / den).max().item()
     assert e_auto <= max(1.5 * e_one, 4e-7), (e_auto, e_one)
     assert (y_auto - y_one).abs().max().item() <= 4e-6 * den.max().item()
-
-
-@pytest.mark.parametrize('m,n,k', [(2046, 1280, 1024), (700, 1024, 1000), (2046, 1204, 4096)])
-def test_b3_transposed_read_variant_is_bit_identical(m, n, k):
-    """gist_gemm_nn_f32 in mode bf16x3 with B's row-form split read transposed (ds_read_b64_tr_b16, tuning hook b3_tr = 2:
-    measured slower, opt-in) against the default (a transposed split of B): the same products in the same order."""
-    from gist_amd import hip
-    prev = hip.gemm_mode()
-    hip.gemm_mode('bf16x3')
-    try:
-        hip.tuning('h3_min_tiles', 1)
-        hip.tuning('h3_min_gflop', 0.5)
-        gen = torch.Generator(device='cuda:0').manual_seed(m + n)
-        a = torch.randn(m, k, device='cuda:0', generator=gen)
-        w = torch.randn(k, n, device='cuda:0', generator=gen)
-        outs = []
-        for knob in (0, 2):
-            hip.tuning('b3_tr', knob)
-            y = torch.empty(m, n, device='cuda:0')
-            hip.gemm_nn(a, w, y)
-            outs.append(y)
-        assert torch.equal(outs[0], outs[1])
-        ref = a.double() @ w.double()
-        assert (outs[1].double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
-    finally:
-        hip.tuning('b3_tr', 0)
-        hip.tuning('h3_min_tiles', 0)
-        hip.tuning('h3_min_gflop', 0)
-        hip.gemm_mode(prev)
