@@ -653,7 +653,10 @@ def main():
     hip.gemm_mode(args.gemm_mode)
     lr = 0.01
     native = engine.plan is not None
-    every = max(args.timing_every, 1) if native else 1
+    # HIP events around every SpMM / GEMM launch of a step cost that step ~80 us (the pairs serialise kernel boundaries):
+    # at most FIVE instrumented steps per timed region, at least --timing-every apart -- 0.2 % of `value` at H = 4096, under
+    # 1 % at the 0.3-ms steps of the narrow widths (10 instrumented steps of 150 were 1.8 % there)
+    every = max(args.timing_every, -(-args.steps // 5), 1) if native else 1
 
     state = dict(total_iter=0, epoch=0)
     sync_ms = []            # HIP-event time of every sync (+ re-dispatch) inside a timed region
@@ -675,7 +678,8 @@ def main():
                     ist_model.dispatch_model()
                 ist_model.sub.reset_optimizer()              # fresh Adam (:405-407)
             if native:      # HIP events around this step's SpMM/GEMM launches?
-                engine.plan.timer = sample_timer if (sample_timer is not None and s % every == 0) else None
+                # (instrumented steps sit in the MIDDLE of their stretch: the first step behind a fence is not a sample)
+                engine.plan.timer = sample_timer if (sample_timer is not None and s % every == every // 2) else None
             engine.train_step(b, lr, 0.0)
             if ids_log is not None:         # bookkeeping only: no device work in the timed region
                 ids_log.append(b.ids)
@@ -725,7 +729,7 @@ def main():
 
     def gemm_roofline(prof, elapsed, steps, mode):
         """`roofline` of the dominant kernel of a timed region run in GEMM mode `mode`."""
-        n_instr = len(range(0, steps, every))               # instrumented steps of the region
+        n_instr = len(range(every // 2, steps, every))      # instrumented steps of the region
         step_ms = elapsed * 1e3 / steps
         share = lambda ms: round(ms / (n_instr * step_ms), 4) if n_instr else None
         gem = prof['gemm']
