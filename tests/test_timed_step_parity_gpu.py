@@ -71,7 +71,7 @@ def _adam64(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     return p - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
 
 
-def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
+def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefetch=False):
     from gist_amd import hip
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
@@ -96,6 +96,7 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
             params.append((rs.uniform(-s, s, (o, 2 * i)).astype(np.float32),
                            rs.uniform(-s, s, o).astype(np.float32)))
         it.bind(eng)
+        eng.prefetch = prefetch                           # (what bench.py and the trainers run at the narrow widths)
         assert eng.plan is not None                       # native step driver (gist_sage_step)
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
                            g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
@@ -118,7 +119,15 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3'):
                 o_ += numel + (numel & 1)
             assert o_ == eng.drop_calls
             b = tg.batch(it.batch_ids(j))
-            assert np.array_equal(batch.rowptr.cpu().numpy(), b[0])
+            if prefetch and j + 1 < len(it):
+                # the batch buffers already hold the NEXT batch (extracted beside this step's optimiser launch):
+                # its induced CSR against the oracle's
+                assert it.batcher.prefetched is not None
+                nb = tg.batch(it.batch_ids(j + 1))
+                assert np.array_equal(it.batcher.rowptr[:len(nb[0])].cpu().numpy(), nb[0])
+                assert np.array_equal(it.batcher.col[:len(nb[1])].cpu().numpy(), nb[1])
+            else:
+                assert np.array_equal(batch.rowptr.cpu().numpy(), b[0])
             # the oracle's step, composed from its own parts (O.train_step's body) so that the ReLU decision of the
             # handful of LayerNorm outputs WITHIN ROUNDING OF ZERO can follow the GPU's: everywhere else the two
             # ReLU masks must agree, and the ambiguous elements are counted
@@ -193,10 +202,20 @@ def test_config3_timed_step_dropout_teacher_forced(hidden):
     assert len(rep) == 5
 
 
-def test_config2_timed_step_dropout_teacher_forced():
-    """BASELINE config 2: Reddit-like, hidden 256, 4 hidden layers (--config 2)."""
+@pytest.mark.parametrize('prefetch', [False, True])
+def test_config2_timed_step_dropout_teacher_forced(prefetch):
+    """BASELINE config 2: Reddit-like, hidden 256, 4 hidden layers (--config 2); with the next batch extracted inside
+    the optimiser's launch (what bench.py times at this width) and without."""
     from gist_amd import datasets
-    rep = _run(datasets.reddit_synth(seed=0), 20, 256, 4, 5, seed=4)
+    rep = _run(datasets.reddit_synth(seed=0), 20, 256, 4, 5, seed=4, prefetch=prefetch)
+    assert len(rep) == 5
+
+
+def test_config3_per_rank_width_with_prefetched_batches():
+    """Config 3's 8-GPU per-rank width (512) as bench.py times it: every batch but the first extracted beside the
+    previous step's optimiser launch."""
+    from gist_amd import datasets
+    rep = _run(datasets.reddit_synth(seed=0), 20, 512, 2, 5, seed=3, prefetch=True)
     assert len(rep) == 5
 
 
