@@ -164,8 +164,10 @@ md = ['# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
       'wave-cycles parked at s_waitcnt / s_barrier -- chains of dependent memory round trips, not bandwidth (fabric reads of 4-35 MB in '
       '7-20 us = 0.6-2 TB/s); the projections are issue-stalled on the matrix pipe (57-69 %) at an occupancy of 0.32-0.59 of the fp32 MFMA '
       'peak -- 128-1024 tiles of 64 x 64 are one to four rounds of one 32 x 32 MFMA tile per SIMD, and a launch has its ramp and tail whatever it '
-      'computes.', '']
-for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2')):
+      'computes.  Third table: the default workload (H = 4096) -- `gemm_b3_kernel` at 0.72-0.76 matrix-pipe occupancy, Adam 86 % parked on '
+      'memory (it IS the bandwidth: 634 MB of reads per launch), the split pre-pass issue-stalled for more than half of its wave-cycles '
+      '(it converts every element twice, once per layout it writes), extraction and block preparation pure latency.', '']
+for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2'), ('h4096', '(the default workload: H = 4096)')):
     f = os.path.join(F, 'pmc_sq_' + sub, 't_counter_collection.csv')
     if not os.path.exists(f):
         continue
