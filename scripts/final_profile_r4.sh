@@ -48,6 +48,7 @@ for sub in h512:--n-hidden:512 cfg2:--config:2 h4096:--n-hidden:4096; do
   tag=${sub%%:*}; rest=${sub#*:}; flag=${rest%%:*}; val=${rest#*:}
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_$tag -o t -- python3 $R/bench.py $flag $val --steps 20 --warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing > $O/pmc_sq_$tag.log 2>&1 || exit 1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$tag -o t -- python3 $R/bench.py $flag $val --steps 20 --warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing > $O/pmc_fetch_$tag.log 2>&1 || exit 1
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_lds_$tag -o t -- python3 $R/bench.py $flag $val --steps 20 --warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing > $O/pmc_lds_$tag.log 2>&1 || exit 1
 done
 echo sq pmc done
 fi

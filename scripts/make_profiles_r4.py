@@ -155,7 +155,7 @@ open(os.path.join(P, TAG + '_pmc_mfma.md'), 'w').write('\n'.join(md) + '\n')
 
 # 5. SQ counters of the narrow steps: what the small kernels wait for
 md = ['# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass) and '
-      '--pmc FETCH_SIZE (its own pass), `bench.py <config> --steps 20 --warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing`, round 4', '',
+      '--pmc FETCH_SIZE and --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (passes of their own), `bench.py <config> --steps 20 --warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing`, round 4', '',
       'Per kernel of the step, medians over its dispatches.  wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave-cycles parked at s_waitcnt / '
       's_barrier: memory latency and barriers), issue-stall share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, active share = SQ_ACTIVE_INST_ANY / '
       'SQ_WAVE_CYCLES; MFMA occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); fabric read = 2 x FETCH_SIZE (gfx950 '
@@ -183,8 +183,13 @@ for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2'), ('h4096', 
     if os.path.exists(ff):
         for r in csv.DictReader(open(ff)):
             fe[(short(r['Kernel_Name'])[:70], int(r['Grid_Size']) // int(r['Workgroup_Size']))].append(float(r['Counter_Value']))
-    md += ['## `bench.py %s`' % what, '', '| kernel | workgroups | dispatches | duration us (profiled) | wait share | issue-stall share | active share | MFMA occupancy | fabric read MB |',
-           '|---|---|---|---|---|---|---|---|---|']
+    ld = collections.defaultdict(lambda: collections.defaultdict(list))
+    fl = os.path.join(F, 'pmc_lds_' + sub, 't_counter_collection.csv')
+    if os.path.exists(fl):
+        for r in csv.DictReader(open(fl)):
+            ld[(short(r['Kernel_Name'])[:70], int(r['Grid_Size']) // int(r['Workgroup_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
+    md += ['## `bench.py %s`' % what, '', '| kernel | workgroups | dispatches | duration us (profiled) | wait share | issue-stall share | active share | MFMA occupancy | fabric read MB | LDS bank-conflict cycles / LDS active cycles |',
+           '|---|---|---|---|---|---|---|---|---|---|']
     med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
     for key in sorted(d, key=lambda k: -sum(dur[k])):
         if len(dur[key]) < 15:
@@ -192,10 +197,13 @@ for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2'), ('h4096', 
         c = {k: med(v) for k, v in d[key].items()}
         wc = max(c.get('SQ_WAVE_CYCLES', 0.0), 1.0)
         cyc = max(c.get('GRBM_GUI_ACTIVE', 0.0) / 8, 1.0)
-        md.append('| `%s` | %d | %d | %.1f | %.2f | %.2f | %.2f | %.3f | %.2f |' % (
+        la = med(ld[key].get('SQ_LDS_IDX_ACTIVE', []))
+        lc = med(ld[key].get('SQ_LDS_BANK_CONFLICT', []))
+        md.append('| `%s` | %d | %d | %.1f | %.2f | %.2f | %.2f | %.3f | %.2f | %s |' % (
             key[0] or '(anonymous namespace)', key[1], len(dur[key]), med(dur[key]), c.get('SQ_WAIT_ANY', 0) / wc,
             c.get('SQ_WAIT_INST_ANY', 0) / wc, c.get('SQ_ACTIVE_INST_ANY', 0) / wc,
-            c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cyc, 2 * med(fe.get(key, [0.0])) / 1024))
+            c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cyc, 2 * med(fe.get(key, [0.0])) / 1024,
+            ('%.3f' % (lc / la)) if la > 0 else '-'))
     md.append('')
 open(os.path.join(P, TAG + '_pmc_narrow_steps.md'), 'w').write('\n'.join(md) + '\n')
 print(open(os.path.join(P, TAG + '_pmc_mfma.md')).read())
