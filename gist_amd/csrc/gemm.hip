@@ -23,8 +23,8 @@
 //     dropped by the hardware range check.
 //
 // LDS images (MI355X_MICROARCH.md section LDS):
-//   k-contiguous operand  : [128 rows][32 k], no padding; the 16-byte chunk c of row r sits in
-//                           slot c ^ (r & 7) of its row (a DMA instruction's 1 KiB lands
+//   k-contiguous operand  : [128 rows][32 k] (or [64][64]), no padding; the 16-byte chunk c of row r sits in
+//                           slot c ^ (r & (chunks per row - 1)) of its row (a DMA instruction's 1 KiB lands
 //                           contiguously; 8 consecutive rows put the same k chunk into 8
 //                           different bank groups).  A lane reads ONE ds_read_b128 = 4
 //                           consecutive k of its row.  Lanes 0-31 take k = 8q..8q+3, lanes 32-63
@@ -165,7 +165,7 @@ __device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&s
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int r = t / CPR + (256 / CPR) * i;
-        *reinterpret_cast<float4 *>(s + r * BK + ((kq ^ (r & 7)) << 2)) = st[i];
+        *reinterpret_cast<float4 *>(s + r * BK + ((kq ^ (r & (CPR - 1))) << 2)) = st[i];
     }
 }
 
@@ -247,7 +247,7 @@ __device__ __forceinline__ void dma_offsets_kc(int64_t ld, int rows, int row0, i
         const int p = 64 * (IT * wave + jj) + lane;
         const int r = p / CPR, slot = p % CPR;
         const int dr = min(r, rows - 1 - row0);
-        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ (r & 7)) << 2)) * 4);
+        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ (r & (CPR - 1))) << 2)) * 4);
     }
 }
 
@@ -286,7 +286,10 @@ template <bool KC, int C, int BK>
 __device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int row, int q, int hh,
                                             const int (&kc_off)[4]) {
     if constexpr (KC) {
-        return *reinterpret_cast<const float4 *>(s + kc_off[q & 3] + (q >> 2) * 32);
+        // BK = 64: the XOR covers all 16 chunk slots of the 256-byte row, so the upper k half (q >= 4) of a row whose
+        // bit 3 is set sits in the LOWER 32 floats: kc_off holds the q < 4 offsets, the others are those ^ 32 floats
+        if constexpr (BK == 64) return *reinterpret_cast<const float4 *>(s + ((q >> 2) ? (kc_off[q & 3] ^ 32) : kc_off[q & 3]));
+        else return *reinterpret_cast<const float4 *>(s + kc_off[q & 3]);
     } else {
         const float *p = s + (8 * q + 4 * hh) * C + row;
         return make_float4(p[0], p[C], p[2 * C], p[3 * C]);
@@ -425,8 +428,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int block
         brow[i] = wn * W + i * 32 + r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            akc[i][q] = arow[i] * BK + ((((2 * q + hh) ^ (arow[i] & 7)) & 7) << 2);
-            bkc[i][q] = brow[i] * BK + ((((2 * q + hh) ^ (brow[i] & 7)) & 7) << 2);
+            akc[i][q] = arow[i] * BK + (((2 * q + hh) ^ (arow[i] & (BK / 4 - 1))) << 2);
+            bkc[i][q] = brow[i] * BK + (((2 * q + hh) ^ (brow[i] & (BK / 4 - 1))) << 2);
         }
         asm volatile("" : "+v"(arow[i]));
         asm volatile("" : "+v"(brow[i]));
