@@ -52,6 +52,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // MFMA tile) for outputs whose 128x128 tile count cannot fill / balance 256 CUs.
 // k depth of a tile: 32 for the 128x128 block, 64 for the 64x64 block (half the barriers
 // per flop where a SIMD holds a single wave and nothing hides them).
+// XOR applied to the 16-byte chunk index of row r of a k-contiguous image.  16 consecutive rows (the rows of a
+// ds_read_b128's lane groups) must land in 16 different 16-byte bank groups of the 256-byte bank space:
+//   BK = 64 (256-byte rows: every row covers the whole space)  : r & 15 over the row's 16 chunks;
+//   BK = 32 (128-byte rows: rows alternate between two halves) : (r >> 1) & 7 over its 8 chunks -- rows r and r + 1
+//                                                               share the XOR and differ in the half.
+// (r & 7 for both, as first written, put rows r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT = half of the LDS
+// cycles on the 64-tile kernel, 6 % of all cycles on the 128-tile one.)
+template <int BK> __device__ __forceinline__ constexpr int kc_swz(int r) { return BK == 64 ? (r & 15) : ((r >> 1) & 7); }
+
 template <int R, int BK> struct Img {   // R = rows of a k-contiguous image = columns of an m/n image
     // k-contiguous image: R rows of BK floats, no padding; the 16-byte chunk c of row r sits in
     // slot c ^ (r & 7) of the row (XOR swizzle: 8 consecutive rows put the same k chunk into 8
@@ -165,7 +174,7 @@ __device__ __forceinline__ void store_kc(float *__restrict__ s, const float4 (&s
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int r = t / CPR + (256 / CPR) * i;
-        *reinterpret_cast<float4 *>(s + r * BK + ((kq ^ (r & (CPR - 1))) << 2)) = st[i];
+        *reinterpret_cast<float4 *>(s + r * BK + ((kq ^ kc_swz<BK>(r)) << 2)) = st[i];
     }
 }
 
@@ -247,7 +256,7 @@ __device__ __forceinline__ void dma_offsets_kc(int64_t ld, int rows, int row0, i
         const int p = 64 * (IT * wave + jj) + lane;
         const int r = p / CPR, slot = p % CPR;
         const int dr = min(r, rows - 1 - row0);
-        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ (r & (CPR - 1))) << 2)) * 4);
+        off[jj] = (uint32_t)(((int64_t)dr * ld + ((slot ^ kc_swz<BK>(r)) << 2)) * 4);
     }
 }
 
@@ -428,8 +437,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int block
         brow[i] = wn * W + i * 32 + r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            akc[i][q] = arow[i] * BK + (((2 * q + hh) ^ (arow[i] & (BK / 4 - 1))) << 2);
-            bkc[i][q] = brow[i] * BK + (((2 * q + hh) ^ (brow[i] & (BK / 4 - 1))) << 2);
+            akc[i][q] = arow[i] * BK + (((2 * q + hh) ^ kc_swz<BK>(arow[i])) << 2);
+            bkc[i][q] = brow[i] * BK + (((2 * q + hh) ^ kc_swz<BK>(brow[i])) << 2);
         }
         asm volatile("" : "+v"(arow[i]));
         asm volatile("" : "+v"(brow[i]));
