@@ -307,16 +307,20 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     int32_t *rem_col = reinterpret_cast<int32_t *>(mf_smem + MF_REM_OFF);
     float *sc = reinterpret_cast<float *>(mf_smem + MF_SC_OFF);
 
-    // staging role of this thread: rows 8 wave + 4 half + i, columns 4 cq .. 4 cq + 3 of the tile
-    const int srow = 8 * wave + 4 * half;
+    // staging role of this thread: rows 8 wave + 4 sh + i, columns 4 scq .. 4 scq + 3 of the tile, with (scq, sh) =
+    // (lane >> 1, lane & 1): the 32 lanes of a ds_write_b64 group then write 16 slots x both 8-byte halves = 256
+    // contiguous bytes (with (lane & 31, lane >> 5) a group wrote one half of 32 slots: 16-byte stride, two lanes per
+    // bank pair and cycle -- SQ_LDS_BANK_CONFLICT 0.17 of the kernel's LDS cycles)
+    const int sh = lane & 1, scq = lane >> 1;
+    const int srow = 8 * wave + 4 * sh;
     float ss[4];
     float4 xv[4];
     int ct = grp;
     // (branch-free: a predicated load compiles to an exec-mask branch and a conservative s_waitcnt
     // vmcnt(0) at its join, which serialises the loads -- clamp the address, select when the value is used)
     auto load_tile = [&](int t) {
-        const bool cok = t * MF_CT + 4 * cq < a.d;
-        const float *px = a.x + (int64_t)xs0 * a.ldx + (cok ? t * MF_CT + 4 * cq : 0);
+        const bool cok = t * MF_CT + 4 * scq < a.d;
+        const float *px = a.x + (int64_t)xs0 * a.ldx + (cok ? t * MF_CT + 4 * scq : 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, nx - 1) * a.ldx);
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
         {   // rows (0, 1) and (2, 3) of a column are converted in pairs: one v_cvt_pk_bf16_f32 per
             // piece gives the packed word the image wants, its two halves shifted / masked back to fp32
             // give the residuals
-            const bool cok = ct * MF_CT + 4 * cq < a.d;
+            const bool cok = ct * MF_CT + 4 * scq < a.d;
             float xs[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
                         x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
                     }
                 }
-                unsigned char *dst = xt + (wave * MF_CHUNK_SLOTS + jj * 36 + cq) * 16 + half * 8;
+                unsigned char *dst = xt + (wave * MF_CHUNK_SLOTS + jj * 36 + scq) * 16 + sh * 8;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     *reinterpret_cast<uint2 *>(dst + q * MF_PIECE) = make_uint2(w[q][0], w[q][1]);
