@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class GistLibraryError(RuntimeError):
@@ -119,6 +119,7 @@ SIGNATURES = {
                                         _p]),
     'gist_sage_step': (_int, [_p, _p, _i64, _u64, _f, _f, _f, _f, _f, _i64, _int, _p]),
     'gist_sage_step_extracts_next': (_int, [_p, _i64, _int]),
+    'gist_extract_parts_desc_batch': (_int, [_p, _p]),
     'gist_adam_segments_extract_f32': (_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _i64, _p, _i64, _i64,
                                               _p, _p, _p]),
 }
@@ -158,7 +159,8 @@ class StepPlan(ctypes.Structure):
                 ('col_partials', _p), ('fused_workspace', _p), ('fused_workspace_bytes', _i64),
                 ('node_part', _p), ('part_slot', _p),
                 ('batch_index', _i32), ('extract_scratch', _p),
-                ('next_ids', _p), ('next_n', _i64), ('next_batch_index', _i32), ('next_drop_offset', _u64)]
+                ('next_ids', _p), ('next_n', _i64), ('next_batch_index', _i32), ('next_drop_offset', _u64),
+                ('feat_intra', _p), ('ld_feat_intra', _i64)]
 
 
 class ExtractPartsDesc(ctypes.Structure):
@@ -170,7 +172,7 @@ class ExtractPartsDesc(ctypes.Structure):
                 ('feat', _p), ('ld_feat', _i64), ('n_feat', _i64), ('z0', _p), ('ldz0', _i64),
                 ('labels_all', _p), ('labels', _p),
                 ('x0', _p), ('ldx0', _i64), ('p', _f), ('seed', _u64), ('offset', _u64), ('mask_ld', _i64),
-                ('scratch', _p)]
+                ('scratch', _p), ('feat_intra', _p), ('ld_intra', _i64), ('ah', _p)]
 
 
 class GradSegment(ctypes.Structure):

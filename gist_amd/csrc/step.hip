@@ -510,19 +510,30 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         }
     }
 
+    // layer 0's aggregation formed by the extraction (this call's, or the previous call's GIST_STEP_EXTRACT_NEXT)?
+    bool pre_ah = (flags & GIST_STEP_PREEXTRACTED) && p->feat_intra != nullptr;
     if (flags & GIST_STEP_EXTRACT) {
         GIST_REQUIRE(ids != nullptr, "gist_sage_step: null ids");
         const gist_layer_desc &l0 = p->layer[0];
         const bool by_parts = fuse && p->node_part && p->part_slot && p->extract_scratch && p->batch_index >= 0 && n <= p->n_max &&
                               gist_extract_parts_supported(p->n_max) == 1;
-        if (by_parts)
-            GIST_TRY(gist_extract_parts_batch(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n, p->n_max,
-                                              p->node_part, p->part_slot, p->batch_index, p->rowptr, p->col, p->t_rowptr, p->t_col,
-                                              p->col_capacity, p->norm, p->feat, p->ld_feat, l0.n_in, l0.Z,
-                                              l0.ldz, p->labels_all, p->labels,
-                                              fwd_fold[0] ? p->hsrc[0] : nullptr, p->ld_hsrc[0], p->p_drop,
-                                              p->seed, offs[0], 2 * l0.n_in, p->extract_scratch, s));
-        else if (fwd_fold[0])
+        if (by_parts) {
+            gist_extract_parts_desc x{};
+            x.g_rowptr = p->g_rowptr; x.g_col = p->g_col; x.g_t_rowptr = p->g_t_rowptr; x.g_t_col = p->g_t_col;
+            x.ids = ids; x.n = n; x.n_max = p->n_max;
+            x.node_part = p->node_part; x.part_slot = p->part_slot; x.batch = p->batch_index;
+            x.rowptr = p->rowptr; x.col = p->col; x.t_rowptr = p->t_rowptr; x.t_col = p->t_col;
+            x.col_capacity = p->col_capacity; x.norm = p->norm;
+            x.feat = p->feat; x.ld_feat = p->ld_feat; x.n_feat = l0.n_in; x.z0 = l0.Z; x.ldz0 = l0.ldz;
+            x.labels_all = p->labels_all; x.labels = p->labels;
+            x.x0 = fwd_fold[0] ? p->hsrc[0] : nullptr; x.ldx0 = p->ld_hsrc[0]; x.p = p->p_drop; x.seed = p->seed;
+            x.offset = offs[0]; x.mask_ld = 2 * l0.n_in; x.scratch = p->extract_scratch;
+            if (p->feat_intra != nullptr) {      // layer 0's aggregation comes with the extraction
+                x.feat_intra = p->feat_intra; x.ld_intra = p->ld_feat_intra; x.ah = l0.Z + l0.n_in;
+                pre_ah = true;
+            }
+            GIST_TRY(gist_extract_parts_desc_batch(&x, s));
+        } else if (fwd_fold[0])
             GIST_TRY(gist_extract_batch_drop(p->g_rowptr, p->g_col, p->g_t_rowptr, p->g_t_col, ids, n,
                                              p->remap, p->rowptr, p->col, p->t_rowptr, p->t_col,
                                              p->col_capacity, p->norm, p->feat, p->ld_feat, l0.n_in, l0.Z,
@@ -559,7 +570,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         const gist_layer_desc &l = p->layer[k];
         int y_slabs_n = 1;                   // > 1: this layer's pre-norm output is still split-K slabs
         const float *y_slabs = nullptr;
-        {
+        if (!(k == 0 && pre_ah)) {
             Scope sc(p->timer, 0, n, n, l.n_in, st);
             if (fwd_fold[k]) {      // source = the undropped input, store = dropout(ah)
                 SpmmDrop dr{};
@@ -880,6 +891,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         x.labels_all = p->labels_all; x.labels = p->labels;
         x.x0 = fold0 ? p->hsrc[0] : nullptr; x.ldx0 = p->ld_hsrc[0]; x.p = p->p_drop; x.seed = p->seed;
         x.offset = p->next_drop_offset; x.mask_ld = 2 * l0.n_in; x.scratch = p->extract_scratch;
+        if (p->feat_intra != nullptr) { x.feat_intra = p->feat_intra; x.ld_intra = p->ld_feat_intra; x.ah = l0.Z + l0.n_in; }
         GIST_TRY(gist_adam_segments_extract_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
                                                 beta2, eps, weight_decay, adam_step, segs, n_segs, p->row_loss, n, n,
                                                 p->loss, &x, s));

@@ -270,15 +270,21 @@ struct PartsArgs {
     float *z0; int64_t ldz0;
     const int32_t *labels_all; int32_t *labels;
     GatherDrop gd; int drop;
+    // layer 0's aggregation, formed here (NULL: not): ah[i] = norm[i] . (feat_intra[v] + sum of feat[u] over the kept
+    // in-neighbours u of v = ids[i] OUTSIDE v's part), feat_intra[v] = the sum over v's in-neighbours inside its part
+    const float *feat_intra; int64_t ld_intra;
+    float *ah;                       // row i at ah + i * ldz0
 };
 
 constexpr int kStash = 256;
+constexpr int kRemote = 64;          // outside-part neighbours of a row listed in LDS (more: the list is walked again)
 constexpr int kPartsWaves = 16;
 
 // workgroup (bx, by) of a (gx, 3) grid of 16-wave workgroups (extract_parts_kernel; adam_extract_kernel below runs
 // the same workgroups in one grid with the optimiser's)
 __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const int bx, const int by, const int gx) {
     __shared__ int32_t stash[kPartsWaves][kStash];
+    __shared__ int32_t remote[kPartsWaves][kRemote];     // global ids of a row's kept neighbours outside its part
     __shared__ int wcnt[kPartsWaves];
     __shared__ int wbase;
     __shared__ int s_tile;
@@ -337,22 +343,28 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
     const int2 *node_part = reinterpret_cast<const int2 *>(a.node_part);
     const int2 *part_slot = reinterpret_cast<const int2 *>(a.part_slot);
     const bool live = i < a.n;
-    int beg = 0, end = 0;
+    const bool agg = which == 0 && a.ah != nullptr;          // this pass also forms layer 0's aggregation of its row
+    int beg = 0, end = 0, v_self = 0, my_part = -1;
     if (live) {
-        const int v = a.ids[i];
-        beg = rowptr[v];
-        end = rowptr[v + 1];
+        v_self = a.ids[i];
+        beg = rowptr[v_self];
+        end = rowptr[v_self + 1];
+        if (agg) my_part = node_part[v_self].x;
     }
-    auto new_id = [&](int e, bool in) {                      // row of neighbour e in this batch, or -1
+    auto new_id = [&](int e, bool in, int &u, int &part) {   // row of neighbour e in this batch, or -1
+        u = -1; part = -1;
         if (!in) return -1;
-        const int2 np = node_part[col[e]];                   // (part, position in the part)
+        u = col[e];
+        const int2 np = node_part[u];                        // (part, position in the part)
         const int2 ps = part_slot[np.x];                     // (batch of the epoch, first row)
+        part = np.x;
         return ps.x == a.batch ? ps.y + np.y : -1;
     };
-    int cnt = 0;
+    int cnt = 0, n_remote = 0;
     for (int base = beg; base < end; base += 2 * kWave) {    // two chunks' loads in flight
         const int e0 = base + lane, e1 = e0 + kWave;
-        const int r0 = new_id(e0, e0 < end), r1 = new_id(e1, e1 < end);
+        int u0, u1, p0, p1;
+        const int r0 = new_id(e0, e0 < end, u0, p0), r1 = new_id(e1, e1 < end, u1, p1);
         const unsigned long long m0 = __ballot(r0 >= 0), m1 = __ballot(r1 >= 0);
         const unsigned long long below = (1ULL << lane) - 1ULL;
         if (r0 >= 0) {
@@ -365,7 +377,73 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
             if (pos < kStash) stash[wave][pos] = r1;
         }
         cnt += __popcll(m1);
+        if (agg) {                                           // kept neighbours outside the row's part, in edge order
+            const bool x0 = r0 >= 0 && p0 != my_part, x1 = r1 >= 0 && p1 != my_part;
+            const unsigned long long q0 = __ballot(x0), q1 = __ballot(x1);
+            if (x0) {
+                const int pos = n_remote + __popcll(q0 & below);
+                if (pos < kRemote) remote[wave][pos] = u0;
+            }
+            n_remote += __popcll(q0);
+            if (x1) {
+                const int pos = n_remote + __popcll(q1 & below);
+                if (pos < kRemote) remote[wave][pos] = u1;
+            }
+            n_remote += __popcll(q1);
+        }
     }
+    // layer 0's aggregation of this row: ah = norm . (the part's own contribution, summed once for the whole run, +
+    // the neighbours in the batch's OTHER parts).  Runs where the wave would otherwise wait: waves 1-15 between the
+    // two barriers below (while wave 0 walks the look-back), wave 0 after them
+    auto aggregate_row = [&]() {
+        if (!live) return;
+        const float nrm = cnt > 0 ? 1.f / (float)cnt : 0.f;
+        const float *__restrict__ pin = a.feat_intra + (int64_t)v_self * a.ld_intra;
+        float *__restrict__ o = a.ah + (int64_t)i * a.ldz0;
+        const uint64_t i0 = a.gd.offset + (uint64_t)i * (uint64_t)a.gd.mask_ld + (uint64_t)a.d;      // mask index of ah[i][0]
+        for (int c0 = 0; c0 < a.d; c0 += 4 * kWave) {
+            float acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = c0 + t * kWave + lane;
+                acc[t] = c < a.d ? pin[c] : 0.f;
+            }
+            if (n_remote <= kRemote) {
+                for (int k = 0; k < n_remote; ++k) {
+                    const float *__restrict__ xr = a.feat + (int64_t)remote[wave][k] * a.ld_feat;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int c = c0 + t * kWave + lane;
+                        if (c < a.d) acc[t] += xr[c];
+                    }
+                }
+            } else {                                         // a hub: its list again, in edge order
+                for (int base = beg; base < end; base += kWave) {
+                    int u, pt;
+                    const int r = new_id(base + lane, base + lane < end, u, pt);
+                    unsigned long long q = __ballot(r >= 0 && pt != my_part);
+                    while (q) {
+                        const int b = __builtin_ctzll(q);
+                        q &= q - 1;
+                        const float *__restrict__ xr = a.feat + (int64_t)__builtin_amdgcn_readlane(u, b) * a.ld_feat;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int c = c0 + t * kWave + lane;
+                            if (c < a.d) acc[t] += xr[c];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = c0 + t * kWave + lane;
+                if (c >= a.d) continue;
+                float val = acc[t] * nrm;
+                if (a.drop) val *= gather_keep(i0 + (uint64_t)c, a.gd);
+                o[c] = val;
+            }
+        }
+    };
     if (lane == 0) {
         wcnt[wave] = cnt;
         if (live && which == 0) a.norm[i] = cnt > 0 ? 1.f / (float)cnt : 0.f;
@@ -423,8 +501,11 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) wbase = part;
+    } else if (agg) {
+        aggregate_row();
     }
     __syncthreads();
+    if (agg && wave == 0) aggregate_row();
     int w = wbase;
     for (int k = 0; k < wave; ++k) w += wcnt[k];
     if (!live) return;
@@ -440,7 +521,8 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
         int64_t wp = w;
         for (int base = beg; base < end; base += kWave) {
             const int e = base + lane;
-            const int r = new_id(e, e < end);
+            int u_, p_;
+            const int r = new_id(e, e < end, u_, p_);
             const unsigned long long m = __ballot(r >= 0);
             if (r >= 0) {
                 const int64_t pos = wp + __popcll(m & ((1ULL << lane) - 1ULL));
@@ -818,8 +900,24 @@ static int parts_args(const char *name, const gist_extract_parts_desc &x, PartsA
         a.gd.x0 = x.x0; a.gd.ldx0 = x.ldx0; a.gd.p = x.p; a.gd.scale = x.p > 0.f ? 1.0f / (1.0f - x.p) : 1.f;
         a.gd.sm = x.seed * 0x9E3779B97F4A7C15ULL; a.gd.offset = x.offset; a.gd.mask_ld = x.mask_ld;
     }
+    if (x.ah != nullptr) {
+        GIST_REQUIRE(x.feat_intra != nullptr && x.ld_intra >= x.n_feat, "%s: bad feat_intra", name);
+        GIST_REQUIRE(x.x0 == nullptr || x.mask_ld >= 2 * x.n_feat, "%s: mask pitch below 2 n_feat with ah", name);
+        a.feat_intra = x.feat_intra; a.ld_intra = x.ld_intra; a.ah = x.ah;
+        a.gd.offset = x.offset; a.gd.mask_ld = x.mask_ld;
+    }
     *out = a;
     return GIST_OK;
+}
+
+extern "C" int gist_extract_parts_desc_batch(const gist_extract_parts_desc *desc, gist_stream_t stream) {
+    GIST_REQUIRE(desc != nullptr, "gist_extract_parts_desc_batch: null descriptor");
+    PartsArgs a;
+    const int rc = parts_args("gist_extract_parts_desc_batch", *desc, &a);
+    if (rc != GIST_OK) return rc;
+    hipLaunchKernelGGL(extract_parts_kernel, dim3((unsigned)ceil_div(desc->n, kPartsWaves), 3),
+                       dim3(64 * kPartsWaves), 0, as_stream(stream), a);
+    return launch_status("gist_extract_parts_desc_batch");
 }
 
 extern "C" int gist_extract_parts_batch(const int32_t *g_rowptr, const int32_t *g_col,

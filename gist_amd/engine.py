@@ -83,7 +83,7 @@ class ParamArena(object):
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
     __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
-                 'row_blocks', 'batcher', 'parts', 'z0_dropped', 'next_info')
+                 'row_blocks', 'batcher', 'parts', 'z0_dropped', 'next_info', 'ah_owner')
 
     def __init__(self):
         self.ready = True
@@ -96,6 +96,9 @@ class Batch(object):
         self.batcher = None         # set on lazy batches: who extracts them
         self.parts = None           # (node_part [N, 2], part_slot [parts, 2], batch index) -- sampler
         self.next_info = None       # (ids, batch index) of the batch that follows in the same epoch -- sampler
+        # the engine whose Z[0] right half already holds layer 0's aggregation of this batch (an eager extraction through
+        # gist_extract_parts_desc_batch with feat_intra); cleared by the first forward that drops Z[0] in place
+        self.ah_owner = None
 
 
 class ClusterBatcher(object):
@@ -120,6 +123,9 @@ class ClusterBatcher(object):
         self.t_col = torch.zeros(self.nnz_max, **i32)
         self.norm = torch.zeros(self.n_max, dtype=torch.float32, device=dev)
         self.lab = torch.zeros(self.n_max, **i32)
+        # per node the sum of its in-neighbours' features INSIDE its part (set by the iterator when the batches are
+        # unions of locality parts): the one-launch extraction then forms layer 0's aggregation itself
+        self.feat_intra = None
         # what a step's optimiser launch extracted into these buffers for the NEXT step (SageEngine.prefetch):
         # (part_slot table, batch index, rows, ids pointer, dropout offset) or None
         self.prefetched = None
@@ -258,6 +264,11 @@ class SageEngine(object):
         P.g_rowptr, P.g_col = g.rowptr.data_ptr(), g.col.data_ptr()
         P.g_t_rowptr, P.g_t_col = g.t_rowptr.data_ptr(), g.t_col.data_ptr()
         P.feat, P.ld_feat = batcher.feat.data_ptr(), batcher.feat.stride(0)
+        fi = getattr(batcher, 'feat_intra', None)
+        if fi is not None and self.fuse:
+            P.feat_intra, P.ld_feat_intra = fi.data_ptr(), fi.stride(0)
+        else:
+            P.feat_intra, P.ld_feat_intra = None, 0
         P.labels_all, P.remap = batcher.labels.data_ptr(), batcher.remap.data_ptr()
         P.rowptr, P.col = batcher.rowptr.data_ptr(), batcher.col.data_ptr()
         P.t_rowptr, P.t_col = batcher.t_rowptr.data_ptr(), batcher.t_col.data_ptr()
@@ -500,12 +511,29 @@ class SageEngine(object):
                 fold[k] = (self.H[k] is not None and (k > 0 or (_step and not b.ready)) and
                            hip.spmm_drop_takes(1, i, self.H[k][:n, :i], self.Z[k][:n, i:], blocked))
         self._fwd_fold = fold
+        self._pre_ah = False
         if not b.ready:
             if b.batcher is None:
                 raise RuntimeError('gist_amd: lazy batch without a batcher')
             i0 = self.dims[0][0]
             dr = (self.H[0][:n, :i0], self.p_drop, self.seed, offs[0], 2 * i0) if fold[0] else None
-            b.batcher.extract(b.ids, self.z0_left(n), drop=dr)
+            fi = getattr(b.batcher, 'feat_intra', None)
+            if (fi is not None and b.parts is not None and self.fuse and self.plan is not None and self.plan.feat_intra
+                    and hip._lib.load().gist_extract_parts_supported(self.n_max)):
+                # the native step's extraction: one launch that also forms layer 0's aggregation
+                # (gist_extract_parts_desc.feat_intra), which sums in its own order -- so the twin runs the same launch
+                bt = b.batcher
+                if self._extract_scratch is None:
+                    self._extract_scratch = torch.zeros(
+                        int(hip._lib.load().gist_extract_parts_scratch_bytes(self.n_max)) // 8 + 1,
+                        dtype=torch.int64, device=self.device)
+                bt.prefetched = None
+                hip.extract_parts(bt.g, b.ids, self.n_max, b.parts[0], b.parts[1], b.parts[2], bt.rowptr[:n + 1], bt.col,
+                                  bt.t_rowptr[:n + 1], bt.t_col, bt.norm, bt.feat, self.z0_left(n), bt.labels, bt.lab,
+                                  self._extract_scratch, drop=dr, feat_intra=fi, ah=self.Z[0][:n, i0:])
+                self._pre_ah = True
+            else:
+                b.batcher.extract(b.ids, self.z0_left(n), drop=dr)
             b.ready = True
             b.z0_dropped = dr is not None
         self._logit_slabs_n = 1
@@ -533,7 +561,11 @@ class SageEngine(object):
                 hip.spmm(b.rowptr, b.col, p_buf, self.Y[k][:n, :o], out_scale=b.norm,
                          accumulate=True)
                 continue
-            if fold[k]:      # source = the undropped input, store = dropout(ah)
+            if k == 0 and (self._pre_ah or b.ah_owner is self):      # ah (and its mask when folded) came with the extraction
+                if drop and not fold[0]:
+                    hip.dropout_(z, self.p_drop, self.seed, offs[k])
+                    b.ah_owner = None
+            elif fold[k]:      # source = the undropped input, store = dropout(ah)
                 hip.spmm_drop(b.rowptr, b.col, self.H[k][:n, :i], z[:, i:], 1, self.p_drop, self.seed,
                               offs[k] + i, 0, 2 * i, out_scale=b.norm, row_blocks=rb, prepared=pf)
             else:

@@ -757,6 +757,42 @@ def adam_segments_(param, grad, exp_avg, exp_avg_sq, step, lr, segments, row_los
     return param
 
 
+def extract_parts(g, ids, n_max, node_part, part_slot, batch_index, rowptr, col, t_rowptr, t_col, norm, feat, z0,
+                  labels_all, labels, scratch, drop=None, feat_intra=None, ah=None):
+    """gist_extract_parts_desc_batch: the one-launch extraction of a batch that is a union of parts.  z0: the [n, F]
+    left half of layer 0's [h | ah] buffer; drop = (x0, p, seed, offset, mask_ld) folds layer 0's dropout into the gather;
+    feat_intra + ah (the right half of the same buffer): layer 0's aggregation is formed too."""
+    import ctypes
+    L = _lib.load()
+    n = ids.numel()
+    x = _lib.ExtractPartsDesc()
+    x.g_rowptr, x.g_col = _vec(g.rowptr, 'g.rowptr', torch.int32), _vec(g.col, 'g.col', torch.int32)
+    x.g_t_rowptr, x.g_t_col = _vec(g.t_rowptr, 'g.t_rowptr', torch.int32), _vec(g.t_col, 'g.t_col', torch.int32)
+    x.ids, x.n, x.n_max = _vec(ids, 'ids', torch.int32), n, int(n_max)
+    x.node_part, x.part_slot, x.batch = node_part.data_ptr(), part_slot.data_ptr(), int(batch_index)
+    x.rowptr, x.col = _vec(rowptr, 'rowptr', torch.int32, n + 1), _vec(col, 'col', torch.int32)
+    x.t_rowptr, x.t_col = _vec(t_rowptr, 't_rowptr', torch.int32, n + 1), _vec(t_col, 't_col', torch.int32)
+    x.col_capacity, x.norm = col.numel(), _vec(norm, 'norm', torch.float32, n)
+    x.feat, x.ld_feat = _mat(feat, 'feat')
+    x.n_feat = feat.shape[1]
+    x.z0, x.ldz0 = _mat(z0, 'z0')
+    x.labels_all, x.labels = _opt(labels_all, 'labels_all', torch.int32), _opt(labels, 'labels', torch.int32, n)
+    if drop is not None:
+        x0, p, seed, offset, mask_ld = drop
+        x.x0, x.ldx0 = _mat(x0, 'x0')
+        x.p, x.seed, x.offset, x.mask_ld = float(p), int(seed), int(offset), int(mask_ld)
+    x.scratch = scratch.data_ptr()
+    if ah is not None:
+        if feat_intra is None or feat_intra.shape != feat.shape:
+            raise ValueError('gist_amd: extract_parts: ah needs feat_intra shaped like feat')
+        x.feat_intra, x.ld_intra = _mat(feat_intra, 'feat_intra')
+        ap, lda = _mat(ah, 'ah')
+        if lda != x.ldz0 or ah.shape[0] < n or ah.shape[1] != feat.shape[1]:
+            raise ValueError('gist_amd: extract_parts: ah must be the right half of z0\'s buffer')
+        x.ah = ap
+    _lib.check(L.gist_extract_parts_desc_batch(ctypes.byref(x), _stream()), 'gist_extract_parts_desc_batch')
+
+
 def extract_batch_drop(g, ids, remap, rowptr, col, t_rowptr, t_col, norm, feat, z0_left, labels_all, labels,
                        x0, p, seed, offset, mask_ld):
     """gist_extract_batch_drop: extraction whose feature gather writes dropout(feat) to z0 and feat to x0."""

@@ -204,9 +204,53 @@ class EngineClusterIter(ClusterIter):
         DESCRIBED here (ids slice) and extracted inside gist_sage_step."""
         self.engine = engine
         self.native = bool(native) and engine.arena.grads is not None
+        if getattr(self.batcher, 'feat_intra', None) is None and self._node_part is not None and self.locality \
+                and engine.fuse and os.environ.get('GIST_STEP_PREAGG', '1') != '0':
+            self.batcher.feat_intra = self._intra_part_sums()
         if self.native:
             self.native = engine.attach_batcher(self.batcher) is not None
         return self
+
+    def _extract_with_aggregation(self, ids, n):
+        from . import hip as _hip
+        from .engine import Batch
+        bt, eng = self.batcher, self.engine
+        L = _hip._lib.load()
+        if self._extract_scratch is None:
+            self._extract_scratch = torch.zeros(int(L.gist_extract_parts_scratch_bytes(self.n_max)) // 8 + 1,
+                                                dtype=torch.int64, device=bt.feat.device)
+        bt.prefetched = None
+        f = bt.feat.shape[1]
+        _hip.extract_parts(bt.g, ids, self.n_max, self._node_part, self._part_tables, self.n, bt.rowptr[:n + 1], bt.col,
+                           bt.t_rowptr[:n + 1], bt.t_col, bt.norm, bt.feat, eng.z0_left(n), bt.labels, bt.lab,
+                           self._extract_scratch, feat_intra=bt.feat_intra, ah=eng.Z[0][:n, f:2 * f])
+        b = Batch()
+        b.n, b.rowptr, b.col, b.t_rowptr, b.t_col = n, bt.rowptr[:n + 1], bt.col, bt.t_rowptr[:n + 1], bt.t_col
+        b.norm, b.labels, b.ids = bt.norm[:n], bt.lab[:n], ids
+        b.ah_owner = eng
+        return b
+
+    def _intra_part_sums(self):
+        """feat_intra[v] = sum of feat[u] over the in-neighbours u of v INSIDE v's part (train graph), once per run.
+        A batch is a union of whole parts, so this part of layer 0's aggregation is the same in every batch: the
+        one-launch extraction adds the few neighbours in the batch's other parts and the norm
+        (gist_extract_parts_desc.feat_intra, include/gist_hip.h)."""
+        tg = self.batcher.g
+        n = tg.number_of_nodes()
+        rp = tg.rowptr.to(torch.int64)
+        deg = rp[1:] - rp[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=tg.device), deg)
+        po = self._node_part[:, 0]
+        keep = po[rows] == po[tg.col.to(torch.int64)]
+        cnt = torch.zeros(n, dtype=torch.int64, device=tg.device)
+        cnt.index_add_(0, rows[keep], torch.ones_like(rows[keep]))
+        rp_f = torch.zeros(n + 1, dtype=torch.int64, device=tg.device)
+        rp_f[1:] = torch.cumsum(cnt, 0)
+        col_f = tg.col[keep].contiguous()                    # (CSR order kept: a boolean mask preserves it)
+        del rows, keep, cnt
+        out = torch.zeros_like(self.batcher.feat)
+        hip.spmm(rp_f.to(torch.int32), col_f, self.batcher.feat, out)
+        return out
 
     def fill_features(self, batch, engine):
         """Gather the current batch's features into ANOTHER engine's layer-0 buffer (several
@@ -296,6 +340,11 @@ class EngineClusterIter(ClusterIter):
             from . import hip as _hip
             if self.native and _hip._prof is None:
                 batch = self.batcher.lazy(ids)
+            elif (getattr(self.batcher, 'feat_intra', None) is not None and self._part_tables is not None
+                  and self.engine.fuse and self.engine.dims[0][0] == self.batcher.feat.shape[1]):
+                # the extraction the native step runs (one launch, layer 0's aggregation formed with it: it sums in its own
+                # order, so the op-by-op path takes the same launch)
+                batch = self._extract_with_aggregation(ids, b - a)
             else:
                 batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
             if self.locality is not False:       # (None: parts of unknown quality, e.g. overlapping: as before)

@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 12 */
+int gist_abi_version(void);   /* currently 13 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -547,7 +547,18 @@ typedef struct gist_extract_parts_desc {
     const int32_t *labels_all; int32_t *labels;
     float *x0; int64_t ldx0; float p; uint64_t seed, offset; int64_t mask_ld;
     void *scratch;
+    /* layer 0's aggregation formed by the extraction itself (ABI 13; ah == NULL: not).  A batch is a union of WHOLE parts,
+     * so the neighbours of a row inside its own part are the same in every batch: feat_intra[v] = sum of feat[u] over
+     * v's in-neighbours u in v's part, computed once per run (gist_spmm_csr_f32 on the intra-part edges); the pass that
+     * filters the row's in-edges adds the few kept neighbours in the batch's OTHER parts and writes
+     * ah[i] = norm[i] . (feat_intra[ids[i]] + sum of those) -- with the mask of mask index offset + i * mask_ld + n_feat + c
+     * when x0 != NULL -- to ah + i * ldz0.  Replaces the model's first g.update_all(copy_src, sum) * norm
+     * (modules.py:223-226) for the input features; sums in another (fixed) order than gist_spmm_csr_f32. */
+    const float *feat_intra; int64_t ld_intra;
+    float *ah;
 } gist_extract_parts_desc;
+/* gist_extract_parts_batch with its arguments as the structure (the only form that carries feat_intra / ah). */
+int gist_extract_parts_desc_batch(const gist_extract_parts_desc *desc, gist_stream_t stream);
 int gist_adam_segments_extract_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
                                    int64_t n, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, int64_t step,
@@ -700,6 +711,9 @@ typedef struct gist_step_plan {
     int64_t next_n;
     int32_t next_batch_index;
     uint64_t next_drop_offset;
+    /* the intra-part neighbour sums of the input features (gist_extract_parts_desc.feat_intra): when set, the one-launch
+     * extraction forms layer 0's aggregation and the step skips that launch */
+    const float *feat_intra; int64_t ld_feat_intra;
 } gist_step_plan;
 
 /* Bytes of fused_workspace / floats of col_partials the plan's shapes need.  Host functions. */

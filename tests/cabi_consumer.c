@@ -9,7 +9,7 @@
 int main(void) {
     gist_step_plan plan;
     memset(&plan, 0, sizeof plan);
-    if (gist_abi_version() != 12) return 1;
+    if (gist_abi_version() != 13) return 1;
     if (gist_gemm_workspace_bytes(2046, 41, 8192) <= 0) return 2;
     if (gist_colsum_partials(129) != 3) return 3;
     /* validation happens before any device work, so these are safe without a GPU */
@@ -42,7 +42,7 @@ int main(void) {
                         (void *)gist_spmm_prepared_useful, (void *)gist_spmm_block_units_f32,
                         (void *)gist_spmm_block_image_bytes, (void *)gist_gemm_dual_takes,
                         (void *)gist_gemm_nn_tn_dual_f32, (void *)gist_adam_segments_extract_f32,
-                        (void *)gist_sage_step_extracts_next};
+                        (void *)gist_sage_step_extracts_next, (void *)gist_extract_parts_desc_batch};
         size_t i;
         for (i = 0; i < sizeof syms / sizeof syms[0]; ++i)
             if (syms[i] == NULL) return 10;
