@@ -72,10 +72,15 @@ def variant(loc, first):
     ev = FullGraphEvaluator(ds.g, dims, True, arena, dev, node_blocks=False)      # one gather pass
     acc = ev.accuracy('val_mask')
     torch.cuda.synchronize()
+    ev.invalidate_input_aggregation()
     t0 = time.time()
     acc = ev.accuracy('val_mask')
     torch.cuda.synchronize()
-    out['eval_forward_H4096_one_pass_s'] = round(time.time() - t0, 4)
+    out['eval_forward_H4096_one_pass_first_s'] = round(time.time() - t0, 4)      # (aggregates the input features)
+    t0 = time.time()
+    acc = ev.accuracy('val_mask')
+    torch.cuda.synchronize()
+    out['eval_forward_H4096_one_pass_s'] = round(time.time() - t0, 4)           # (their aggregation kept: every later one)
     logits_one_pass = ev.forward().clone()
     del ev
     for tag, pme in (('diag_plus_gather', 0), ('diag_plus_pairs_plus_gather', args.pair_min_edges)):
@@ -85,11 +90,16 @@ def variant(loc, first):
         r = {'setup_s': round(time.time() - t0, 2)}
         acc2 = ev2.accuracy('val_mask')
         torch.cuda.synchronize()
+        ev2.invalidate_input_aggregation()
+        t0 = time.time()
+        acc2 = ev2.accuracy('val_mask')
+        torch.cuda.synchronize()
+        r['eval_forward_H4096_first_s'] = round(time.time() - t0, 4)      # (the run's first evaluation: aggregates the input features)
         t0 = time.time()
         acc2 = ev2.accuracy('val_mask')
         torch.cuda.synchronize()
         sp = ev2.split
-        r['eval_forward_H4096_s'] = round(time.time() - t0, 4)
+        r['eval_forward_H4096_s'] = round(time.time() - t0, 4)            # (every later one: that product is kept)
         r['edges'] = {'inside_blocks': sp['diag_edges'], 'dense_pairs': sp['pair_edges'], 'rest_gathered': sp['rest_edges'],
                       'n_pairs': sp['n_pairs']}
         r['max_abs_diff_logits_vs_one_pass'] = float((ev2.forward() - logits_one_pass).abs().max().item())

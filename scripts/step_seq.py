@@ -1,28 +1,29 @@
 #!/usr/bin/env python3
 """Dev tool: the kernel SEQUENCE of one training step from a rocprofv3 --kernel-trace CSV of bench.py: per launch
 (in stream order) name, grid, duration and the gap to the previous kernel's end -- medians over the traced steps.
-    python scripts/step_seq.py <kernel_trace.csv> [first_kernel_substring]
-A step starts at every launch whose name contains the substring (default: extract_parts_kernel)."""
+    python scripts/step_seq.py <kernel_trace.csv> [last_kernel_substring]
+A step ENDS with every launch whose name contains the substring (default: `adam_`, the optimiser launch -- with the next
+batch prefetched, `adam_extract_kernel`, there is no extraction launch at a step's start to look for)."""
 import csv
 import sys
 import collections
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-first = sys.argv[2] if len(sys.argv) > 2 else 'extract_parts_kernel'
+last = sys.argv[2] if len(sys.argv) > 2 else 'adam_'
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-steps, cur = [], None
+steps, cur = [], []
 for r in rows:
-    if first in r['Kernel_Name']:
-        if cur:
-            steps.append(cur)
+    cur.append(r)
+    if last in r['Kernel_Name']:
+        steps.append(cur)
         cur = []
-    if cur is not None:
-        cur.append(r)
+steps = steps[1:]                                       # (the first "step" carries the set-up launches)
 if not steps:
     sys.exit('no step found')
 lens = collections.Counter(len(s) for s in steps)
 L = lens.most_common(1)[0][0]
-steps = [s for s in steps if len(s) == L][5:]           # (skip the first few: warm-up)
+steps = [s for s in steps if len(s) == L]
+steps = steps[5:] if len(steps) > 10 else steps        # (skip the first few: warm-up)
 print('%d steps of %d launches' % (len(steps), L))
 tot_k = tot_g = 0.0
 for i in range(L):

@@ -539,6 +539,41 @@ def test_drop_in_evaluate_matches_engine_evaluator():
     assert not model.training                           # evaluate() put the model in eval mode
 
 
+@pytest.mark.parametrize('blocks', [None, False])
+def test_evaluator_keeps_input_aggregation(blocks):
+    """Layer 0 of the full-graph evaluation aggregates the input features -- the same product at every evaluation of a
+    run.  The evaluator keeps it after its first forward: logits of later forwards (parameters changed in between) are
+    bit for bit those of an evaluator that aggregates every time, and invalidate_input_aggregation() recomputes."""
+    from gist_amd import datasets
+    from gist_amd.trainer import FullGraphEvaluator
+    from gist_amd.engine import ParamArena, dims_for
+    ds = datasets.make_block_dataset('ev', 3000, 30, 132, 5, intra_deg=10, inter_deg=3, seed=5)
+    g = ds.g.to(DEV)                  # (one device copy: both evaluators see the same feature tensor)
+    dims = dims_for(132, 160, 5, 2)
+    arena = ParamArena(dims, DEV, with_grads=False)
+    gen = torch.Generator().manual_seed(2)
+    kept = FullGraphEvaluator(g, dims, True, arena, DEV, row_block=1100, node_blocks=blocks)
+    plain = FullGraphEvaluator(g, dims, True, arena, DEV, row_block=1100, node_blocks=blocks, cache_input_aggregation=False)
+    assert kept.cache_input_aggregation and not plain.cache_input_aggregation
+    assert (kept.split is not None) == (blocks is None) and kept.feat is plain.feat
+    for rnd in range(3):
+        for k, (i, o) in enumerate(dims):
+            arena.W[k].copy_((torch.rand(o, 2 * i, generator=gen) - 0.5) * (2.0 / np.sqrt(2 * i)))
+            arena.b[k].copy_((torch.rand(o, generator=gen) - 0.5) * 0.1)
+        a = kept.forward().clone()
+        assert kept._ah0_ready and plain._ah0 is None
+        assert torch.equal(a, plain.forward())
+        assert abs(kept.accuracy('val_mask') - plain.accuracy('val_mask')) == 0.0
+    # features changed in place: the kept product is stale until invalidated
+    kept.feat.mul_(1.5)
+    stale = kept.forward().clone()
+    fresh = plain.forward().clone()
+    assert not torch.equal(stale, fresh)
+    kept.invalidate_input_aggregation()
+    assert torch.equal(kept.forward(), fresh)
+    kept.feat.div_(1.5)
+
+
 def _steps_vs_oracle(ds, batch_parts, n_hidden, n_layers, n_steps, p_seed):
     """Run n_steps real training iterations (native step driver, dropout off) on the GPU and
     the same iterations with the CPU oracle on the same cluster batches; compare losses,
