@@ -382,11 +382,6 @@ extern "C" int gist_sage_step_extracts_next(const gist_step_plan *p, int64_t n, 
     // CU's wave slots for the ~20 us of its look-back chain -- 233 against 199 + 21 us at 38.8 M parameters, 32 against
     // 16 + 21 at 1.2 M; measured break-even between 3.3 M and 38.8 M)
     if (p->n_params > kPrefetchMaxParams) return 0;
-    // (with layer 0's aggregation formed by the extraction, the extraction is the long pole of the shared grid; on narrow
-    // features the gather it overlaps is too short to pay for that: F = 100, 0.3559 against 0.3497 ms per step of
-    // BASELINE config 4 with every batch extracted at the start of its own step; F = 602 keeps 11-13 us --
-    // profiles/r04_prefetch_side_stream.txt)
-    if (p->feat_intra != nullptr && p->layer[0].n_in < 256) return 0;
     return defer && next_parts_ok(p, fuse) ? 1 : 0;
 }
 

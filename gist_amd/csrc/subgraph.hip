@@ -280,6 +280,69 @@ constexpr int kStash = 256;
 constexpr int kRemote = 64;          // outside-part neighbours of a row listed in LDS (more: the list is walked again)
 constexpr int kPartsWaves = 16;
 
+// Layer 0's aggregation of one row by one wave, rows of at most NT * 64 <= 1024 features: every load of the row's
+// part-internal sum is issued before the first use, the neighbours outside the part are taken RB at a time with all their
+// loads in flight (a loop of load / add per neighbour and 256-column piece was a chain of 3 x (1 + n_remote) memory
+// latencies: +20 us on the kernel).  Loads are BUFFER loads: a row is a buffer of d floats (scalar descriptor), a lane's
+// offset one register for the whole row (4 * lane + an immediate per piece), columns past the row's end read as zero by
+// the hardware's range check -- no per-load address pairs, no clamping, straight-line code, and the kernel keeps the 64
+// registers that let two of these 1024-thread workgroups share a CU (with 64-bit addresses per load: 124).  Sums in edge
+// order.
+template <int NT, int RB>
+__device__ __forceinline__ void aggregate_row_regs(const PartsArgs &a, const int i, const int v_self, const int cnt,
+                                                   const int n_remote, const int32_t *rem, const int lane) {
+    const float nrm = cnt > 0 ? 1.f / (float)cnt : 0.f;
+    const int row_bytes = a.d * 4;
+    auto row = [&](const float *base, int64_t ld, int r) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + (int64_t)__builtin_amdgcn_readfirstlane(r) * ld, 0,
+                                                 row_bytes, 0x00020000);
+    };
+    const int voff = lane * 4;
+    float acc[NT];
+    {
+        const __amdgpu_buffer_rsrc_t rs = row(a.feat_intra, a.ld_intra, v_self);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t * 256, 0, 0));
+    }
+    int k = 0;
+    for (; k + RB <= n_remote; k += RB) {
+        float u[RB][NT];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const __amdgpu_buffer_rsrc_t rs = row(a.feat, a.ld_feat, rem[k + r]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                u[r][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t * 256, 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] += u[r][t];
+    }
+    if (RB > 1) {
+        for (; k < n_remote; ++k) {
+            const __amdgpu_buffer_rsrc_t rs = row(a.feat, a.ld_feat, rem[k]);
+            float u[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                u[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t * 256, 0, 0));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] += u[t];
+        }
+    }
+    float *__restrict__ o = a.ah + (int64_t)i * a.ldz0;
+    const uint64_t i0 = a.gd.offset + (uint64_t)i * (uint64_t)a.gd.mask_ld + (uint64_t)a.d;      // mask index of ah[i][0]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = t * kWave + lane;
+        if (c >= a.d) continue;
+        float val = acc[t] * nrm;
+        if (a.drop) val *= gather_keep(i0 + (uint64_t)c, a.gd);
+        o[c] = val;
+    }
+}
+
 // workgroup (bx, by) of a (gx, 3) grid of 16-wave workgroups (extract_parts_kernel; adam_extract_kernel below runs
 // the same workgroups in one grid with the optimiser's)
 __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const int bx, const int by, const int gx) {
@@ -397,6 +460,15 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
     // two barriers below (while wave 0 walks the look-back), wave 0 after them
     auto aggregate_row = [&]() {
         if (!live) return;
+        if (n_remote <= kRemote && a.d <= 16 * kWave) {      // (everything but hubs and very wide inputs)
+            const int nt = (a.d + kWave - 1) / kWave;
+            if (nt <= 2) aggregate_row_regs<2, 4>(a, i, v_self, cnt, n_remote, remote[wave], lane);
+            else if (nt <= 4) aggregate_row_regs<4, 4>(a, i, v_self, cnt, n_remote, remote[wave], lane);
+            else if (nt <= 8) aggregate_row_regs<8, 2>(a, i, v_self, cnt, n_remote, remote[wave], lane);
+            else if (nt <= 10) aggregate_row_regs<10, 2>(a, i, v_self, cnt, n_remote, remote[wave], lane);
+            else aggregate_row_regs<16, 1>(a, i, v_self, cnt, n_remote, remote[wave], lane);
+            return;
+        }
         const float nrm = cnt > 0 ? 1.f / (float)cnt : 0.f;
         const float *__restrict__ pin = a.feat_intra + (int64_t)v_self * a.ld_intra;
         float *__restrict__ o = a.ah + (int64_t)i * a.ldz0;
@@ -533,7 +605,7 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
     }
 }
 
-__global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsArgs a) {
+__global__ __launch_bounds__(64 * kPartsWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void extract_parts_kernel(PartsArgs a) {
     extract_parts_block(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
@@ -542,7 +614,7 @@ __global__ __launch_bounds__(64 * kPartsWaves) void extract_parts_kernel(PartsAr
 // extraction workgroups (dispatched first: their look-back chain is latency, 21 us for ~2000 rows) run beside the
 // optimiser's (memory), instead of in front of the next step's first aggregation.  1024-thread workgroups: an
 // optimiser workgroup runs four of adam_body.h's virtual blocks; the last workgroup reduces the loss.
-__global__ __launch_bounds__(64 * kPartsWaves) void adam_extract_kernel(PartsArgs a, int gx, AdamArgs A) {
+__global__ __launch_bounds__(64 * kPartsWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void adam_extract_kernel(PartsArgs a, int gx, AdamArgs A) {
     __shared__ float red[4];
     const int n_ex = 3 * gx;
     if ((int)blockIdx.x < n_ex) {
