@@ -989,18 +989,19 @@ def main():
                 bb = it.batcher.extract(ids, engine.z0_left(ids.numel()))
                 nnz[i] = int(bb.rowptr[bb.n].item())
             sp = prof['spmm']
-            per_step = 2 * len(dims) - 1                 # SpMM launches per instrumented step
+            # aggregation launches per instrumented step: 2 (L + 1) - 1, one fewer when layer 0's is formed by the extraction
+            per_step = max(len(sp) // max(len(range(0, args.steps, every)), 1), 1)
             s_ms = sum(ms for ms, _ in sp)
             s_bytes = 0.0
             for idx, (ms, (n, n_src, d)) in enumerate(sp):
-                z = int(nnz[min((idx // per_step) * every, args.steps - 1)])
+                z = int(nnz[min((idx // per_step) * every + every // 2, args.steps - 1)])      # (the sampled step's batch)
                 s_bytes += 4.0 * (n + 1) + 4.0 * z + 4.0 * n_src * d + 4.0 * n * d
             s_ach = s_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
             traffic, src = _traffic('spmm_traffic.json')
             copy_gbs = measured_copy_gbs(dev)
             n_instr = len(range(0, args.steps, every))
             out['roofline_spmm'] = {
-                'kernel': ('gist::spmm_csr_mfma_kernel (block-dense, wide layers)' if H // S >= 1536 else 'gist::spmm_csr_lds2_kernel (LDS gather, wide layers)') + '; gist::spmm_csr_rowsplit_kernel / spmm_csr_kernel for the F=%d input layer' % in_feats, 'bound': 'hbm', 'achieved': round(s_ach, 2),
+                'kernel': ('gist::spmm_csr_mfma_kernel (block-dense, wide layers)' if H // S >= 1536 else 'gist::spmm_csr_lds2_kernel (LDS gather, wide layers)') + ("; the F=%d input layer's aggregation is formed by the batch extraction (no launch)" % in_feats if engine.plan is not None and engine.plan.feat_intra else '; gist::spmm_csr_rowsplit_kernel / spmm_csr_kernel for the F=%d input layer' % in_feats), 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
                 # achievable HBM bandwidth on this box: a 1 GiB device-to-device copy (read+write)
                 'peak_measured_copy': round(copy_gbs, 1),
