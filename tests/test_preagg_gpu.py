@@ -53,7 +53,10 @@ def test_intra_part_sums_against_float64(hip):
 
 @pytest.mark.parametrize('kind,n_feats,batch,with_drop', [('toy', 50, 5, False), ('toy', 50, 5, True), ('toy', 301, 5, True),
                                                           ('toy', 64, 1, False), ('hubs', 16, 6, False),
-                                                          ('hubs', 260, 6, True)])
+                                                          ('hubs', 260, 6, True),
+                                                          ('toy', 640, 5, True),       # (the widest register form: 10 x 64)
+                                                          ('toy', 1000, 5, False),     # (16 x 64)
+                                                          ('toy', 1100, 5, True)])     # (rows beyond 1024 floats: the loop form)
 def test_extraction_forms_layer0_aggregation(hip, kind, n_feats, batch, with_drop):
     """ah of the extraction == norm . A . feat on the extracted CSR (1e-5), the rest of the extraction bit for bit; with
     layer 0's dropout folded in, [h | ah] is bit for bit gist_dropout_f32 of the undropped pair."""
