@@ -364,7 +364,7 @@ static int step_spmm(const gist_step_plan *p, const int32_t *rowptr, const int32
     return gist_spmm_csr_f32(rowptr, col, x, ldx, y, ldy, n, d, out_scale, src_scale, accumulate, s);
 }
 
-constexpr int64_t kPrefetchMaxParams = 6LL << 20;
+constexpr int64_t kPrefetchMaxParams = 12LL << 20;
 // can the next batch (plan->next_*) be extracted by gist_extract_parts_batch's kernel?
 static bool next_parts_ok(const gist_step_plan *p, bool fuse) {
     return fuse && p->node_part && p->part_slot && p->extract_scratch && p->next_ids && p->next_batch_index >= 0 &&
@@ -380,7 +380,8 @@ extern "C" int gist_sage_step_extracts_next(const gist_step_plan *p, int64_t n, 
                                                      : (aligned16(p->fused_workspace) && fl.bytes <= p->fused_workspace_bytes);
     // (beside a LARGE optimiser pass the extraction's 1024-thread workgroups cost more than they hide: each holds half a
     // CU's wave slots for the ~20 us of its look-back chain -- 233 against 199 + 21 us at 38.8 M parameters, 32 against
-    // 16 + 21 at 1.2 M; measured break-even between 3.3 M and 38.8 M)
+    // 16 + 21 at 1.2 M.  With the aggregating extraction's loads restructured the break-even is at ~11 M: H = 2048,
+    // 11.0 M parameters, 0.9788 / 0.9822 ms per step against 0.9807 / 0.9836 without; H = 4096, 38.8 M: +70 us)
     if (p->n_params > kPrefetchMaxParams) return 0;
     return defer && next_parts_ok(p, fuse) ? 1 : 0;
 }
