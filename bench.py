@@ -963,7 +963,14 @@ def main():
             'rccl_ranks': (dist.get_world_size() if world > 1 else 1),
             'rccl_devices_distinct': bool(devices_distinct),
             'rank_devices': idents,
+            'layer0_aggregation': ('formed by the batch extraction: a batch is a union of whole METIS parts, so the sum of the input '
+                                   'features over a row\'s in-neighbours INSIDE its own part is the same in every batch -- computed once per '
+                                   'run on the device (setup_seconds.intra_part_sums), the timed extraction adds the kept neighbours in the '
+                                   'batch\'s other parts and the in-degree norm; GIST_STEP_PREAGG=0 keeps it a launch of its own (+13 to +28 us '
+                                   'per step, profiles/r04_preagg.txt)') if (engine.plan is not None and engine.plan.feat_intra) else
+                                  'its own launch in every step',
             'setup_seconds': {'total_before_first_step': round(t_setup, 2), 'dataset': round(t_dataset, 2),
+                              'intra_part_sums': round(getattr(it, 'intra_part_sums_seconds', 0.0), 3),
                               'dataset_how': ('rank 0 %s the synthetic graph%s' % (
                                   dataset_how, '' if world == 1 else
                                   ' and wrote it to /dev/shm before any GPU call; the other %d ranks loaded it' % (world - 1)))},

@@ -206,7 +206,12 @@ class EngineClusterIter(ClusterIter):
         self.native = bool(native) and engine.arena.grads is not None
         if getattr(self.batcher, 'feat_intra', None) is None and self._node_part is not None and self.locality \
                 and engine.fuse and os.environ.get('GIST_STEP_PREAGG', '1') != '0':
+            import time
+            t0 = time.time()
             self.batcher.feat_intra = self._intra_part_sums()
+            if self.batcher.feat_intra.is_cuda:
+                torch.cuda.synchronize(self.batcher.feat_intra.device)
+            self.intra_part_sums_seconds = time.time() - t0      # (once per run; bench.py reports it with its set-up times)
         if self.native:
             self.native = engine.attach_batcher(self.batcher) is not None
         return self
