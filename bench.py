@@ -650,6 +650,8 @@ def main():
     it.bind(engine)                  # (the kept-split workspace is sized for either split mode)
     # the timed loop only reads the loss: let a step's optimiser launch extract the next batch of the epoch as well
     engine.prefetch = os.environ.get('GIST_BENCH_PREFETCH', '1') != '0'
+    if os.environ.get('GIST_BENCH_TUNE_CLASS_FUSED'):       # (A/B of the class layer's launch forms: include/gist_hip.h)
+        hip.tuning('class_fused', int(os.environ['GIST_BENCH_TUNE_CLASS_FUSED']))
     hip.gemm_mode(args.gemm_mode)
     lr = 0.01
     native = engine.plan is not None

@@ -104,6 +104,8 @@ SIGNATURES = {
                                     _p, _i64, _i64, _i64, _p]),
     'gist_class_dw_slab_bytes': (_i64, [_i64, _i64, _i64]),
     'gist_class_dw_slabs_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
+    'gist_ln_relu_bwd_colsum_class_dw_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p,
+                                                    _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p]),
     'gist_gemm_nn_dropout_colsum_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _u64, _u64,
                                                _p, _i64, _p, _p]),
     'gist_softmax_xent_slabs_f32': (_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64,

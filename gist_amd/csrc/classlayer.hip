@@ -19,6 +19,7 @@
 // class_dw_kernel: dW = dlogits^T . Z as split-K slabs over 128-row chunks (the optimiser sums them:
 // gist_adam_segments_f32), one 16-column tile per wave, all C classes.
 #include "common.h"
+#include "class_dw_body.h"
 
 namespace gist {
 namespace {
@@ -27,7 +28,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kRows = 16;        // rows per workgroup
 constexpr int kCpad = 48;        // classes padded to three 16-wide MFMA tiles
-constexpr int kDwRows = 128;     // rows per slab of class_dw_kernel
 
 struct ClassArgs {
     const float *z; int64_t ldz;
@@ -221,65 +221,8 @@ __global__ __launch_bounds__(256) void class_layer_kernel(ClassArgs a) {
     }
 }
 
-struct ClassDwArgs {
-    const float *dlog; int64_t ldg;
-    const float *z; int64_t ldz;
-    float *slabs;                     // [ceil(n / 128)][C][K]
-    int n_rows, n_classes, k;
-};
-
-// grid (K / 64, ceil(n / 128)): wave w of workgroup (x, y) owns columns [64 x + 16 w, +16) of slab y
-__global__ __launch_bounds__(256) void class_dw_kernel(ClassDwArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int C = a.n_classes, K = a.k;
-    const int n0 = blockIdx.x * 64 + wave * 16;
-    const int rb = blockIdx.y * kDwRows;
-    const int re = min(rb + kDwRows, a.n_rows);
-    int cls[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) cls[t] = min(16 * t + r, C - 1);
-    f32x4 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // eight k steps (32 rows) per chunk, the next chunk's 32 loads in flight under the current chunk's 24 MFMAs
-    constexpr int U = 8;
-    float bz[2][U], av[2][U][3];
-    auto load = [&](float (&bzz)[U], float (&avv)[U][3], int k0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = k0 + 4 * u + q;
-            const bool live = rr < re;
-            const int rc = live ? rr : re - 1;
-            const float zv = a.z[(int64_t)rc * a.ldz + n0 + r];
-            bzz[u] = live ? zv : 0.f;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) avv[u][t] = a.dlog[(int64_t)rc * a.ldg + cls[t]];
-        }
-    };
-    auto compute = [&](const float (&bzz)[U], const float (&avv)[U][3]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv[u][t], bzz[u], acc[t], 0, 0, 0);
-    };
-    const int n_chunks = (re - rb + 4 * U - 1) / (4 * U);
-    if (n_chunks > 0) load(bz[0], av[0], rb);
-    for (int c = 0; c < n_chunks; c += 2) {
-        if (c + 1 < n_chunks) load(bz[1], av[1], rb + (c + 1) * 4 * U);
-        compute(bz[0], av[0]);
-        if (c + 2 < n_chunks) load(bz[0], av[0], rb + (c + 2) * 4 * U);
-        if (c + 1 < n_chunks) compute(bz[1], av[1]);
-    }
-    float *slab = a.slabs + (int64_t)blockIdx.y * C * K;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = 16 * t + 4 * q + i;
-            if (c < C) slab[(int64_t)c * K + n0 + r] = acc[t][i];
-        }
-}
+// grid (K / 64, ceil(n / 128)): class_dw_body.h
+__global__ __launch_bounds__(256) void class_dw_kernel(ClassDwArgs a) { class_dw_block(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 }  // namespace
 
@@ -333,19 +276,33 @@ extern "C" int gist_class_layer_f32(const float *z, int64_t ldz, const float *w,
     return launch_status("gist_class_layer_f32");
 }
 
-extern "C" int gist_class_dw_slabs_f32(const float *d_logits, int64_t ldg, const float *z, int64_t ldz,
-                                       float *slabs, int64_t slab_bytes, int32_t *n_slabs, int64_t n_rows,
-                                       int64_t n_classes, int64_t k, gist_stream_t stream) {
-    GIST_REQUIRE(d_logits && z && slabs && n_slabs, "gist_class_dw_slabs_f32: null pointer");
+namespace gist {
+int class_dw_args(const char *name, const float *d_logits, int64_t ldg, const float *z, int64_t ldz, float *slabs,
+                  int64_t slab_bytes, int64_t n_rows, int64_t n_classes, int64_t k, ClassDwArgs *out, int32_t *n_slabs) {
+    GIST_REQUIRE(d_logits && z && slabs && n_slabs, "%s: null pointer", name);
     GIST_REQUIRE(n_rows > 0 && n_rows < (1LL << 31) - 256 && n_classes >= 1 && n_classes <= kCpad && k >= 64 &&
                      k % 64 == 0 && ldg >= n_classes && ldz >= k,
-                 "gist_class_dw_slabs_f32: bad shape");
+                 "%s: bad shape", name);
     const int64_t ns = class_dw_slabs(n_rows);
-    GIST_REQUIRE(slab_bytes >= ns * n_classes * k * 4, "gist_class_dw_slabs_f32: slab buffer too small");
+    GIST_REQUIRE(slab_bytes >= ns * n_classes * k * 4, "%s: slab buffer too small", name);
     ClassDwArgs a{};
     a.dlog = d_logits; a.ldg = ldg; a.z = z; a.ldz = ldz; a.slabs = slabs;
     a.n_rows = (int)n_rows; a.n_classes = (int)n_classes; a.k = (int)k;
-    hipLaunchKernelGGL(class_dw_kernel, dim3((unsigned)(k / 64), (unsigned)ns), dim3(256), 0, as_stream(stream), a);
+    *out = a;
     *n_slabs = (int32_t)ns;
+    return GIST_OK;
+}
+}  // namespace gist
+
+extern "C" int gist_class_dw_slabs_f32(const float *d_logits, int64_t ldg, const float *z, int64_t ldz,
+                                       float *slabs, int64_t slab_bytes, int32_t *n_slabs, int64_t n_rows,
+                                       int64_t n_classes, int64_t k, gist_stream_t stream) {
+    GIST_REQUIRE(n_slabs != nullptr, "gist_class_dw_slabs_f32: null n_slabs");
+    ClassDwArgs a{};
+    int32_t ns = 0;
+    const int rc = class_dw_args("gist_class_dw_slabs_f32", d_logits, ldg, z, ldz, slabs, slab_bytes, n_rows, n_classes, k, &a, &ns);
+    if (rc != GIST_OK) return rc;
+    hipLaunchKernelGGL(class_dw_kernel, dim3((unsigned)(k / 64), (unsigned)ns), dim3(256), 0, as_stream(stream), a);
+    *n_slabs = ns;
     return launch_status("gist_class_dw_slabs_f32");
 }

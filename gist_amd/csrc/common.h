@@ -181,6 +181,10 @@ int colsum_finish(const float *partials, int64_t chunks, int64_t d, float *out, 
 int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
                        float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
                        float *col_partials, hipStream_t st);
+struct ClassDwArgs;
+int ln_relu_bwd_colsum_class_dw(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                                float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                float *col_partials, const ClassDwArgs &dw, hipStream_t st);
 int gemm_nn_dropout_ex(const char *name, const float *g, int64_t ldg, const float *w, int64_t ldw, float *z,
                        int64_t ldz, int64_t m, int64_t n, int64_t k, float p, uint64_t seed, uint64_t offset,
                        void *workspace, int64_t workspace_bytes, float *dy_col_partials, hipStream_t st);

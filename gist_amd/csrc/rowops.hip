@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "class_dw_body.h"
 #include "adam_body.h"
 
 namespace gist {
@@ -378,13 +379,13 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(
 constexpr int kLnCsRows = 16;
 
 template <int U>
-__global__ __launch_bounds__(256) void ln_relu_bwd_cs_kernel(
+__device__ __forceinline__ void ln_relu_bwd_cs_block(
     const float *__restrict__ d_out, int64_t ldg, const float *yhat, int64_t ldy,
     const float *__restrict__ rstd_in, float *dy, int64_t lddy, int n_rows, int d, int use_lynorm,
-    int relu, float *__restrict__ col_partials) {
+    int relu, float *__restrict__ col_partials, const int bx) {
     __shared__ __attribute__((aligned(16))) float part[3][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * kLnCsRows;
+    const int r0 = bx * kLnCsRows;
     float4 gq[4][U], yq[4][U];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_cs_kernel(
     }
     __syncthreads();
     if (wave == 0) {
-        float *pr = col_partials + (int64_t)blockIdx.x * d;
+        float *pr = col_partials + (int64_t)bx * d;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = lane * 4 + 256 * u;
@@ -466,6 +467,35 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_cs_kernel(
         }
     }
 }
+
+template <int U>
+__global__ __launch_bounds__(256) void ln_relu_bwd_cs_kernel(
+    const float *__restrict__ d_out, int64_t ldg, const float *yhat, int64_t ldy,
+    const float *__restrict__ rstd_in, float *dy, int64_t lddy, int n_rows, int d, int use_lynorm,
+    int relu, float *__restrict__ col_partials) {
+    ln_relu_bwd_cs_block<U>(d_out, ldg, yhat, ldy, rstd_in, dy, lddy, n_rows, d, use_lynorm, relu, col_partials,
+                            (int)blockIdx.x);
+}
+
+// The same workgroups and, IN FRONT of them in the grid, those of the class layer's weight gradient
+// (class_dw_body.h: dW = dlogits^T . Z as 128-row slabs).  In the fused step the two are independent -- the slabs need
+// dlogits and the class layer's input, this backward the reverse aggregation of the class layer's dZ -- and each alone
+// fills a fraction of the chip for ~6 us (n / 16 = 128 workgroups here, K / 64 x n / 128 there): one launch instead of two.
+template <int U>
+__global__ __launch_bounds__(256) void ln_relu_bwd_cs_dw_kernel(
+    const float *__restrict__ d_out, int64_t ldg, const float *yhat, int64_t ldy,
+    const float *__restrict__ rstd_in, float *dy, int64_t lddy, int n_rows, int d, int use_lynorm,
+    int relu, float *__restrict__ col_partials, ClassDwArgs w, int n_dw, int dw_gx) {
+    const int b = (int)blockIdx.x;
+    if (b < n_dw) {
+        class_dw_block(w, b % dw_gx, b / dw_gx);
+        return;
+    }
+    ln_relu_bwd_cs_block<U>(d_out, ldg, yhat, ldy, rstd_in, dy, lddy, n_rows, d, use_lynorm, relu, col_partials,
+                            b - n_dw);
+}
+
+__global__ __launch_bounds__(256) void class_dw_only_kernel(ClassDwArgs a) { class_dw_block(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // column sums of g per 16-row chunk, in the order of the fused producers: INTERLEAVED (the LayerNorm
 // backward: rows r0 + w + 4 j summed over j for w = 0..3, then ((w0 + w1) + w2) + w3) or sequential (the
@@ -957,14 +987,20 @@ int colsum_rows16(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float 
 
 // ln_relu_bwd_ex + col_partials [ceil(n_rows / 16)][d]: one kernel when d <= 1024 and the rows are
 // 16-byte aligned, else the plain backward followed by the chunk sums of dy (same format, same order)
-int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
-                       float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
-                       float *col_partials, hipStream_t st) {
+static int ln_relu_bwd_colsum_impl(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                                   float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                   float *col_partials, const ClassDwArgs *dw, hipStream_t st) {
     GIST_REQUIRE(col_partials != nullptr, "gist_ln_relu_bwd_colsum_f32: null col_partials");
     const bool v4 = d % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && aligned16(d_out) &&
                     aligned16(yhat) && aligned16(dy) && aligned16(col_partials);
     if (!(v4 && d <= 1024 && n_rows > 0 && d > 0 && d_out && yhat && dy && (!use_lynorm || rstd) &&
           ldg >= d && ldy >= d && lddy >= d && n_rows < (1LL << 31) - 16)) {
+        if (dw != nullptr) {      // (no shared grid for this shape: the slabs as their own launch)
+            hipLaunchKernelGGL(class_dw_only_kernel, dim3((unsigned)(dw->k / 64), (unsigned)ceil_div(dw->n_rows, kDwRows)),
+                               dim3(256), 0, st, *dw);
+            const int rc0 = launch_status("gist_ln_relu_bwd_colsum_class_dw_f32");
+            if (rc0 != GIST_OK) return rc0;
+        }
         const int rc = ln_relu_bwd_ex(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu,
                                       nullptr, st);
         if (rc != GIST_OK) return rc;
@@ -972,6 +1008,20 @@ int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64
     }
     const unsigned grid = (unsigned)ceil_div(n_rows, kLnCsRows);
     const int U = (int)ceil_div(d, 256);
+    if (dw != nullptr) {
+        const int dw_gx = dw->k / 64, n_dw = dw_gx * (int)ceil_div(dw->n_rows, kDwRows);
+#define L(UU)                                                                                                        \
+    hipLaunchKernelGGL((ln_relu_bwd_cs_dw_kernel<UU>), dim3(grid + (unsigned)n_dw), dim3(256), 0, st, d_out, ldg, yhat, \
+                       ldy, rstd, dy, lddy, (int)n_rows, (int)d, use_lynorm, relu, col_partials, *dw, n_dw, dw_gx)
+        switch (U) {
+            case 1: L(1); break;
+            case 2: L(2); break;
+            case 3: L(3); break;
+            default: L(4); break;
+        }
+#undef L
+        return launch_status("gist_ln_relu_bwd_colsum_class_dw_f32");
+    }
 #define L(UU)                                                                                         \
     hipLaunchKernelGGL((ln_relu_bwd_cs_kernel<UU>), dim3(grid), dim3(256), 0, st, d_out, ldg, yhat, ldy, \
                        rstd, dy, lddy, (int)n_rows, (int)d, use_lynorm, relu, col_partials)
@@ -984,6 +1034,21 @@ int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64
 #undef L
     return launch_status("gist_ln_relu_bwd_colsum_f32");
 }
+
+int ln_relu_bwd_colsum(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                       float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                       float *col_partials, hipStream_t st) {
+    return ln_relu_bwd_colsum_impl(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu, col_partials,
+                                   nullptr, st);
+}
+
+// ln_relu_bwd_colsum with the class layer's weight-gradient slabs formed in the same launch (class_dw_body.h)
+int ln_relu_bwd_colsum_class_dw(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,
+                                float *dy, int64_t lddy, int64_t n_rows, int64_t d, int use_lynorm, int relu,
+                                float *col_partials, const ClassDwArgs &dw, hipStream_t st) {
+    return ln_relu_bwd_colsum_impl(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu, col_partials,
+                                   &dw, st);
+}
 }  // namespace gist
 
 extern "C" int gist_ln_relu_bwd_colsum_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
@@ -992,6 +1057,24 @@ extern "C" int gist_ln_relu_bwd_colsum_f32(const float *d_out, int64_t ldg, cons
                                            gist_stream_t stream) {
     return gist::ln_relu_bwd_colsum(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu,
                                     col_partials, gist::as_stream(stream));
+}
+
+extern "C" int gist_ln_relu_bwd_colsum_class_dw_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
+                                                    const float *rstd, float *dy, int64_t lddy, int64_t n_rows,
+                                                    int64_t d, int use_lynorm, int relu, float *col_partials,
+                                                    const float *d_logits, int64_t ld_dlogits, const float *z, int64_t ldz,
+                                                    float *slabs, int64_t slab_bytes, int32_t *n_slabs,
+                                                    int64_t n_rows_cls, int64_t n_classes, int64_t k,
+                                                    gist_stream_t stream) {
+    GIST_REQUIRE(n_slabs != nullptr, "gist_ln_relu_bwd_colsum_class_dw_f32: null n_slabs");
+    gist::ClassDwArgs w{};
+    int32_t ns = 0;
+    const int rc = gist::class_dw_args("gist_ln_relu_bwd_colsum_class_dw_f32", d_logits, ld_dlogits, z, ldz, slabs, slab_bytes,
+                                       n_rows_cls, n_classes, k, &w, &ns);
+    if (rc != GIST_OK) return rc;
+    *n_slabs = ns;
+    return gist::ln_relu_bwd_colsum_class_dw(d_out, ldg, yhat, ldy, rstd, dy, lddy, n_rows, d, use_lynorm, relu,
+                                             col_partials, w, gist::as_stream(stream));
 }
 
 extern "C" int gist_colsum_chunks_f32(const float *partials, int64_t chunks, int64_t d, float *out,

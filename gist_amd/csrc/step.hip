@@ -9,6 +9,7 @@
 #include <new>
 
 #include "common.h"
+#include "class_dw_body.h"
 
 using namespace gist;
 
@@ -686,6 +687,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         g.begin = l.db - p->grads; g.end = g.begin + l.n_out;
         g.src = fl.partials[k]; g.stride = l.n_out; g.n_src = (int32_t)chunks16;
     };
+    ClassDwArgs dw_args{};          // the class layer's weight-gradient slabs, deferred to the LayerNorm backward below it
+    bool dw_pending = false;
     for (int k = L1 - 1; k >= 0; --k) {
         const gist_layer_desc &l = p->layer[k];
         const float *dy;
@@ -697,8 +700,15 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         } else {
             const int64_t i_next = p->layer[k + 1].n_in;      // == l.n_out
             if (defer && plain[k]) {
-                GIST_TRY(ln_relu_bwd_colsum(p->dZ, 2 * i_next, l.Y, l.ldy, p->use_layernorm ? l.rstd : nullptr,
-                                            l.Y, l.ldy, n, l.n_out, p->use_layernorm, 1, fl.partials[k], st));
+                if (dw_pending) {      // ... with the class layer's weight-gradient slabs in the same grid
+                    GIST_TRY(ln_relu_bwd_colsum_class_dw(p->dZ, 2 * i_next, l.Y, l.ldy, p->use_layernorm ? l.rstd : nullptr,
+                                                         l.Y, l.ldy, n, l.n_out, p->use_layernorm, 1, fl.partials[k], dw_args,
+                                                         st));
+                    dw_pending = false;
+                } else {
+                    GIST_TRY(ln_relu_bwd_colsum(p->dZ, 2 * i_next, l.Y, l.ldy, p->use_layernorm ? l.rstd : nullptr,
+                                                l.Y, l.ldy, n, l.n_out, p->use_layernorm, 1, fl.partials[k], st));
+                }
                 db_done = true;
             } else {
                 GIST_TRY(ln_relu_bwd_ex(p->dZ, 2 * i_next, l.Y, l.ldy,
@@ -831,11 +841,22 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             db_done = db_done || chunk_db;
         }
         if (!dual_done) {
-            Scope sc(p->timer, 1, l.n_out, 2 * l.n_in, n, st);
+            // The class layer's weight-gradient slabs need dlogits and the layer's input only; the LayerNorm backward of
+            // the layer below (next iteration of this loop, behind the reverse aggregation) runs 128 workgroups for ~6 us:
+            // the slabs' workgroups go into ITS grid (ln_relu_bwd_cs_dw_kernel) -- one launch fewer per step
+            const bool dw_with_ln = cls_fused && k == L1 - 1 && L1 >= 2 && defer && plain[L1 - 2] &&
+                                    (int)tune(GIST_TUNE_CLASS_FUSED) != 2;
+            Scope sc(dw_with_ln ? nullptr : p->timer, 1, l.n_out, 2 * l.n_in, n, st);
             if (cls_fused && k == L1 - 1) {
                 int32_t ns = 1;
-                GIST_TRY(gist_class_dw_slabs_f32(dy, lddy, l.Z, l.ldz, fl.dw_slabs[k], fl.dw_bytes[k], &ns, n, l.n_out,
-                                                 2 * l.n_in, s));
+                if (dw_with_ln) {
+                    GIST_TRY(class_dw_args("gist_sage_step", dy, lddy, l.Z, l.ldz, fl.dw_slabs[k], fl.dw_bytes[k], n, l.n_out,
+                                           2 * l.n_in, &dw_args, &ns));
+                    dw_pending = true;
+                } else {
+                    GIST_TRY(gist_class_dw_slabs_f32(dy, lddy, l.Z, l.ldz, fl.dw_slabs[k], fl.dw_bytes[k], &ns, n, l.n_out,
+                                                     2 * l.n_in, s));
+                }
                 gist_grad_segment &g = segs[n_segs++];
                 g.begin = l.dW - p->grads; g.end = g.begin + l.n_out * 2 * l.n_in;
                 g.src = fl.dw_slabs[k]; g.stride = l.n_out * 2 * l.n_in; g.n_src = ns;
@@ -874,6 +895,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             }
         }
     }
+    GIST_REQUIRE(!dw_pending, "gist_sage_step: internal error (class-layer weight gradient not launched)");
     if (defer && (flags & GIST_STEP_EXTRACT_NEXT) && next_parts_ok(p, fuse) && p->n_params <= kPrefetchMaxParams) {
         // the optimiser and the NEXT batch's extraction in one grid: nothing reads the batch buffers any more.  Layer 0's
         // mask goes into the next batch's feature gather under the rule the next call applies to itself (fwd_fold[0])

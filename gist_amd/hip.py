@@ -724,6 +724,27 @@ def class_dw_slabs(d_logits, z, slabs):
     return int(ns.value)
 
 
+def ln_relu_bwd_colsum_class_dw(d_out, yhat, rstd, dy, use_lynorm, relu, col_partials, d_logits, z, slabs):
+    """gist_ln_relu_bwd_colsum_class_dw_f32: ln_relu_bwd_colsum and class_dw_slabs in one launch; returns the slab count."""
+    import ctypes
+    L = _lib.load()
+    gp, ldg = _mat(d_out, 'd_out')
+    yp, ldy = _mat(yhat, 'yhat')
+    dp, ldd = _mat(dy, 'dy')
+    n, d = yhat.shape
+    lp, ldl = _mat(d_logits, 'd_logits')
+    zp, ldz = _mat(z, 'z')
+    nc, c = d_logits.shape
+    k = z.shape[1]
+    ns = ctypes.c_int32(0)
+    _lib.check(L.gist_ln_relu_bwd_colsum_class_dw_f32(
+        gp, ldg, yp, ldy, _opt(rstd, 'rstd', torch.float32, n), dp, ldd, n, d, int(bool(use_lynorm)), int(bool(relu)),
+        _vec(col_partials, 'col_partials', torch.float32, L.gist_row_chunks16(n) * d),
+        lp, ldl, zp, ldz, slabs.data_ptr(), slabs.numel() * slabs.element_size(), ctypes.byref(ns), nc, c, k, _stream()),
+        'gist_ln_relu_bwd_colsum_class_dw_f32')
+    return int(ns.value)
+
+
 def softmax_xent_slabs(logits, slabs, n_slabs, bias, labels, mask, count, row_loss, loss, d_logits):
     L = _lib.load()
     lp, ldl = _mat(logits, 'logits')

@@ -252,7 +252,7 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_SPMM_SPLIT 6    /* row split of the LDS-staged SpMM (1..8)                    */
 #define GIST_TUNE_SPMM_KERNEL 7   /* blocked SpMM: 1 = LDS gather kernel, 2 = block-dense bf16x3 MFMA kernel, 3 = fp32 block-dense kernel at every width (prepared calls) */
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
-#define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off) */
+#define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off), 2 = its dW slabs as their own launch (not in the LayerNorm backward's grid) */
 #define GIST_TUNE_GEMM_DUAL 10    /* backward of a narrow hidden layer: 1 = dZ and dW as two launches (gist_gemm_nn_tn_dual_f32 off) */
 #define GIST_TUNE_COUNT 11
 int gist_tuning_set(int knob, double value);
@@ -303,6 +303,19 @@ int64_t gist_row_chunks16(int64_t n_rows);                                 /* ho
 int gist_ln_relu_bwd_colsum_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
                                 const float *rstd, float *dy, int64_t lddy, int64_t n_rows, int64_t d,
                                 int use_lynorm, int relu, float *col_partials, gist_stream_t stream);
+/* gist_ln_relu_bwd_colsum_f32 and gist_class_dw_slabs_f32 (below: the class layer's weight gradient as 128-row slabs of
+ * d_logits^T . z) in ONE launch: in a training step the two are independent -- the slabs need the class layer's dlogits
+ * and input, this backward the reverse aggregation of the class layer's dZ -- and each alone fills a fraction of the chip
+ * for ~6 us, so their workgroups share a grid (the slabs' first).  Same results bit for bit as the two calls; shapes the
+ * one-kernel backward does not take (d > 1024, unaligned rows) run the slabs as their own launch.  gist_sage_step uses it
+ * when the class layer is gist_class_layer_f32 and a hidden layer follows below (tuning hook GIST_TUNE_CLASS_FUSED = 2
+ * keeps the two launches). */
+int gist_ln_relu_bwd_colsum_class_dw_f32(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy,
+                                         const float *rstd, float *dy, int64_t lddy, int64_t n_rows, int64_t d,
+                                         int use_lynorm, int relu, float *col_partials,
+                                         const float *d_logits, int64_t ld_dlogits, const float *z, int64_t ldz,
+                                         float *slabs, int64_t slab_bytes, int32_t *n_slabs, int64_t n_rows_cls,
+                                         int64_t n_classes, int64_t k, gist_stream_t stream);
 /* out[j] = sum over chunks (in order) of partials[chunk][j]. */
 int gist_colsum_chunks_f32(const float *partials, int64_t chunks, int64_t d, float *out,
                            gist_stream_t stream);

@@ -42,7 +42,8 @@ int main(void) {
                         (void *)gist_spmm_prepared_useful, (void *)gist_spmm_block_units_f32,
                         (void *)gist_spmm_block_image_bytes, (void *)gist_gemm_dual_takes,
                         (void *)gist_gemm_nn_tn_dual_f32, (void *)gist_adam_segments_extract_f32,
-                        (void *)gist_sage_step_extracts_next, (void *)gist_extract_parts_desc_batch};
+                        (void *)gist_sage_step_extracts_next, (void *)gist_extract_parts_desc_batch,
+                        (void *)gist_ln_relu_bwd_colsum_class_dw_f32};
         size_t i;
         for (i = 0; i < sizeof syms / sizeof syms[0]; ++i)
             if (syms[i] == NULL) return 10;

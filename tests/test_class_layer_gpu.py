@@ -113,6 +113,41 @@ def test_class_dw_slabs_against_float64(hip, n, c, k):
     assert np.all(slabs[ns * c * k:].cpu().numpy() == 3.0)
 
 
+@pytest.mark.parametrize('n,d,c,k,use_ln', [(2046, 512, 41, 1024, True), (1140, 256, 47, 512, True), (333, 1024, 5, 64, False),
+                                             (2046, 1028, 41, 1024, True)])      # (d > 1024: no shared grid, two launches inside)
+def test_layernorm_backward_and_class_dw_in_one_launch(hip, n, d, c, k, use_ln):
+    """gist_ln_relu_bwd_colsum_class_dw_f32 (the LayerNorm backward of the layer below the class layer and the class layer's
+    weight-gradient slabs in one grid) == gist_ln_relu_bwd_colsum_f32 + gist_class_dw_slabs_f32, bit for bit: dy, the bias
+    gradient's chunk sums, every slab."""
+    from gist_amd import _lib
+    L = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(n + d)
+    d_out = torch.randn(n, 2 * d, device=DEV, generator=gen)
+    yhat = torch.randn(n, d, device=DEV, generator=gen)
+    rstd = torch.rand(n, device=DEV, generator=gen) + 0.5
+    dlog = torch.zeros(n, 48, device=DEV)
+    dlog[:, :c] = torch.randn(n, c, device=DEV, generator=gen) * 1e-3
+    z = torch.randn(n, k, device=DEV, generator=gen)
+    chunks = int(L.gist_row_chunks16(n))
+    n_slabs = (n + 127) // 128
+    outs = []
+    for fused in (False, True):
+        dy = torch.full((n, d), float('nan'), device=DEV)
+        part = torch.full((chunks * d,), float('nan'), device=DEV)
+        slabs = torch.full((n_slabs * c * k + 5,), 3.0, device=DEV)
+        if fused:
+            ns = hip.ln_relu_bwd_colsum_class_dw(d_out[:, :d], yhat, rstd if use_ln else None, dy, use_ln, True, part, dlog[:, :c],
+                                                 z, slabs)
+        else:
+            hip.ln_relu_bwd_colsum(d_out[:, :d], yhat, rstd if use_ln else None, dy, use_ln, True, part)
+            ns = hip.class_dw_slabs(dlog[:, :c], z, slabs)
+        assert ns == n_slabs
+        outs.append((dy, part, slabs))
+    for a, b in zip(*outs):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+    assert torch.all(outs[1][2][n_slabs * c * k:] == 3.0)
+
+
 @pytest.mark.parametrize('p_drop,n_layers,hidden', [(0.2, 2, 512), (0.0, 2, 512), (0.2, 4, 256), (0.2, 1, 512)])
 def test_step_with_fused_class_layer_equals_four_launch_sequence(hip, p_drop, n_layers, hidden):
     """gist_sage_step with the class layer as gist_class_layer_f32 + gist_class_dw_slabs_f32 (the default) against the
