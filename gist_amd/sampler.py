@@ -216,6 +216,14 @@ class EngineClusterIter(ClusterIter):
             self.native = engine.attach_batcher(self.batcher) is not None
         return self
 
+    def refresh_input_aggregation(self):
+        """Recompute the part-internal neighbour sums after the input features were changed IN PLACE (they are summed once,
+        at bind(): a run normally fixes its features -- scaler, --use-pp -- before it builds its iterator).  Same buffer, so
+        an attached engine's plan stays valid."""
+        fi = getattr(self.batcher, 'feat_intra', None)
+        if fi is not None:
+            fi.copy_(self._intra_part_sums())
+
     def _extract_with_aggregation(self, ids, n):
         from . import hip as _hip
         from .engine import Batch

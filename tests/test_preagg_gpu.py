@@ -157,3 +157,26 @@ def test_training_with_and_without_preaggregation(hip, monkeypatch, p_drop, n_la
     assert a0 - a1 == 4                                   # layer 0's aggregation launch is gone from every step
     assert max(abs(x - y) for x, y in zip(l1, l0)) <= 1e-5 * max(1.0, max(abs(y) for y in l0))
     assert (p1 - p0).abs().max().item() < 1e-4
+
+
+def test_refresh_after_features_changed_in_place(hip):
+    """The part-internal sums are formed once, at bind(); refresh_input_aggregation() re-forms them (same buffer) after an
+    in-place change of the features: the next extraction's ah follows the new features."""
+    from gist_amd.engine import SageEngine, dims_for
+    ds, it = _iter('toy', 64, 5)
+    eng = SageEngine(dims_for(64, 96, 6, 2), True, 0.0, it.n_max, DEV, seed=1)
+    it.bind(eng)
+    fi = it.batcher.feat_intra
+    assert fi is not None
+    before, ptr = fi.clone(), fi.data_ptr()
+    it.batcher.feat.mul_(2.0)
+    it.refresh_input_aggregation()
+    assert it.batcher.feat_intra.data_ptr() == ptr
+    assert torch.equal(it.batcher.feat_intra, before * 2.0)          # (a sum of doubled terms: exact)
+    b = next(iter(it))
+    eng.forward(b, training=False)
+    n, f = b.n, 64
+    want = torch.zeros(n, f, device=DEV)
+    hip.spmm(b.rowptr, b.col, eng.Z[0][:n, :f], want, out_scale=b.norm)
+    assert (eng.Z[0][:n, f:2 * f] - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    it.batcher.feat.mul_(0.5)
