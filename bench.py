@@ -82,6 +82,13 @@ def parse():
                     help='products of the large projections behind `value`: three bf16 pieces per fp32 '
                          'operand = all 24 bits, six cross terms (default), v_mfma_f32_32x32x2_f32, or the '
                          '3-term f16 split (22 bits)')
+    ap.add_argument('--host-path', choices=['engine', 'module'], default='engine',
+                    help='engine: one gist_sage_step call per iteration (SageEngine.train_step).  module: the reference\'s '
+                         'own loop body -- pred = model(cluster); loss = loss_f(pred[mask], labels[mask]); '
+                         'optimizer.zero_grad(); loss.backward(); optimizer.step() (cluster_gcn/cluster_gcn.py:96-105) -- on '
+                         'gist_amd.modules.GCN / nn.CrossEntropyLoss / optim.Adam / sampler.ClusterIter (N = 1 only)')
+    ap.add_argument('--no-module-leg', action='store_true',
+                    help='skip the module_path leg of the default N = 1 line')
     ap.add_argument('--no-second-leg', action='store_true',
                     help='N=1: skip re-timing the workload in the other GEMM mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -663,6 +670,79 @@ def main():
     state = dict(total_iter=0, epoch=0)
     sync_ms = []            # HIP-event time of every sync (+ re-dispatch) inside a timed region
 
+    # ---- the module path: the reference's loop body, statement for statement (cluster_gcn/cluster_gcn.py:89-105) ----
+    class ModuleLoop(object):
+        """model(cluster) / loss_f / zero_grad / backward / step on gist_amd's drop-in classes.  Same graph, parts,
+        batch size, model shape, initial parameters and dropout seed as the engine path's headline."""
+
+        def __init__(self):
+            import torch.nn.functional as F
+            from gist_amd.modules import GCN
+            from gist_amd.nn import CrossEntropyLoss
+            from gist_amd.optim import Adam
+            from gist_amd.sampler import ClusterIter
+            rstate = random.getstate()
+            self.cluster_iterator = ClusterIter(ds.name, g, psize, batch_size, train_nid, use_pp=False,
+                                                par_li=[p.copy() for p in ds.par_li], device=dev)
+            random.setstate(rstate)
+            self.model = GCN(in_feats, H, n_classes, L, F.relu, args.dropout, use_ln, False, False, 1, True)
+            rs_ = np.random.RandomState(seed)
+            for layer, (i, o) in zip(self.model.layers, dims):
+                stdv = 1.0 / np.sqrt(2 * i)
+                layer.linear.weight.data.copy_(torch.from_numpy(rs_.uniform(-stdv, stdv, (o, 2 * i)).astype(np.float32)))
+                layer.linear.bias.data.copy_(torch.from_numpy(rs_.uniform(-stdv, stdv, o).astype(np.float32)))
+            self.model.cuda()
+            self.model.set_dropout_seed(seed)
+            self.loss_f = CrossEntropyLoss()
+            self.optimizer = Adam(self.model.parameters(), lr=lr, weight_decay=0.0)
+            self.gen = self._batches()
+            self.engine = None
+
+        def _batches(self):
+            while True:
+                for cluster in self.cluster_iterator:
+                    yield cluster
+
+        def run(self, count, sample_timer=None, ids_log=None, n_log=None, loss_log=None, every_=1):
+            model, loss_f, optimizer = self.model, self.loss_f, self.optimizer
+            for s in range(count):
+                cluster = next(self.gen)
+                if self.engine is not None:
+                    self.engine.plan.timer = sample_timer if (sample_timer is not None and s % every_ == every_ // 2) else None
+                cluster = cluster.to(torch.cuda.current_device())
+                model.train()
+                pred = model(cluster)
+                batch_labels = cluster.ndata['label']
+                batch_train_mask = cluster.ndata['train_mask']
+                loss = loss_f(pred[batch_train_mask], batch_labels[batch_train_mask])
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                if self.engine is None:
+                    mes = getattr(model, '_module_engines', None)
+                    me = list(mes.values())[0] if mes else None
+                    if not me:
+                        raise RuntimeError('bench.py --host-path module: the model did not bind to the step plan')
+                    self.engine = me.engine
+                if ids_log is not None:
+                    ids_log.append(cluster._ids)
+                    n_log.append(cluster._n)
+                if loss_log is not None and (s == 0 or s == count - 1):
+                    loss_log.append(loss.detach().clone())
+
+    module_headline = args.host_path == 'module'
+    if module_headline and (world != 1 or ist_model is not None):
+        fail_line('--host-path module is the N = 1 loop (cluster_gcn.py)', 2)
+        os._exit(2)
+    mloop = None
+    if module_headline:
+        mloop = ModuleLoop()
+        mloop.run(1)                                   # (binds the model: its engine carries the timers from here on)
+        torch.cuda.synchronize(dev)
+        engine = mloop.engine
+        it = mloop.cluster_iterator
+        native = True
+
     def batches():
         while True:
             for b in it:
@@ -672,6 +752,8 @@ def main():
     gen = batches()
 
     def run_steps(count, sample_timer=None, ids_log=None, n_log=None, loss_log=None):
+        if module_headline:
+            return mloop.run(count, sample_timer, ids_log, n_log, loss_log, every)
         for s in range(count):
             b = next(gen)
             ti = state['total_iter']
@@ -893,6 +975,31 @@ def main():
         hip.gemm_mode(args.gemm_mode)
         engine.check_extract()
 
+    # ---- N=1: the same workload through the reference's own loop body (module path), same process ----------------
+    if world == 1 and ist_model is None and not module_headline and not args.no_module_leg:
+        try:
+            ml = ModuleLoop()
+            n_re = max(args.steps // 2, 10)
+            ml.run(max(min(args.warmup, 10), 3))
+            fence()
+            t0 = time.time()
+            ml.run(n_re)
+            fence()
+            e3 = time.time() - t0
+            ml.engine.check_extract()
+            legs['module_path'] = {
+                'value': round(n_re / STEPS_PER_EPOCH / e3, 4), 'unit': 'epochs/s', 'ms_per_step': round(e3 / n_re * 1e3, 4),
+                'steps': n_re, 'vs_engine_path_ms_per_step': round((e3 / n_re) / (elapsed / args.steps), 4),
+                'host_path': 'pred = model(cluster); loss = loss_f(pred[mask], labels[mask]); optimizer.zero_grad(); '
+                             'loss.backward(); optimizer.step() -- cluster_gcn/cluster_gcn.py:96-105 on gist_amd.modules.GCN, '
+                             'nn.CrossEntropyLoss, optim.Adam, sampler.ClusterIter: three gist_sage_step phase calls per '
+                             'iteration (gist::gcn_forward, gist::gcn_backward, the flat-arena Adam)',
+                'note': 'same process, same workload, timed after the headline run; not `value`'}
+            del ml
+        except Exception as e:                          # report, never fake
+            legs['module_path'] = {'value': None, 'error': repr(e)}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # every rank runs `steps` iterations of its own sub-GCN: S * steps / 75 epochs of work
@@ -984,7 +1091,9 @@ def main():
                          'rises to ~100), then trains: the default 150-step run goes 78 -> 4.6, 3000 steps '
                          'reach 2.8 (DESIGN.md section 5); a --steps 20 run sees only the transient',
             **({'INVALID': 'GIST_BENCH_SHARED_GPU validation run: ranks share one GPU, host-staged gloo'} if shared_gpu else {}),
-            'host_path': 'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',
+            'host_path': ('module path: the reference loop body on gist_amd.modules.GCN / nn.CrossEntropyLoss / optim.Adam / '
+                          'sampler.ClusterIter (three gist_sage_step phase calls per iteration)') if module_headline else
+                         'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',
         }
         if sync_info is not None:
             out['weight_sync'] = sync_info

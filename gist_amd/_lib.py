@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class GistLibraryError(RuntimeError):
@@ -112,6 +112,7 @@ SIGNATURES = {
                                            _i64, _p]),
     'gist_adam_segments_f32': (_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _i64, _p, _i64, _i64,
                                       _p, _p]),
+    'gist_grad_segments_finish_f32': (_int, [_p, _i64, _p, _i64, _p]),
     'gist_extract_batch_drop': (_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p,
                                        _i64, _p, _p, _p, _i64, _f, _u64, _u64, _i64, _p]),
     'gist_extract_parts_scratch_bytes': (_i64, [_i64]),
@@ -133,6 +134,10 @@ GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 GIST_STEP_EXTRACT_NEXT = 4
 GIST_STEP_PREEXTRACTED = 8
+GIST_STEP_PHASE_FORWARD = 16
+GIST_STEP_PHASE_BACKWARD = 32
+GIST_STEP_PHASE_OPTIMIZER = 64
+GIST_STEP_DLOGITS_GIVEN = 128
 
 
 class LayerDesc(ctypes.Structure):

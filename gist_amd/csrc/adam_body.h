@@ -28,6 +28,10 @@ struct AdamSegs {
     int n_src[kAdamMaxSegs];
     int ded_first[kAdamMaxSegs];      // first dedicated block of the segment (-1: inline)
     int n_ded;                         // dedicated blocks in total
+    // gist_grad_segments_finish_f32 (the sums WITHOUT the optimiser update): an inline segment's own arena chunks,
+    // fin_first[s] = its first block in that launch's grid (-1: dedicated), n_fin = such blocks in total
+    int fin_first[kAdamMaxSegs];
+    int n_fin;
     int64_t begin[kAdamMaxSegs], end[kAdamMaxSegs], stride[kAdamMaxSegs];
     const float *src[kAdamMaxSegs];
 };
@@ -88,8 +92,11 @@ __device__ __forceinline__ void adam_update(float *__restrict__ p, float *__rest
     p[i] = pv - step_size * (mv / denom);
 }
 
-// virtual block vb (arena chunks first, then the dedicated blocks), thread vt of its 256; no barrier inside
-__device__ __forceinline__ void adam_virtual_block(const AdamArgs &A, int64_t vb, int vt) {
+// virtual block vb (arena chunks first, then the dedicated blocks), thread vt of its 256; no barrier inside.
+// kUpdate = false (gist_grad_segments_finish_f32): the segment sums are formed and written to the gradient arena
+// in the same order, the optimiser update is left out; only_seg >= 0 restricts an arena chunk to that segment
+template <bool kUpdate = true>
+__device__ __forceinline__ void adam_virtual_block(const AdamArgs &A, int64_t vb, int vt, int only_seg = -1) {
     const AdamSegs &segs = A.segs;
     const int64_t n_chunks = adam_arena_blocks(A.n);
     if (vb >= n_chunks) {
@@ -112,7 +119,7 @@ __device__ __forceinline__ void adam_virtual_block(const AdamArgs &A, int64_t vb
         if (q == 0 && live) {
             const float gv = ((acc + a1) + a2) + a3;
             A.g[i] = gv;
-            adam_update(A.p, A.m, A.v, i, gv, A.beta1, A.beta2, A.eps, A.wd, A.step_size, A.inv_bc2_sqrt);
+            if (kUpdate) adam_update(A.p, A.m, A.v, i, gv, A.beta1, A.beta2, A.eps, A.wd, A.step_size, A.inv_bc2_sqrt);
         }
         return;
     }
@@ -120,7 +127,7 @@ __device__ __forceinline__ void adam_virtual_block(const AdamArgs &A, int64_t vb
     const int64_t hi = lo + 1024 < A.n ? lo + 1024 : A.n;
     unsigned touch = 0;                                   // uniform: segments intersecting [lo, hi)
     for (int s = 0; s < segs.n; ++s)
-        if (segs.begin[s] < hi && segs.end[s] > lo) touch |= 1u << s;
+        if (segs.begin[s] < hi && segs.end[s] > lo && (only_seg < 0 || s == only_seg)) touch |= 1u << s;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t i = lo + vt + 256 * u;
@@ -147,9 +154,10 @@ __device__ __forceinline__ void adam_virtual_block(const AdamArgs &A, int64_t vb
             gv = acc;
             A.g[i] = acc;
         } else {
+            if (!kUpdate) continue;
             gv = A.g[i];
         }
-        adam_update(A.p, A.m, A.v, i, gv, A.beta1, A.beta2, A.eps, A.wd, A.step_size, A.inv_bc2_sqrt);
+        if (kUpdate) adam_update(A.p, A.m, A.v, i, gv, A.beta1, A.beta2, A.eps, A.wd, A.step_size, A.inv_bc2_sqrt);
     }
 }
 

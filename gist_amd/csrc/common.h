@@ -194,6 +194,8 @@ int softmax_xent_ex(const char *name, float *logits, int64_t ldl, const float *s
                     int64_t n_classes, hipStream_t st);
 int colsum_rows16(const float *g, int64_t ldg, int64_t n_rows, int64_t d, float *partials, bool interleaved,
                   hipStream_t st);
+// loss[0] = sum(row_loss[0..n_rows)) / count, the reduction gist_adam_segments_f32 performs, as its own launch
+int loss_finish(const float *row_loss, int64_t n_rows, int64_t count, float *loss, hipStream_t st);
 
 // Tuning hooks (gist_tuning_set, include/gist_hip.h): explicit process-wide overrides of the
 // launchers' own choices, for sweeps and for tests that must reach both variants of a kernel.

@@ -826,6 +826,22 @@ __global__ __launch_bounds__(256) void adam_segments_kernel(AdamArgs A) {
     adam_virtual_block(A, blockIdx.x, threadIdx.x);
 }
 
+// The deferred gradient sums WITHOUT the optimiser (gist_grad_segments_finish_f32): the same device code with the update
+// left out.  Grid: the inline segments' own arena chunks, then the dedicated blocks.
+__global__ __launch_bounds__(256) void grad_finish_kernel(AdamArgs A) {
+    const int b = (int)blockIdx.x;
+    if (b >= A.segs.n_fin) {
+        adam_virtual_block<false>(A, adam_arena_blocks(A.n) + (b - A.segs.n_fin), threadIdx.x);
+        return;
+    }
+    int sg = -1;                                           // uniform: the inline segment this block serves
+    for (int s = 0; s < A.segs.n; ++s)
+        if (A.segs.fin_first[s] >= 0 && A.segs.fin_first[s] <= b && (sg < 0 || A.segs.fin_first[s] > A.segs.fin_first[sg]))
+            sg = s;
+    if (sg < 0) return;
+    adam_virtual_block<false>(A, A.segs.begin[sg] / 1024 + (b - A.segs.fin_first[sg]), threadIdx.x, sg);
+}
+
 // ---------------------------------------------------------------------------
 // accuracy: first-max argmax like numpy; integer atomics => deterministic
 // ---------------------------------------------------------------------------
@@ -1284,9 +1300,14 @@ int adam_segments_args(const char *name, float *param, float *grad, float *exp_a
         sg.n_src[sg.n] = q.n_src; sg.src[sg.n] = q.src;
         // many sources, few elements (a bias gradient in row chunks): dedicated blocks of 64 elements
         sg.ded_first[sg.n] = -1;
+        sg.fin_first[sg.n] = -1;
         if (q.n_src > 16 && q.end - q.begin <= 65536) {
             sg.ded_first[sg.n] = sg.n_ded;
             sg.n_ded += (int)ceil_div(q.end - q.begin, 64);
+        } else {      // (gist_grad_segments_finish_f32: the arena chunks this segment touches)
+            GIST_REQUIRE((q.end - 1) / 1024 - q.begin / 1024 + 1 + sg.n_fin < (1LL << 30), "%s: segment too large", name);
+            sg.fin_first[sg.n] = sg.n_fin;
+            sg.n_fin += (int)((q.end - 1) / 1024 - q.begin / 1024 + 1);
         }
         ++sg.n;
     }
@@ -1321,6 +1342,26 @@ extern "C" int gist_adam_segments_f32(float *param, float *grad, float *exp_avg,
     hipLaunchKernelGGL(gist::adam_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, gist::as_stream(stream), A);
     return gist::launch_status("gist_adam_segments_f32");
 }
+
+extern "C" int gist_grad_segments_finish_f32(float *grad, int64_t n, const gist_grad_segment *segments,
+                                             int64_t n_segments, gist_stream_t stream) {
+    gist::AdamArgs A;
+    const int rc = gist::adam_segments_args("gist_grad_segments_finish_f32", grad, grad, grad, grad, n, 0.f, 0.9f, 0.999f,
+                                            1e-8f, 0.f, 1, segments, n_segments, nullptr, 0, 0, nullptr, &A);
+    if (rc != GIST_OK) return rc;
+    const int64_t blocks = (int64_t)A.segs.n_fin + A.segs.n_ded;
+    if (blocks == 0) return GIST_OK;
+    hipLaunchKernelGGL(gist::grad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, gist::as_stream(stream), A);
+    return gist::launch_status("gist_grad_segments_finish_f32");
+}
+
+namespace gist {
+// loss = mean of row_loss[0..n): the reduction gist_adam_segments_f32 performs, as a launch of its own
+int loss_finish(const float *row_loss, int64_t n_rows, int64_t count, float *loss, hipStream_t st) {
+    hipLaunchKernelGGL(xent_loss_kernel, dim3(1), dim3(256), 0, st, row_loss, (int)n_rows, 1.0f / (float)count, loss);
+    return launch_status("gist_sage_step");
+}
+}  // namespace gist
 
 extern "C" int gist_argmax_correct_i32(const float *logits, int64_t ldl, const int32_t *labels,
                                        const uint8_t *mask, int32_t *correct, int64_t n_rows,

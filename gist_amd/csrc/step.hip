@@ -403,6 +403,21 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     ActiveTimer active(p->timer);
     const bool train = (flags & GIST_STEP_TRAIN) != 0;
     const bool drop = train && p->p_drop > 0.f;
+    // Phases (gist_hip.h, GIST_STEP_PHASE_*): a caller whose loop is `pred = model(g); loss = f(pred); loss.backward();
+    // optimizer.step()` issues the same iteration as three calls.  Every decision below is a function of (plan, n,
+    // drop_offset, flags without the phase bits), so the three calls agree on it.
+    const int phase_bits = flags & (GIST_STEP_PHASE_FORWARD | GIST_STEP_PHASE_BACKWARD | GIST_STEP_PHASE_OPTIMIZER);
+    GIST_REQUIRE(phase_bits == 0 || train, "gist_sage_step: GIST_STEP_PHASE_* belong to training steps");
+    GIST_REQUIRE(!(flags & GIST_STEP_DLOGITS_GIVEN) || phase_bits == GIST_STEP_PHASE_BACKWARD,
+                 "gist_sage_step: GIST_STEP_DLOGITS_GIVEN belongs to a GIST_STEP_PHASE_BACKWARD call");
+    const bool do_fwd = phase_bits == 0 || (phase_bits & GIST_STEP_PHASE_FORWARD);
+    const bool do_bwd = train && (phase_bits == 0 || (phase_bits & GIST_STEP_PHASE_BACKWARD));
+    const bool do_opt = train && (phase_bits == 0 || (phase_bits & GIST_STEP_PHASE_OPTIMIZER));
+    const bool split_phases = phase_bits != 0 && phase_bits != (GIST_STEP_PHASE_FORWARD | GIST_STEP_PHASE_BACKWARD |
+                                                                GIST_STEP_PHASE_OPTIMIZER);
+    GIST_REQUIRE(!split_phases || ((do_fwd ? 1 : 0) + (do_bwd ? 1 : 0) + (do_opt ? 1 : 0)) == 1,
+                 "gist_sage_step: one GIST_STEP_PHASE_* per call (or none / all three)");
+    const bool dlogits_given = (flags & GIST_STEP_DLOGITS_GIVEN) != 0;
     const bool blocked = p->row_blocks != nullptr && p->n_row_blocks > 0;
 
     // Split operands kept by the step (see gist_step_plan.h3_workspace); off = per-call splits
@@ -472,7 +487,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                             blocked ? p->row_blocks : nullptr);
     }
 
-    if (b3.any) {      // this step's weights, one read each
+    if (b3.any && do_fwd) {      // this step's weights, one read each
         Scope sc(p->timer, 3, 0, 0, 0, st);
         for (int k = 0; k < L1; ++k) {
             const B3Layer &hl = b3.layer[k];
@@ -485,7 +500,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             GIST_TRY(b3_dual_split(d, st));
         }
     }
-    if (h3.any) {      // this step's weights: rows split for Y = Z.W^T, transposed for dZ = dY.W
+    if (h3.any && do_fwd) {      // this step's weights: rows split for Y = Z.W^T, transposed for dZ = dY.W
         Scope sc(p->timer, 3, 0, 0, 0, st);
         bool zeroed = false;
         for (int k = 0; k < L1; ++k) {
@@ -514,7 +529,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
 
     // layer 0's aggregation formed by the extraction (this call's, or the previous call's GIST_STEP_EXTRACT_NEXT)?
     bool pre_ah = (flags & GIST_STEP_PREEXTRACTED) && p->feat_intra != nullptr;
-    if (flags & GIST_STEP_EXTRACT) {
+    if ((flags & GIST_STEP_EXTRACT) && do_fwd) {      // (pre_ah only matters to the forward loop)
         GIST_REQUIRE(ids != nullptr, "gist_sage_step: null ids");
         const gist_layer_desc &l0 = p->layer[0];
         const bool by_parts = fuse && p->node_part && p->part_slot && p->extract_scratch && p->batch_index >= 0 && n <= p->n_max &&
@@ -558,6 +573,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                                                p->layer[k].Z, p->layer[k].Z + p->layer[k].n_in);
         if (wide && p->spmm_prepared_bytes >= (train ? 2 : 1) * one) {
             char *base = static_cast<char *>(p->spmm_prepared);
+            if (do_fwd)
             GIST_TRY(launch_spmm_blocks_prepare(p->rowptr, p->col, train ? p->t_rowptr : nullptr,
                                                 train ? p->t_col : nullptr, n, p->row_blocks, p->n_row_blocks,
                                                 base, train ? base + one : nullptr, st));
@@ -568,7 +584,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
 
     // ---- forward (modules.py:310-314 / :218-237) ---------------------------------
     int logit_slabs = 0;           // > 1: the class layer's logits are still split-K slabs
-    for (int k = 0; k < L1; ++k) {
+    for (int k = 0; k < L1 && do_fwd; ++k) {
         const gist_layer_desc &l = p->layer[k];
         int y_slabs_n = 1;                   // > 1: this layer's pre-norm output is still split-K slabs
         const float *y_slabs = nullptr;
@@ -664,7 +680,8 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     const gist_layer_desc &last = p->layer[L1 - 1];
     // the optimiser kernel reduces the loss when it runs with deferred work anyway
     const bool loss_in_adam = train && defer;
-    if (cls_fused) {
+    if (!do_fwd) {
+    } else if (cls_fused) {
         Scope sc(p->timer, 1, n, (L1 > 1 ? 2 : 1) * last.n_out, 2 * last.n_in, st);
         GIST_TRY(gist_class_layer_f32(last.Z, last.ldz, last.W, 2 * last.n_in, last.b, p->labels, n, last.Y, last.ldy,
                                       p->dlogits, p->ldc, p->row_loss, L1 > 1 ? p->dZ : nullptr, 2 * last.n_in,
@@ -676,8 +693,13 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                              p->row_loss, loss_in_adam ? nullptr : p->loss, p->dlogits, p->ldc, n,
                              last.n_out, st));
     if (!train) return GIST_OK;
+    // a forward-phase call leaves the loss complete: its optimiser launch is another call
+    if (do_fwd && split_phases && loss_in_adam) GIST_TRY(loss_finish(p->row_loss, n, n, p->loss, st));
 
     // ---- backward --------------------------------------------
+    // GIST_STEP_DLOGITS_GIVEN: plan->dlogits was written by the caller (any loss on the logits): the class layer's dZ and
+    // bias chunk sums of the fused forward belong to ANOTHER dlogits and are recomputed from the given one
+    const bool cls_dz_done = cls_fused && !dlogits_given;
     gist_grad_segment segs[2 * GIST_MAX_LAYERS];
     int n_segs = 0;
     const int64_t chunks16 = gist_row_chunks16(n);
@@ -689,7 +711,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     };
     ClassDwArgs dw_args{};          // the class layer's weight-gradient slabs, deferred to the LayerNorm backward below it
     bool dw_pending = false;
-    for (int k = L1 - 1; k >= 0; --k) {
+    for (int k = L1 - 1; k >= 0 && do_bwd; --k) {
         const gist_layer_desc &l = p->layer[k];
         const float *dy;
         int64_t lddy;
@@ -837,7 +859,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
             dual_done = true;
         }
         if (dual_done) {
-        } else if (cls_fused && k == L1 - 1) {
+        } else if (cls_dz_done && k == L1 - 1) {
             db_done = true;      // (dZ and the bias chunks came with the loss)
         } else if (k > 0) {      // dZ with its dropout mask (or the mask left to the reverse aggregation)
             Scope sc(p->timer, 1, n, 2 * l.n_in, l.n_out, st);
@@ -904,6 +926,15 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         }
     }
     GIST_REQUIRE(!dw_pending, "gist_sage_step: internal error (class-layer weight gradient not launched)");
+    if (do_bwd && !do_opt) {
+        // the gradient arena complete on return (p.grad is read by the caller's optimiser, possibly by its own code first):
+        // the deferred sums in the optimiser's order, without the update
+        if (defer && n_segs > 0) GIST_TRY(gist_grad_segments_finish_f32(p->grads, p->n_params, segs, n_segs, s));
+        return GIST_OK;
+    }
+    if (!do_opt) return GIST_OK;
+    if (!do_bwd) n_segs = 0;      // (an optimiser-phase call: the backward-phase call finished the gradients)
+    const float *opt_row_loss = do_bwd || !split_phases ? p->row_loss : nullptr;      // (and the forward-phase call the loss)
     if (defer && (flags & GIST_STEP_EXTRACT_NEXT) && next_parts_ok(p, fuse) && p->n_params <= kPrefetchMaxParams) {
         // the optimiser and the NEXT batch's extraction in one grid: nothing reads the batch buffers any more.  Layer 0's
         // mask goes into the next batch's feature gather under the rule the next call applies to itself (fwd_fold[0])
@@ -924,11 +955,11 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         x.offset = p->next_drop_offset; x.mask_ld = 2 * l0.n_in; x.scratch = p->extract_scratch;
         if (p->feat_intra != nullptr) { x.feat_intra = p->feat_intra; x.ld_intra = p->ld_feat_intra; x.ah = l0.Z + l0.n_in; }
         GIST_TRY(gist_adam_segments_extract_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
-                                                beta2, eps, weight_decay, adam_step, segs, n_segs, p->row_loss, n, n,
+                                                beta2, eps, weight_decay, adam_step, segs, n_segs, opt_row_loss, n, n,
                                                 p->loss, &x, s));
     } else if (defer)
         GIST_TRY(gist_adam_segments_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,
-                                        beta2, eps, weight_decay, adam_step, segs, n_segs, p->row_loss, n, n,
+                                        beta2, eps, weight_decay, adam_step, segs, n_segs, opt_row_loss, n, n,
                                         p->loss, s));
     else
         GIST_TRY(gist_adam_f32(p->params, p->grads, p->exp_avg, p->exp_avg_sq, p->n_params, lr, beta1,

@@ -373,19 +373,43 @@ class SageEngine(object):
             out.append((ms.value, kind.value, m.value, n.value, k.value))
         return out
 
-    def _native_step(self, b, lr, weight_decay, train, betas=(0.9, 0.999), eps=1e-8):
+    def _native_step(self, b, lr, weight_decay, train, betas=(0.9, 0.999), eps=1e-8, phase=0, given=False,
+                     adam_step=None):
+        """One gist_sage_step call.  phase = 0: the whole iteration; GIST_STEP_PHASE_FORWARD / _BACKWARD / _OPTIMIZER: one
+        third of it (the module path: GCN.forward, loss.backward(), optimizer.step()); the backward and optimiser calls
+        reuse the forward call's batch, dropout offset and flags.  given: the caller wrote its own dlogits."""
         import ctypes
         from . import _lib
         L = _lib.load()
+        P = self.plan
+        if phase in (_lib.GIST_STEP_PHASE_BACKWARD, _lib.GIST_STEP_PHASE_OPTIMIZER):
+            cb, off, flags, ids_ptr = self._phase_ctx
+            if cb is not b:
+                raise RuntimeError('gist_amd: backward / optimiser phase of a batch that is not the last one forwarded')
+            batcher = b.batcher
+            nxt = None
+            if phase == _lib.GIST_STEP_PHASE_OPTIMIZER:
+                nxt, flags = self._plan_next(b, batcher, flags)
+                self.arena.step += 1
+            elif given:
+                flags |= _lib.GIST_STEP_DLOGITS_GIVEN
+            rc = L.gist_sage_step(ctypes.byref(P), ids_ptr, b.n, off, lr, betas[0], betas[1], eps, weight_decay,
+                                  max(adam_step if adam_step is not None else self.arena.step, 1), flags | phase,
+                                  hip._stream())
+            _lib.check(rc, 'gist_sage_step')
+            if phase == _lib.GIST_STEP_PHASE_OPTIMIZER and batcher is not None:
+                batcher.prefetched = nxt
+            return self.loss
         off = self.drop_calls
         ids_ptr = b.ids.data_ptr() if b.ids is not None else None
-        # was this batch extracted beside the previous step's optimiser launch (self.prefetch)?
+        # was this batch extracted beside the previous step's optimiser launch (self.prefetch)?  The GEMM mode is part of
+        # the key: it decides whether layer 0's mask was folded into that extraction's feature gather (advisor, round 4)
         batcher = b.batcher
         pre = batcher.prefetched if batcher is not None else None
         if batcher is not None:
             batcher.prefetched = None
         pre_ok = (pre is not None and train and not b.ready and b.parts is not None and
-                  pre == (b.parts[1].data_ptr(), int(b.parts[2]), b.n, ids_ptr, off))
+                  pre == (b.parts[1].data_ptr(), int(b.parts[2]), b.n, ids_ptr, off, L.gist_gemm_get_mode(), id(self)))
         flags = (_lib.GIST_STEP_TRAIN if train else 0)
         if pre_ok:
             flags |= _lib.GIST_STEP_PREEXTRACTED
@@ -395,22 +419,21 @@ class SageEngine(object):
             for (i, o) in self.dims:
                 numel = b.n * 2 * i
                 self.drop_calls += numel + (numel & 1)
-        if train:
+        if train and phase == 0:
             self.arena.step += 1
         rb = b.row_blocks
         if rb is not None and rb.numel() > 1:
-            self.plan.row_blocks, self.plan.n_row_blocks = rb.data_ptr(), rb.numel() - 1
+            P.row_blocks, P.n_row_blocks = rb.data_ptr(), rb.numel() - 1
             # room for the batch's prepared block structure (include/gist_hip.h, spmm_prepared):
             # both orientations, grown to the largest block count seen
             need = 2 * L.gist_spmm_blocks_bytes(rb.numel() - 1)
             if self._spmm_prep is None or self._spmm_prep.numel() < need:
                 self._spmm_prep = torch.empty(need + need // 4, dtype=torch.uint8, device=self.device)
-                self.plan.spmm_prepared = self._spmm_prep.data_ptr()
-                self.plan.spmm_prepared_bytes = self._spmm_prep.numel()
+                P.spmm_prepared = self._spmm_prep.data_ptr()
+                P.spmm_prepared_bytes = self._spmm_prep.numel()
         else:
-            self.plan.row_blocks, self.plan.n_row_blocks = None, 0
+            P.row_blocks, P.n_row_blocks = None, 0
         # one-launch extraction when the batch comes with its part tables (gist_extract_parts_batch)
-        P = self.plan
         if b.parts is not None and not b.ready and self.fuse and L.gist_extract_parts_supported(self.n_max):
             node_part, tab, j = b.parts
             if self._extract_scratch is None:
@@ -421,29 +444,45 @@ class SageEngine(object):
         else:
             P.node_part = P.part_slot = P.extract_scratch = None
             P.batch_index = -1
-        # the NEXT batch of the epoch, extracted beside this step's optimiser launch (GIST_STEP_EXTRACT_NEXT): only
-        # for callers that promise not to look at the batch buffers (labels, CSR, Z[0]) after a training step
-        nxt = None
         P.next_ids, P.next_n, P.next_batch_index, P.next_drop_offset = None, 0, -1, 0
-        if (self.prefetch and self._prefetch_refused is not True and train and batcher is not None
-                and b.next_info is not None and P.node_part is not None and b.row_blocks is not None):
-            nids, nj = b.next_info
-            P.next_ids, P.next_n, P.next_batch_index = nids.data_ptr(), nids.numel(), int(nj)
-            P.next_drop_offset = self.drop_calls          # (= `off` of the next training step)
-            if L.gist_sage_step_extracts_next(ctypes.byref(self.plan), b.n, flags):
-                flags |= _lib.GIST_STEP_EXTRACT_NEXT
-                nxt = (P.part_slot, int(nj), nids.numel(), nids.data_ptr(), self.drop_calls)
-            else:
-                self._prefetch_refused = True      # (a property of the plan: un-fused, or an arena too large to gain)
-        rc = L.gist_sage_step(ctypes.byref(self.plan), ids_ptr, b.n, off, lr, betas[0], betas[1],
-                              eps, weight_decay, max(self.arena.step, 1), flags, hip._stream())
+        nxt = None
+        if phase == 0:
+            nxt, flags = self._plan_next(b, batcher, flags)
+        else:
+            self._phase_ctx = (b, off, flags, ids_ptr)
+        rc = L.gist_sage_step(ctypes.byref(P), ids_ptr, b.n, off, lr, betas[0], betas[1],
+                              eps, weight_decay, max(adam_step if adam_step is not None else self.arena.step, 1),
+                              flags | phase, hip._stream())
         _lib.check(rc, 'gist_sage_step')
         if batcher is not None:
             batcher.prefetched = nxt
         if not b.ready and train and self.fuse and self.p_drop > 0.0 and self.H[0] is not None:
-            b.z0_dropped = True      # (layer 0's mask went into the feature gather: Batch contract)
+            b.z0_dropped = True      # (one training step per extraction: Batch contract)
         b.ready = True
         return self.loss
+
+    def _plan_next(self, b, batcher, flags):
+        """The NEXT batch of the epoch, extracted beside this step's optimiser launch (GIST_STEP_EXTRACT_NEXT): only for
+        callers that promise not to look at the batch buffers (labels, CSR, Z[0]) after a training step.  Returns
+        (the key the next step must match, flags)."""
+        import ctypes
+        from . import _lib
+        L = _lib.load()
+        P = self.plan
+        nxt = None
+        P.next_ids, P.next_n, P.next_batch_index, P.next_drop_offset = None, 0, -1, 0
+        if (self.prefetch and self._prefetch_refused is not True and (flags & _lib.GIST_STEP_TRAIN) and batcher is not None
+                and b.next_info is not None and P.node_part is not None and b.row_blocks is not None):
+            nids, nj = b.next_info
+            P.next_ids, P.next_n, P.next_batch_index = nids.data_ptr(), nids.numel(), int(nj)
+            P.next_drop_offset = self.drop_calls          # (= `off` of the next training step)
+            if L.gist_sage_step_extracts_next(ctypes.byref(P), b.n, flags):
+                flags |= _lib.GIST_STEP_EXTRACT_NEXT
+                nxt = (P.part_slot, int(nj), nids.numel(), nids.data_ptr(), self.drop_calls, L.gist_gemm_get_mode(),
+                       id(self))
+            else:
+                self._prefetch_refused = True      # (a property of the plan: un-fused, or an arena too large to gain)
+        return nxt, flags
 
     # ------------------------------------------------------------------
     def z0_left(self, n):
@@ -739,9 +778,9 @@ class SageEngine(object):
         Returns the device loss tensor; nothing synchronises with the host.  With a native
         plan attached (attach_batcher) and no mask this is a single gist_sage_step call."""
         if b.ready and getattr(b, 'z0_dropped', False):
-            raise RuntimeError('gist_amd: this Batch was already stepped once with layer 0\'s dropout folded into '
-                               'its extraction (Z[0] holds dropped features); one training step per extraction -- '
-                               'take a fresh batch from the iterator')
+            raise RuntimeError('gist_amd: one training step per extraction -- this Batch was already stepped once (with '
+                               'dropout fused into the step its buffers may hold dropped values); take a fresh batch '
+                               'from the iterator')
         if self.plan is not None and mask is None and hip._prof is None:
             return self._native_step(b, lr, weight_decay, train=True)
         self.forward(b, training=True, _step=mask is None)

@@ -148,7 +148,7 @@ class Graph(object):
         if apply_node_func is not None:
             raise NotImplementedError('gist_amd: apply_node_func is not supported')
 
-    def subgraph(self, nids):
+    def subgraph(self, nids, with_ndata=True):
         """Node-induced subgraph, node i of the result = nids[i]; ndata rows gathered
         (cluster_gcn/partition_utils.py:23, sampler.py:34)."""
         if not self.rowptr.is_cuda:
@@ -174,7 +174,7 @@ class Graph(object):
         sg = Graph(srp, scl, trp, tcl, nb, self._idtype)
         sg._nnz = nnz
         idl = None
-        for k, v in self.ndata.items():
+        for k, v in (self.ndata.items() if with_ndata else ()):
             if v.dtype == torch.float32 and v.dim() == 2 and v.is_cuda:
                 out = torch.empty(nb, v.shape[1], dtype=torch.float32, device=dev)
                 sg.ndata[k] = hip.gather_rows(v, ids, out)
@@ -187,3 +187,133 @@ class Graph(object):
         from .dgl_compat import NID
         sg.ndata[NID] = ids.to(self._idtype)
         return sg
+
+
+class AllRowsMask(torch.Tensor):
+    """A boolean row mask that is KNOWN to be all True (the train mask of a batch of the train-induced graph,
+    cluster_gcn/sampler.py:34): `x[mask]` with a leading dimension of mask.numel() is x itself -- no nonzero(), no
+    device-to-host synchronisation, no gather (cluster_gcn/cluster_gcn.py:100-101 indexes the logits and the labels
+    with it in every iteration).  Everything else sees an ordinary bool tensor."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[1]) is AllRowsMask:
+            x, m = args
+            if isinstance(x, torch.Tensor) and x.dim() >= 1 and m.dim() == 1 and x.shape[0] == m.shape[0]:
+                return x
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+class _BatchNData(dict):
+    """ndata of a ClusterBatch: the train graph's columns for the batch's rows, produced on first access -- a slice of
+    the column gathered once per epoch in batch order (ClusterIter.epoch_column)."""
+
+    def __init__(self, batch):
+        super().__init__()
+        self._b = batch
+
+    def _lazy_keys(self):
+        from .dgl_compat import NID
+        return list(self._b._it.g.ndata.keys()) + [NID]
+
+    def __missing__(self, key):
+        from .dgl_compat import NID
+        b = self._b
+        it = b._it
+        a = int(it._offsets[b._j])
+        if key == NID:
+            v = b._ids.to(b._idtype)
+        elif key not in it.g.ndata:
+            raise KeyError(key)
+        elif key == 'train_mask' and it._all_train:
+            v = it._ones[:b._n].as_subclass(AllRowsMask)
+        elif key == 'feat':
+            src = it.g.ndata['feat']
+            v = hip.gather_rows(src, b._ids, torch.empty(b._n, src.shape[1], dtype=torch.float32, device=src.device))
+        else:
+            v = it.epoch_column(key)[a:a + b._n]
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy_keys()
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        ks = list(dict.keys(self))
+        return ks + [k for k in self._lazy_keys() if k not in ks]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def pop(self, key, *default):
+        if key in self:
+            v = self[key]
+            dict.pop(self, key, None)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+
+class ClusterBatch(Graph):
+    """What ClusterIter yields in feed mode (cluster_gcn/sampler.py:85-93): batch j of the current epoch, DESCRIBED --
+    node ids, the row ranges of its parts -- with nothing launched.  A gist_amd.modules.GCN bound to the iterator
+    extracts it on the device as the first launch of its forward (gist_sage_step); any other consumer that touches the
+    structure (rowptr / col / update_all / in_degrees / subgraph ...) gets the induced subgraph built on first access by
+    the generic path (Graph.subgraph: its own tensors), exactly what the eager iterator yielded."""
+
+    def __init__(self, it, j):
+        self._it, self._j = it, int(j)
+        ids, n, row_blocks, parts, next_info = it.describe(j)
+        self._ids, self._n = ids, n
+        self.row_blocks, self.parts, self.next_info = row_blocks, parts, next_info
+        self._idtype = it.g._idtype
+        self._sg = None
+        self._norm = self._remap = self._nnz = None
+        self.ndata = _BatchNData(self)
+
+    def _structure(self):
+        if self._sg is None:
+            it = self._it
+            sg = it.g.subgraph(self._ids, with_ndata=False)      # (the batch's columns come from _BatchNData)
+            self._sg = sg
+            self._nnz = sg._nnz
+        return self._sg
+
+    rowptr = property(lambda self: self._structure().rowptr)
+    col = property(lambda self: self._structure().col)
+    t_rowptr = property(lambda self: self._structure().t_rowptr)
+    t_col = property(lambda self: self._structure().t_col)
+
+    @property
+    def device(self):
+        return self._ids.device
+
+    def local_var(self):
+        g = ClusterBatch.__new__(ClusterBatch)
+        g.__dict__.update(self.__dict__)
+        nd = _BatchNData(g)
+        dict.update(nd, self.ndata)
+        g.ndata = nd
+        return g
+
+    def to(self, device):
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        if device.type == 'cuda' and (device.index is None or device == self.device):
+            return self                               # cluster_gcn/cluster_gcn.py:97 (already there)
+        sg = self._structure().local_var()
+        sg.ndata = NData({k: self.ndata[k] for k in self.ndata.keys()})
+        return sg.to(device)

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import autograd
+from . import autograd, module_engine
 
 
 def _is_relu(fn):
@@ -127,10 +127,17 @@ class GCN(nn.Module):
             self.layers.append(layer_type(n_hidden, n_classes, dropout, False, activation=None))
 
     def set_dropout_seed(self, seed):
+        self._drop_seed = int(seed)           # (the fused step's generator: one seed, a running element offset)
         for k, layer in enumerate(self.layers):
             layer.drop_seed = int(seed) * 1000003 + k
 
     def forward(self, g):
+        # A cluster batch from ClusterIter: the whole forward is ONE dispatcher op on the preallocated step plan
+        # (gist_amd/module_engine.py); anything else -- the full graph of an evaluation, a hand-built graph -- runs
+        # layer by layer below
+        me = module_engine.engine_for(self, g)
+        if me is not None:
+            return me.forward(g, self.training)
         h = g.ndata['feat']
         for layer in self.layers:
             h = layer(g, h)

@@ -33,4 +33,11 @@ class CrossEntropyLoss(torch.nn.Module):
     def forward(self, logits, labels):
         if logits.shape[0] == 0:
             raise ValueError('gist_amd: CrossEntropyLoss over zero rows')
+        st = logits.__dict__.get('_gist_step') if type(logits) is torch.Tensor else None
+        if st is not None:
+            # the logits of a fused step with the batch's own labels: the class-layer launch of the forward already
+            # formed this loss and its gradient (gist_amd/module_engine.py)
+            out = st[0].fused_loss(logits, labels, st[1])
+            if out is not None:
+                return out
         return _SoftmaxXent.apply(logits, labels)

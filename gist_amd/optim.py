@@ -32,6 +32,12 @@ class Adam(object):
     def step(self):
         self.step_count += 1
         lr = self.param_groups[0]['lr']
+        # parameters that live in a step plan's arena (a GCN bound to its ClusterIter, gist_amd/module_engine.py) with
+        # their gradients in its gradient arena: the whole model is one launch
+        me = self.params[0].__dict__.get('_gist_me') if self.params else None
+        if me is not None and me.owns(self.params) and me.homed() and me.grads_in_arena():
+            me.optimizer_step(self)
+            return
         for i, p in enumerate(self.params):
             if p.grad is None:
                 continue

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .graph import ClusterBatch
 
 
 def load_partition_cache(path):
@@ -90,6 +91,17 @@ class ClusterIter(object):
         random.shuffle(self.par_li)                                  # sampler.py:55
         self.get_fn = get_subgraph
         self.n = 0
+        # device feed (None = not tried yet): the epoch's part order uploaded once per epoch and every batch DESCRIBED
+        # to the consumer, which extracts it on the device (gist_extract_parts_batch inside gist_sage_step) -- what
+        # EngineClusterIter always does and what this class does for `model(cluster)` loops when the parts partition the
+        # train graph (ClusterBatch below).  GIST_MODULE_ENGINE=0: every cluster built eagerly by g.subgraph
+        self._feed = None
+        self.batcher = None
+        self.engine = None
+        self.native = False
+        self._node_part = None
+        self.locality = None
+        self.locality_stats = None
 
     def precalc(self, g):
         """sampler.py:58-69: the TRAIN graph's features become [X | A^ X] (A^ = mean over
@@ -109,8 +121,28 @@ class ClusterIter(object):
     def __len__(self):
         return self.max
 
+    def feed(self):
+        """True when this iterator describes its batches for on-device extraction (lazily set up on first use)."""
+        if self._feed is None:
+            self._feed = False
+            tg = self.g
+            ok = (os.environ.get('GIST_MODULE_ENGINE', '1') != '0' and not self.use_pp and tg.device.type == 'cuda'
+                  and 'feat' in tg.ndata and 'label' in tg.ndata and tg.ndata['feat'].dim() == 2
+                  and tg.ndata['feat'].dtype == torch.float32 and self.max > 0)
+            if ok:
+                self._init_feed()
+                self._feed = self._node_part is not None and hip._lib.load().gist_extract_parts_supported(self.n_max) == 1
+                if self._feed:
+                    tm = tg.ndata.get('train_mask')
+                    self._all_train = bool(tm.all().item()) if tm is not None else False
+                    self._ones = torch.ones(self.n_max, dtype=torch.bool, device=tg.device)
+        return self._feed
+
     def __iter__(self):
         self.n = 0
+        if self.feed():
+            self._upload_epoch()
+            self._epoch_cols = {}
         return self
 
     def batch_ids(self, i):
@@ -120,33 +152,41 @@ class ClusterIter(object):
 
     def __next__(self):
         if self.n < self.max:
-            result = self.get_fn(self.g, self.par_li, self.n, self.psize, self.batch_size)
+            if self._feed:
+                result = ClusterBatch(self, self.n)
+            else:
+                result = self.get_fn(self.g, self.par_li, self.n, self.psize, self.batch_size)
             self.n += 1
             return result
+        if self._feed and self.engine is not None:
+            self.engine.check_extract_deferred()
         random.shuffle(self.par_li)                                  # sampler.py:92
         raise StopIteration
 
+    def epoch_column(self, key):
+        """ndata[key] of the train graph in THIS epoch's batch order (one gather per epoch and key: a batch's rows are a
+        slice of it, valid for the whole epoch whatever happens to the batch buffers)."""
+        col = self._epoch_cols.get(key)
+        if col is None:
+            v = self.g.ndata[key]
+            idx = self._epoch_cols.get('__ids64')
+            if idx is None:
+                idx = self._epoch_cols['__ids64'] = self._epoch_ids.to(torch.int64)
+            col = self._epoch_cols[key] = v.index_select(0, idx)
+        return col
 
-class EngineClusterIter(ClusterIter):
-    """ClusterIter that feeds a SageEngine: yields engine Batches built in preallocated
-    device buffers.  The epoch's part order is uploaded ONCE per epoch (one H2D of the
-    permuted node ids); every batch is then a slice of that device array, so the
-    training loop performs no per-iteration host<->device traffic."""
-
-    def __init__(self, dn, g, psize, batch_size, seed_nid, engine_in_feats=None, **kw):
-        super().__init__(dn, g, psize, batch_size, seed_nid, **kw)
+    # ---- device feed: what the extraction kernels need, per run / per epoch ----------------------------------------
+    def _init_feed(self):
         from .engine import ClusterBatcher, batch_capacity
         tg = self.g
         rowptr_host = tg.rowptr.cpu().numpy()
-        self.n_max, self.nnz_max = batch_capacity(rowptr_host, self.par_li, batch_size)
+        self.n_max, self.nnz_max = batch_capacity(rowptr_host, self.par_li, self.batch_size)
         feat = tg.ndata['feat']
         lab = tg.ndata['label']
         if lab.dtype != torch.int32:
             lab = lab.to(torch.int32)
         self.batcher = ClusterBatcher(tg, feat.contiguous(), lab.contiguous(), self.n_max,
                                       self.nnz_max)
-        self.engine = None
-        self.native = False
         self._epoch_ids = None
         self._offsets = None
         # One-launch extraction (gist_extract_parts_batch): every node's part and position in it.  Only
@@ -192,7 +232,7 @@ class EngineClusterIter(ClusterIter):
             nnz = tg.number_of_edges()
             inside = intra / float(nnz)
             n_parts = max(len(self.par_li), 2)
-            outside_in_batch = (nnz - intra) / float(n_nodes) * (min(batch_size, n_parts) - 1) / (n_parts - 1)
+            outside_in_batch = (nnz - intra) / float(n_nodes) * (min(self.batch_size, n_parts) - 1) / (n_parts - 1)
             self.locality_stats = dict(edges_inside_parts=round(inside, 4),
                                        outside_neighbours_per_batch_row=round(outside_in_batch, 3))
             self.locality = inside >= 0.5 and outside_in_batch <= 4.0
@@ -224,25 +264,6 @@ class EngineClusterIter(ClusterIter):
         if fi is not None:
             fi.copy_(self._intra_part_sums())
 
-    def _extract_with_aggregation(self, ids, n):
-        from . import hip as _hip
-        from .engine import Batch
-        bt, eng = self.batcher, self.engine
-        L = _hip._lib.load()
-        if self._extract_scratch is None:
-            self._extract_scratch = torch.zeros(int(L.gist_extract_parts_scratch_bytes(self.n_max)) // 8 + 1,
-                                                dtype=torch.int64, device=bt.feat.device)
-        bt.prefetched = None
-        f = bt.feat.shape[1]
-        _hip.extract_parts(bt.g, ids, self.n_max, self._node_part, self._part_tables, self.n, bt.rowptr[:n + 1], bt.col,
-                           bt.t_rowptr[:n + 1], bt.t_col, bt.norm, bt.feat, eng.z0_left(n), bt.labels, bt.lab,
-                           self._extract_scratch, feat_intra=bt.feat_intra, ah=eng.Z[0][:n, f:2 * f])
-        b = Batch()
-        b.n, b.rowptr, b.col, b.t_rowptr, b.t_col = n, bt.rowptr[:n + 1], bt.col, bt.t_rowptr[:n + 1], bt.t_col
-        b.norm, b.labels, b.ids = bt.norm[:n], bt.lab[:n], ids
-        b.ah_owner = eng
-        return b
-
     def _intra_part_sums(self):
         """feat_intra[v] = sum of feat[u] over the in-neighbours u of v INSIDE v's part (train graph), once per run.
         A batch is a union of whole parts, so this part of layer 0's aggregation is the same in every batch: the
@@ -264,11 +285,6 @@ class EngineClusterIter(ClusterIter):
         out = torch.zeros_like(self.batcher.feat)
         hip.spmm(rp_f.to(torch.int32), col_f, self.batcher.feat, out)
         return out
-
-    def fill_features(self, batch, engine):
-        """Gather the current batch's features into ANOTHER engine's layer-0 buffer (several
-        sub-GCNs trained in one process share one extracted batch)."""
-        hip.gather_rows(self.batcher.feat, batch.ids, engine.z0_left(batch.n))
 
     def _host_epoch_tables(self):
         """Everything the device needs for one epoch, computed on the HOST from the (already shuffled) part order,
@@ -328,18 +344,73 @@ class EngineClusterIter(ClusterIter):
             cap = total + total // 8 + 64
             bufs[par] = (torch.empty(cap, dtype=torch.int32).pin_memory(),
                          torch.empty(cap, dtype=torch.int32, device=dev))
-        host, devbuf = bufs[par]
+        host, devbuf = bufs[par][0], bufs[par][1]
+        if len(bufs[par]) > 2 and bufs[par][2] is not None:
+            bufs[par][2].synchronize()      # the copy issued from this staging buffer two epochs ago (long done)
         hv = host.numpy()
         hv[:n_ids] = ids
         hv[o_blk:o_blk + n_blk] = blocks
         if n_tab:
             hv[o_tab:total] = tab.ravel()
         devbuf[:total].copy_(host[:total], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        bufs[par] = (host, devbuf, ev)
         self._epoch_ids = devbuf[:n_ids]
         self._offsets = off
         self._epoch_blocks = devbuf[o_blk:o_blk + n_blk]
         self._block_offsets = boff
         self._part_tables = devbuf[o_tab:total].view(-1, 2) if n_tab else None
+
+    def describe(self, j):
+        """(ids, n, row_blocks, parts, next_info) of batch j of the current epoch: what Batch / ClusterBatch carry."""
+        a, b = int(self._offsets[j]), int(self._offsets[j + 1])
+        ids = self._epoch_ids[a:b]
+        row_blocks = parts = next_info = None
+        if self.locality is not False:       # (None: parts of unknown quality, e.g. overlapping: as before)
+            row_blocks = self._epoch_blocks[int(self._block_offsets[j]):int(self._block_offsets[j + 1])]
+        if self._part_tables is not None:
+            parts = (self._node_part, self._part_tables, j)
+            if j + 1 < self.max:      # the batch that follows in this epoch (SageEngine.prefetch)
+                a2, b2 = int(self._offsets[j + 1]), int(self._offsets[j + 2])
+                next_info = (self._epoch_ids[a2:b2], j + 1)
+        return ids, b - a, row_blocks, parts, next_info
+
+
+class EngineClusterIter(ClusterIter):
+    """ClusterIter that feeds a SageEngine: yields engine Batches built in preallocated
+    device buffers.  The epoch's part order is uploaded ONCE per epoch (one H2D of the
+    permuted node ids); every batch is then a slice of that device array, so the
+    training loop performs no per-iteration host<->device traffic."""
+
+    def __init__(self, dn, g, psize, batch_size, seed_nid, engine_in_feats=None, **kw):
+        super().__init__(dn, g, psize, batch_size, seed_nid, **kw)
+        self._init_feed()
+        self._feed = True
+
+    def _extract_with_aggregation(self, ids, n):
+        from . import hip as _hip
+        from .engine import Batch
+        bt, eng = self.batcher, self.engine
+        L = _hip._lib.load()
+        if self._extract_scratch is None:
+            self._extract_scratch = torch.zeros(int(L.gist_extract_parts_scratch_bytes(self.n_max)) // 8 + 1,
+                                                dtype=torch.int64, device=bt.feat.device)
+        bt.prefetched = None
+        f = bt.feat.shape[1]
+        _hip.extract_parts(bt.g, ids, self.n_max, self._node_part, self._part_tables, self.n, bt.rowptr[:n + 1], bt.col,
+                           bt.t_rowptr[:n + 1], bt.t_col, bt.norm, bt.feat, eng.z0_left(n), bt.labels, bt.lab,
+                           self._extract_scratch, feat_intra=bt.feat_intra, ah=eng.Z[0][:n, f:2 * f])
+        b = Batch()
+        b.n, b.rowptr, b.col, b.t_rowptr, b.t_col = n, bt.rowptr[:n + 1], bt.col, bt.t_rowptr[:n + 1], bt.t_col
+        b.norm, b.labels, b.ids = bt.norm[:n], bt.lab[:n], ids
+        b.ah_owner = eng
+        return b
+
+    def fill_features(self, batch, engine):
+        """Gather the current batch's features into ANOTHER engine's layer-0 buffer (several
+        sub-GCNs trained in one process share one extracted batch)."""
+        hip.gather_rows(self.batcher.feat, batch.ids, engine.z0_left(batch.n))
 
     def __iter__(self):
         self.n = 0
@@ -348,8 +419,7 @@ class EngineClusterIter(ClusterIter):
 
     def __next__(self):
         if self.n < self.max:
-            a, b = int(self._offsets[self.n]), int(self._offsets[self.n + 1])
-            ids = self._epoch_ids[a:b]
+            ids, n, row_blocks, parts, next_info = self.describe(self.n)
             from . import hip as _hip
             if self.native and _hip._prof is None:
                 batch = self.batcher.lazy(ids)
@@ -357,17 +427,10 @@ class EngineClusterIter(ClusterIter):
                   and self.engine.fuse and self.engine.dims[0][0] == self.batcher.feat.shape[1]):
                 # the extraction the native step runs (one launch, layer 0's aggregation formed with it: it sums in its own
                 # order, so the op-by-op path takes the same launch)
-                batch = self._extract_with_aggregation(ids, b - a)
+                batch = self._extract_with_aggregation(ids, n)
             else:
-                batch = self.batcher.extract(ids, self.engine.z0_left(b - a))
-            if self.locality is not False:       # (None: parts of unknown quality, e.g. overlapping: as before)
-                batch.row_blocks = self._epoch_blocks[int(self._block_offsets[self.n]):
-                                                      int(self._block_offsets[self.n + 1])]
-            if self._part_tables is not None:
-                batch.parts = (self._node_part, self._part_tables, self.n)
-                if self.n + 1 < self.max:      # the batch that follows in this epoch (SageEngine.prefetch)
-                    a2, b2 = int(self._offsets[self.n + 1]), int(self._offsets[self.n + 2])
-                    batch.next_info = (self._epoch_ids[a2:b2], self.n + 1)
+                batch = self.batcher.extract(ids, self.engine.z0_left(n))
+            batch.row_blocks, batch.parts, batch.next_info = row_blocks, parts, next_info
             self.n += 1
             return batch
         if self.engine is not None:

@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 13 */
+int gist_abi_version(void);   /* currently 14 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -458,6 +458,13 @@ int gist_adam_segments_f32(float *param, float *grad, float *exp_avg, float *exp
                            const float *row_loss, int64_t n_loss_rows, int64_t loss_count, float *loss,
                            gist_stream_t stream);
 
+/* The deferred gradient sums of gist_adam_segments_f32 WITHOUT the optimiser update (ABI 14): grad[i] = sum of the
+ * segment's sources in the same order (so a later gist_adam_f32 over the arena is bitwise gist_adam_segments_f32),
+ * elements outside every segment untouched.  For a loop that must see complete gradients between loss.backward() and
+ * optimizer.step() (cluster_gcn/cluster_gcn.py:103-105): the backward-phase call of gist_sage_step ends with it. */
+int gist_grad_segments_finish_f32(float *grad, int64_t n, const gist_grad_segment *segments, int64_t n_segments,
+                                  gist_stream_t stream);
+
 /* correct[0] += #{i : mask[i] && argmax_j logits[i,j] == labels[i]} (first max wins,
  * like numpy argmax).  Replaces calc_acc / calc_f1(micro), cluster_gcn/utils.py:47-67. */
 int gist_argmax_correct_i32(const float *logits, int64_t ldl, const int32_t *labels,
@@ -762,6 +769,23 @@ int gist_timer_read(gist_timer *t, int64_t i, float *ms, int32_t *kind, int64_t 
 #define GIST_STEP_TRAIN 2     /* dropout on, backward + Adam (else: forward + loss only)      */
 #define GIST_STEP_EXTRACT_NEXT 4   /* TRAIN only: also extract plan->next_* (gist_sage_step_extracts_next says whether this call can) */
 #define GIST_STEP_PREEXTRACTED 8   /* TRAIN only: the batch buffers hold THIS batch, extracted by the previous call's EXTRACT_NEXT */
+/* Phases (ABI 14, TRAIN only): the reference's loop body is four statements -- `pred = model(cluster)`, `loss = loss_f(...)`,
+ * `loss.backward()`, `optimizer.step()` (cluster_gcn/cluster_gcn.py:96-105, cluster_gcn_ist_distrib.py:410-417) -- and a
+ * script that keeps them (gist_amd/modules.py: GCN.forward, nn.CrossEntropyLoss, optim.Adam) issues the SAME iteration as
+ * three calls with the same (plan, ids, n, drop_offset, other flags):
+ *   FORWARD    extraction (EXTRACT) -> forward -> logits, mean CE in plan->loss (complete on return), and what the fused
+ *              class layer produces beside them for the standard loss (dlogits, the class layer's dZ and bias chunk sums);
+ *   BACKWARD   the backward pass from those; the gradient arena is COMPLETE on return (deferred split-K slabs / chunk sums
+ *              are summed by gist_grad_segments_finish_f32 in the optimiser's order).  With GIST_STEP_DLOGITS_GIVEN the caller
+ *              has overwritten plan->dlogits with the gradient of ITS loss w.r.t. the logits: the class layer's dZ is
+ *              recomputed from it;
+ *   OPTIMIZER  Adam over the arena from plan->grads (+ EXTRACT_NEXT: the next batch's extraction in the same grid).
+ * No phase bit (or all three) = the whole iteration in one call, as before.  Parameters after the three calls are bitwise
+ * those of the one-call step. */
+#define GIST_STEP_PHASE_FORWARD 16
+#define GIST_STEP_PHASE_BACKWARD 32
+#define GIST_STEP_PHASE_OPTIMIZER 64
+#define GIST_STEP_DLOGITS_GIVEN 128
 
 /* One iteration of the reference's training loop on the batch whose node ids (in the
  * training graph) are ids[0..n): induced subgraph + feature/label gather
