@@ -40,6 +40,7 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the projection G
 cores and one thread).
 """
 import argparse
+import gc
 import json
 import os
 import random
@@ -703,12 +704,36 @@ def main():
                 for cluster in self.cluster_iterator:
                     yield cluster
 
-        def run(self, count, sample_timer=None, ids_log=None, n_log=None, loss_log=None, every_=1):
+        breakdown = None
+
+        def _run_timed(self, cluster):
+            pc = time.perf_counter
+            t = [pc()]
+            cluster = cluster.to(torch.cuda.current_device()); self.model.train(); t.append(pc())
+            pred = self.model(cluster); t.append(pc())
+            if t[-1] - t[-2] > 2e-3 and self.engine is not None:
+                self.breakdown['forward_native_call_ms'] = round(self._native_ms[-1], 3)
+            batch_labels = cluster.ndata['label']; batch_train_mask = cluster.ndata['train_mask']; t.append(pc())
+            loss = self.loss_f(pred[batch_train_mask], batch_labels[batch_train_mask]); t.append(pc())
+            self.optimizer.zero_grad(); t.append(pc())
+            loss.backward(); t.append(pc())
+            self.optimizer.step(); t.append(pc())
+            d = [round((b - a) * 1e3, 3) for a, b in zip(t[:-1], t[1:])]
+            if sum(d) > self.breakdown.get('total', 0.0):
+                self.breakdown.update(total=sum(d), parts=dict(zip(('to+train', 'forward', 'ndata', 'loss', 'zero_grad',
+                                                                    'backward', 'step'), d)))
+
+        def run(self, count, sample_timer=None, ids_log=None, n_log=None, loss_log=None, every_=1, stamps=None):
             model, loss_f, optimizer = self.model, self.loss_f, self.optimizer
             for s in range(count):
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
                 cluster = next(self.gen)
                 if self.engine is not None:
                     self.engine.plan.timer = sample_timer if (sample_timer is not None and s % every_ == every_ // 2) else None
+                if self.breakdown is not None:          # (dev: where a slow iteration spends its host time)
+                    self._run_timed(cluster)
+                    continue
                 cluster = cluster.to(torch.cuda.current_device())
                 model.train()
                 pred = model(cluster)
@@ -751,10 +776,14 @@ def main():
 
     gen = batches()
 
+    host_stamps = []        # host clock at the start of every step of the LAST timed region (issue gaps: diagnostics)
+
     def run_steps(count, sample_timer=None, ids_log=None, n_log=None, loss_log=None):
+        del host_stamps[:]
         if module_headline:
-            return mloop.run(count, sample_timer, ids_log, n_log, loss_log, every)
+            return mloop.run(count, sample_timer, ids_log, n_log, loss_log, every, stamps=host_stamps)
         for s in range(count):
+            host_stamps.append(time.perf_counter())
             b = next(gen)
             ti = state['total_iter']
             if ist_model is not None and ti % args.iter_per_site == 0:
@@ -778,7 +807,57 @@ def main():
                 e1.record()
                 sync_ms.append((e0, e1))
 
-    def fence():
+    gc_log, gc_t0 = [], [0.0]
+
+    def gc_cb(phase, info):      # (diagnostics: collections of the cyclic GC that take more than a millisecond of host time)
+        if phase == 'start':
+            gc_t0[0] = time.perf_counter()
+        else:
+            d_ = (time.perf_counter() - gc_t0[0]) * 1e3
+            if d_ > 1.0:
+                gc_log.append((info.get('generation'), round(d_, 2), info.get('collected')))
+    gc.callbacks.append(gc_cb)
+
+    def host_counters():
+        """What can keep a runnable Python thread off its core: run-queue wait of this thread (/proc schedstat), CFS
+        bandwidth throttling of the container (cgroup cpu.stat), context switches, page faults."""
+        import resource
+        c = {}
+        try:
+            a, b, n_ = open('/proc/thread-self/schedstat').read().split()
+            c['on_cpu_ms'], c['runqueue_wait_ms'], c['timeslices'] = int(a) / 1e6, int(b) / 1e6, int(n_)
+        except Exception:
+            pass
+        for f_ in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat', '/sys/fs/cgroup/cpu,cpuacct/cpu.stat'):
+            try:
+                for line in open(f_):
+                    k_, v_ = line.split()
+                    if k_ in ('nr_throttled', 'throttled_usec', 'throttled_time', 'nr_periods'):
+                        c['cgroup_' + k_] = int(v_)
+                break
+            except Exception:
+                continue
+        ru = resource.getrusage(resource.RUSAGE_SELF)
+        c['minor_faults'], c['major_faults'] = ru.ru_minflt, ru.ru_majflt
+        c['vol_ctx'], c['invol_ctx'] = ru.ru_nvcsw, ru.ru_nivcsw
+        return c
+
+    def counter_delta(a, b):
+        return {k: (round(b[k] - a[k], 2) if isinstance(b[k], float) else b[k] - a[k]) for k in b if k in a}
+
+    def gap_stats(gaps):
+        """Host time from the start of one step's issue to the next's (no synchronisation inside a timed region: the host
+        runs ahead of the GPU; a long gap is the host, not a kernel)."""
+        if gaps.size == 0:
+            return None
+        big = np.flatnonzero(gaps > 1.0)
+        return {'median': round(float(np.median(gaps)), 4), 'max': round(float(gaps.max()), 3),
+                'over_1ms': [(int(i), round(float(gaps[i]), 2)) for i in big[:12]]}
+
+    def fence(collect=False):
+        if collect:       # (host hygiene, before a timed region only: no generation-2 pass of the cyclic GC over the
+            gc.collect()  # process's ~10^6 long-lived objects inside it: 20-70 ms of host time, profiles/r05_module_path.md)
+            gc.freeze()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -792,7 +871,7 @@ def main():
         elif with_timer:
             hip.profile_begin()
         ids_log, n_log, loss_log = [], [], []
-        fence()
+        fence(collect=True)
         t0 = time.time()
         run_steps(steps, sample_timer, ids_log, n_log, loss_log)
         fence()
@@ -897,7 +976,10 @@ def main():
     run_steps(args.warmup)
     del sync_ms[:]                 # syncs of the warm-up are not part of the timed region
     timing = not args.no_kernel_timing
+    hc_head0 = host_counters()
     elapsed_local, prof, timed_ids, n_log, loss_log = timed_region(args.steps, timing)
+    hc_head = counter_delta(hc_head0, host_counters())
+    head_gaps = np.diff(np.asarray(host_stamps)) * 1e3
     engine.check_extract()         # no batch of the warm-up / timed region was built from a timed-out extraction
     n_sync_timed = len(sync_ms)
     sync_timed = list(sync_ms)
@@ -981,15 +1063,35 @@ def main():
             ml = ModuleLoop()
             n_re = max(args.steps // 2, 10)
             ml.run(max(min(args.warmup, 10), 3))
-            fence()
+            fence(collect=True)
             t0 = time.time()
-            ml.run(n_re)
+            stamps = []
+            hc0 = host_counters()
+            if os.environ.get('GIST_BENCH_STEP_BREAKDOWN'):
+                ml.breakdown = {}
+                ml._native_ms = [0.0]
+                orig_native = ml.engine._native_step
+
+                def timed_native(*a_, **k_):
+                    t_ = time.perf_counter()
+                    r_ = orig_native(*a_, **k_)
+                    ml._native_ms.append((time.perf_counter() - t_) * 1e3)
+                    if len(ml._native_ms) > 8:
+                        del ml._native_ms[:4]
+                    return r_
+                ml.engine._native_step = timed_native
+            ml.run(n_re, stamps=stamps)
             fence()
             e3 = time.time() - t0
+            gaps = np.diff(np.asarray(stamps)) * 1e3
+            hc1 = host_counters()
             ml.engine.check_extract()
             legs['module_path'] = {
                 'value': round(n_re / STEPS_PER_EPOCH / e3, 4), 'unit': 'epochs/s', 'ms_per_step': round(e3 / n_re * 1e3, 4),
                 'steps': n_re, 'vs_engine_path_ms_per_step': round((e3 / n_re) / (elapsed / args.steps), 4),
+                'host_issue_ms_per_step': gap_stats(gaps), 'gc_collections_over_1ms': list(gc_log),
+                'host_counters_delta': counter_delta(hc0, hc1),
+                **({'slowest_step_host_ms': ml.breakdown} if ml.breakdown is not None else {}),
                 'host_path': 'pred = model(cluster); loss = loss_f(pred[mask], labels[mask]); optimizer.zero_grad(); '
                              'loss.backward(); optimizer.step() -- cluster_gcn/cluster_gcn.py:96-105 on gist_amd.modules.GCN, '
                              'nn.CrossEntropyLoss, optim.Adam, sampler.ClusterIter: three gist_sage_step phase calls per '
@@ -1091,6 +1193,7 @@ def main():
                          'rises to ~100), then trains: the default 150-step run goes 78 -> 4.6, 3000 steps '
                          'reach 2.8 (DESIGN.md section 5); a --steps 20 run sees only the transient',
             **({'INVALID': 'GIST_BENCH_SHARED_GPU validation run: ranks share one GPU, host-staged gloo'} if shared_gpu else {}),
+            'host_issue_ms_per_step': gap_stats(head_gaps), 'host_counters_delta': hc_head,
             'host_path': ('module path: the reference loop body on gist_amd.modules.GCN / nn.CrossEntropyLoss / optim.Adam / '
                           'sampler.ClusterIter (three gist_sage_step phase calls per iteration)') if module_headline else
                          'native step driver (gist_sage_step, 1 call/iteration)' if native else 'python op-by-op',

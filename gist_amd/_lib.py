@@ -60,6 +60,8 @@ SIGNATURES = {
     'gist_induced_mark': (_int, [_p, _i64, _p, _p]),
     'gist_induced_unmark': (_int, [_p, _i64, _p, _p]),
     'gist_fill_i32': (_int, [_p, _i64, _i32, _p]),
+    'gist_copy_i32': (_int, [_p, _p, _i64, _p]),
+    'gist_publish_i64': (_int, [_p, _i64, _p, _p]),
     'gist_induced_rowptr': (_int, [_p, _p, _p, _i64, _p, _p, _p]),
     'gist_induced_fill': (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     'gist_extract_batch': (_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),

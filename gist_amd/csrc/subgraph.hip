@@ -744,6 +744,36 @@ extern "C" int gist_fill_i32(int32_t *p, int64_t n, int32_t value, gist_stream_t
     return launch_status("gist_fill_i32");
 }
 
+// dst[i] = src[i]: a copy issued as a KERNEL.  Either pointer may be pinned host memory (hipHostMalloc: device-
+// accessible at the same address): the per-epoch tables travel this way (gist_hip.h, gist_copy_i32).
+__global__ void copy_i32_kernel(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+extern "C" int gist_copy_i32(const int32_t *src, int32_t *dst, int64_t n, gist_stream_t stream) {
+    GIST_REQUIRE(n >= 0, "gist_copy_i32: n < 0");
+    if (n == 0) return GIST_OK;
+    GIST_REQUIRE(src && dst, "gist_copy_i32: null pointer");
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024);
+    hipLaunchKernelGGL(copy_i32_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, n);
+    return launch_status("gist_copy_i32");
+}
+
+// host_word[0] = *device_word (0 if NULL), host_word[1] = tag, visible to the host when the kernel has run
+__global__ void publish_i64_kernel(const int64_t *__restrict__ device_word, int64_t tag, volatile int64_t *host_word) {
+    host_word[0] = device_word ? *device_word : 0;
+    __threadfence_system();
+    host_word[1] = tag;
+    __threadfence_system();
+}
+
+extern "C" int gist_publish_i64(const int64_t *device_word, int64_t tag, int64_t *host_word, gist_stream_t stream) {
+    GIST_REQUIRE(host_word, "gist_publish_i64: null pointer");
+    hipLaunchKernelGGL(publish_i64_kernel, dim3(1), dim3(1), 0, as_stream(stream), device_word, tag, host_word);
+    return launch_status("gist_publish_i64");
+}
+
 extern "C" int gist_induced_rowptr(const int32_t *rowptr, const int32_t *col, const int32_t *ids,
                                    int64_t n_ids, const int32_t *remap, int32_t *sub_rowptr,
                                    gist_stream_t stream) {

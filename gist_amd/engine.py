@@ -320,23 +320,32 @@ class SageEngine(object):
                                'the batches extracted since the last check are invalid')
 
     def check_extract_deferred(self):
-        """The same check without draining the queue: raises for the error word copied out at the PREVIOUS call (its
-        copy has long completed), then starts an asynchronous copy of the current word into pinned host memory."""
+        """The same check without draining the queue: a one-thread kernel writes the error word and a running tag into
+        pinned host memory (gist_publish_i64: no copy command, no event object, no busy-waiting runtime call); this call
+        first makes sure the mark of the PREVIOUS call has arrived -- it normally has, long ago; a host more than one call
+        ahead of the GPU sleeps here in 50-us naps, which is what bounds its run-ahead -- and raises for that mark's
+        error word."""
         if self._extract_scratch is None:
             return
-        pend = getattr(self, '_extract_pending', None)
-        if pend is not None:
-            host, ev = pend
-            ev.synchronize()
-            if int(host[0].item()) != 0:
+        import time
+        if getattr(self, '_mark', None) is None:
+            self._mark = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+            self._mark_np = self._mark.numpy()
+            self._mark_tag = 0
+        prev = self._mark_tag
+        if prev > 0:
+            deadline = None
+            while int(self._mark_np[1]) < prev:
+                if deadline is None:
+                    deadline = time.time() + 600.0
+                elif time.time() > deadline:
+                    raise RuntimeError('gist_amd: the GPU never reached the progress mark of the previous epoch')
+                time.sleep(5e-5)
+            if int(self._mark_np[0]) != 0:
                 raise RuntimeError('gist_amd: gist_extract_parts_batch timed out at its grid barrier; '
                                    'the batches extracted since the last check are invalid')
-        else:
-            host = torch.zeros(1, dtype=torch.int64).pin_memory()
-        host.copy_(self._extract_scratch[1:2], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._extract_pending = (host, ev)
+        self._mark_tag = prev + 1
+        hip.publish_i64_raw(self._extract_scratch[1:2].data_ptr(), self._mark_tag, self._mark.data_ptr())
 
     def enable_timer(self, capacity):
         """HIP-event timing of every SpMM/GEMM issued by the native step (gist_timer_*)."""

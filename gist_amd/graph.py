@@ -16,6 +16,8 @@ summation order stays deterministic.
 Structure can be built on the host (numpy) -- that is graph construction, not the
 hot path -- but every compute call requires the graph to be on the GPU.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -211,7 +213,7 @@ class _BatchNData(dict):
 
     def __init__(self, batch):
         super().__init__()
-        self._b = batch
+        self._b = weakref.proxy(batch)      # (no reference cycle: a finished batch is freed by its refcount, not by the GC)
 
     def _lazy_keys(self):
         from .dgl_compat import NID

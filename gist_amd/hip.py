@@ -377,6 +377,16 @@ def argmax_correct(logits, labels, mask, correct):
 
 
 # -- cluster batch extraction -------------------------------------------------------------
+def copy_i32_raw(src_ptr, dst_ptr, n):
+    """dst[i] = src[i] by a kernel (gist_copy_i32); raw addresses: either side may be pinned host memory."""
+    _lib.check(_lib.load().gist_copy_i32(src_ptr, dst_ptr, int(n), _stream()), 'gist_copy_i32')
+
+
+def publish_i64_raw(device_word_ptr, tag, host_word_ptr):
+    """host_word[0] = *device_word, host_word[1] = tag, by a kernel on the current stream (gist_publish_i64)."""
+    _lib.check(_lib.load().gist_publish_i64(device_word_ptr, int(tag), host_word_ptr, _stream()), 'gist_publish_i64')
+
+
 def fill_i32_(t, value):
     L = _lib.load()
     _lib.check(L.gist_fill_i32(_vec(t, 't', torch.int32), t.numel(), int(value), _stream()),

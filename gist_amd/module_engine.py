@@ -175,6 +175,9 @@ class ModuleEngine(object):
         self._loss0 = None
         self._f32 = dict(dtype=torch.float32, device=dev)
         self._last = len(layers) - 1
+        self._first_step = True
+        self._logit_ring = [torch.empty(it.n_max, self.ldc, **self._f32) for _ in range(4)]
+        self._loss_ring = list(torch.zeros(1024, **self._f32).unbind(0))
 
     def __deepcopy__(self, memo):
         return None                   # (a copied model binds its own engine on first use)
@@ -193,11 +196,13 @@ class ModuleEngine(object):
         b = self.it.batcher.lazy(g._ids)
         b.row_blocks, b.parts, b.next_info = g.row_blocks, g.parts, g.next_info
         P = eng.plan
-        y = torch.empty(n, self.ldc, **self._f32)
-        P.layer[self._last].Y = y.data_ptr()
-        self._loss0 = torch.empty((), **self._f32)
-        P.loss = self._loss0.data_ptr()
+        # logits and loss of a step live in small rings (no allocator call in the loop): `pred` stays valid until the
+        # 4th forward after its own, the loss tensor for 1024 steps -- copy them to keep them longer
         self.token += 1
+        y = self._logit_ring[self.token & 3][:n]
+        P.layer[self._last].Y = y.data_ptr()
+        self._loss0 = self._loss_ring[self.token & 1023]
+        P.loss = self._loss0.data_ptr()
         self._pending = (b, g, y)
         if not training:
             eng._native_step(b, 0.0, 0.0, train=False)
@@ -313,6 +318,13 @@ class ModuleEngine(object):
             eng._native_step(self._pending[0], lr, opt.weight_decay, train=True, betas=opt.betas, eps=opt.eps,
                              phase=_lib.GIST_STEP_PHASE_OPTIMIZER, adam_step=opt.step_count)
             self.state = _IDLE
+            if self._first_step:
+                # the first complete iteration has pulled in what torch imports lazily (dispatcher caches, autograd,
+                # pinned-memory allocator: ~10^5 objects created AFTER bind()'s freeze): freeze those too, or the first
+                # full garbage collection of the loop (~100 iterations in) stalls the host for 20-40 ms
+                self._first_step = False
+                from .sampler import freeze_setup_objects
+                freeze_setup_objects()
         else:
             hip.adam_(A.params, A.grads, m, v, opt.step_count, lr, opt.betas[0], opt.betas[1], opt.eps,
                       opt.weight_decay)

@@ -27,6 +27,19 @@ from . import hip
 from .graph import ClusterBatch
 
 
+def freeze_setup_objects():
+    """Everything a run has built by the time its iterator is bound -- the dataset, the partition lists, torch itself:
+    ~10^6 Python objects -- lives until the process ends.  A full (generation 2) pass of the cyclic garbage collector
+    over them takes ~70 ms on the host and lands in the middle of the training loop every few thousand iterations
+    (measured: one such pass in a 300-step window, profiles/r05_module_path.md).  gc.freeze() moves them to the
+    permanent generation: later collections only walk what the loop itself allocates.  GIST_GC_FREEZE=0 leaves the
+    collector alone."""
+    if os.environ.get('GIST_GC_FREEZE', '1') != '0':
+        import gc
+        gc.collect()
+        gc.freeze()
+
+
 def load_partition_cache(path):
     """Reader for the reference's cache: object array of int64 node-id arrays."""
     arr = np.load(path, allow_pickle=True)
@@ -254,6 +267,7 @@ class ClusterIter(object):
             self.intra_part_sums_seconds = time.time() - t0      # (once per run; bench.py reports it with its set-up times)
         if self.native:
             self.native = engine.attach_batcher(self.batcher) is not None
+        freeze_setup_objects()
         return self
 
     def refresh_input_aggregation(self):
@@ -322,11 +336,14 @@ class ClusterIter(object):
         return ids, off, blocks, boff, tab
 
     def _upload_epoch(self):
-        """ONE asynchronous host-to-device copy per epoch from a pinned staging buffer into the epoch's own set of
-        device buffers (two sets, alternating: the previous epoch's last batches may still be executing).  No
-        synchronisation: the pageable-memory copy this replaces waited for the whole queue, and the GPU then sat idle
-        through ~3 ms of Python loops -- 30-65 us per step of an epoch of 75 (the gap between a step's kernel time and
-        ms_per_step in the round-3 profiles)."""
+        """ONE upload per epoch: the tables are built in a pinned staging buffer and a copy KERNEL (gist_copy_i32) moves
+        them into the epoch's own set of device buffers (two sets, alternating: the previous epoch's last batches may
+        still be executing).  No synchronisation: the pageable-memory copy of round 3 waited for the whole queue (30-65 us
+        per step of an epoch of 75).  Both staging buffers are allocated at the FIRST call, directly as pinned memory
+        (round 5): `torch.empty(n).pin_memory()` at the first epoch boundary ran a multi-threaded CPU copy whose OpenMP
+        workers then spin-waited on every core -- inside a container with a CPU quota that exhausted the quota and the
+        kernel froze the whole process for the rest of the 100-ms period (profiles/r05_module_path.md: 30-65 ms of idle GPU
+        in ~half of all 150-step windows, on either host path)."""
         ids, off, blocks, boff, tab = self._host_epoch_tables()
         dev = self.g.device
         n_ids, n_blk = ids.shape[0], blocks.shape[0]
@@ -340,22 +357,24 @@ class ClusterIter(object):
         bufs = getattr(self, '_epoch_bufs', None)
         if bufs is None:
             bufs = self._epoch_bufs = [None, None]
-        if bufs[par] is None or bufs[par][0].numel() < total:
-            cap = total + total // 8 + 64
-            bufs[par] = (torch.empty(cap, dtype=torch.int32).pin_memory(),
-                         torch.empty(cap, dtype=torch.int32, device=dev))
-        host, devbuf = bufs[par][0], bufs[par][1]
-        if len(bufs[par]) > 2 and bufs[par][2] is not None:
-            bufs[par][2].synchronize()      # the copy issued from this staging buffer two epochs ago (long done)
+        for q in ((0, 1) if bufs[par] is None else (par,)):
+            if bufs[q] is None or bufs[q][0].numel() < total:
+                cap = total + total // 8 + 64
+                bufs[q] = (torch.empty(cap, dtype=torch.int32, pin_memory=True),
+                           torch.empty(cap, dtype=torch.int32, device=dev))
+        host, devbuf = bufs[par]
+        # The staging buffer is rewritten here: the copy issued from it two epochs ago must be complete.  With a bound
+        # engine that runs the one-launch extraction it is -- check_extract_deferred() at the end of the previous epoch
+        # waited for an event recorded after it.  Otherwise nothing bounds the host's run-ahead: wait for the stream.
+        # (No torch event of its own: the progress mark below it is the loop's only host <-> device handshake.)
+        if self.engine is None or self.engine._extract_scratch is None:
+            torch.cuda.current_stream(dev).synchronize()
         hv = host.numpy()
         hv[:n_ids] = ids
         hv[o_blk:o_blk + n_blk] = blocks
         if n_tab:
             hv[o_tab:total] = tab.ravel()
-        devbuf[:total].copy_(host[:total], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        bufs[par] = (host, devbuf, ev)
+        hip.copy_i32_raw(host.data_ptr(), devbuf.data_ptr(), total)      # (a kernel reading the pinned buffer: no copy command)
         self._epoch_ids = devbuf[:n_ids]
         self._offsets = off
         self._epoch_blocks = devbuf[o_blk:o_blk + n_blk]

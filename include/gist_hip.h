@@ -481,6 +481,17 @@ int gist_induced_mark(const int32_t *ids, int64_t n_ids, int32_t *remap, gist_st
 int gist_induced_unmark(const int32_t *ids, int64_t n_ids, int32_t *remap, gist_stream_t stream);
 int gist_fill_i32(int32_t *p, int64_t n, int32_t value, gist_stream_t stream);
 
+/* Stream-ordered host <-> device traffic as KERNELS on pinned host memory (hipHostMalloc: device-accessible at its host
+ * address), ABI 14: the training loop's queue then holds launches only -- no copy command, no event object, and the host
+ * never sits in a busy-waiting runtime call (the loop's host thread shares a CPU quota with everything else in its
+ * container: profiles/r05_module_path.md).
+ *   gist_copy_i32      dst[i] = src[i]; either side may be pinned host memory (the per-epoch part order,
+ *                      cluster_gcn/sampler.py:55,92, built on the host once per epoch);
+ *   gist_publish_i64   host_word[0] = *device_word (0 if NULL), then host_word[1] = tag: a progress mark the host
+ *                      polls (the extraction's error word of gist_extract_parts_batch + the epoch it belongs to). */
+int gist_copy_i32(const int32_t *src, int32_t *dst, int64_t n, gist_stream_t stream);
+int gist_publish_i64(const int64_t *device_word, int64_t tag, int64_t *host_word, gist_stream_t stream);
+
 /* sub_rowptr[0..n_ids] = exclusive scan of the induced degree of ids[i] in the
  * CSR (rowptr, col): #neighbours u of ids[i] with remap[u] >= 0. */
 int gist_induced_rowptr(const int32_t *rowptr, const int32_t *col, const int32_t *ids,

@@ -118,16 +118,20 @@ def test_module_loop_is_the_engine_path_bit_for_bit(p_drop, n_layers, n_feats, h
 
 def test_any_loss_on_the_logits_goes_through_the_tape():
     """torch's own cross entropy on `pred` (int64 labels): an ordinary autograd graph ending in gist::gcn_backward with
-    the caller's d_logits.  Same mathematics as the fused loss: parameters agree to rounding after two epochs, and the
-    first step's gradients to 1e-6 relative."""
+    the caller's d_logits (GIST_STEP_DLOGITS_GIVEN).  Same mathematics as the fused loss: one step on one batch gives the
+    same loss and the same gradients to rounding (parameters after Adam are not compared: its update is an
+    ill-conditioned function of gradient elements near zero); a short run's losses stay together."""
+    a = _module_run(0.0, 2, 302, 512, epochs=1, bs=30, loss_kind='torch')
+    b = _module_run(0.0, 2, 302, 512, epochs=1, bs=30, loss_kind='gist')
+    assert type(b[3]) is torch.Tensor
+    assert abs(a[3][0].item() - b[3][0].item()) < 1e-5
+    for la, lb in zip(a[0].layers, b[0].layers):
+        for ga, gb in ((la.linear.weight.grad, lb.linear.weight.grad), (la.linear.bias.grad, lb.linear.bias.grad)):
+            assert ((ga - gb).norm() / gb.norm()).item() < 1e-5
+            assert (ga - gb).abs().max().item() < 1e-5 * gb.abs().max().item() + 1e-9
     a = _module_run(0.0, 2, 302, 512, epochs=1, loss_kind='torch')
     b = _module_run(0.0, 2, 302, 512, epochs=1, loss_kind='gist')
-    assert (a[3] - b[3]).abs().max().item() < 1e-5
-    for la, lb in zip(a[0].layers, b[0].layers):
-        d = (la.linear.weight - lb.linear.weight).abs().max().item()
-        assert d < 2e-4, d
-        ga, gb = la.linear.weight.grad, lb.linear.weight.grad
-        assert ((ga - gb).norm() / gb.norm()).item() < 1e-4
+    assert ((a[3] - b[3]).abs() / b[3].abs()).max().item() < 1e-3
 
 
 def test_first_step_gradients_match_the_op_by_op_module_path(monkeypatch):
@@ -253,7 +257,7 @@ def test_dispatcher_ops_schema_and_fake():
     me = list(model._module_engines.values())[0]
     assert 'gcn_forward' in str(torch.ops.gist.gcn_forward.default._schema)
     with torch.no_grad():
-        args = (me.params, me.handle, me.token, cluster.number_of_nodes(), me.ldc, True)
+        args = ([p.detach() for p in me.params], me.handle, me.token, cluster.number_of_nodes(), me.ldc, True)
         opcheck(torch.ops.gist.gcn_forward.default, args, test_utils=('test_schema', 'test_faketensor'))
     # (a backward consumes its forward's activations in place: it runs once per forward, so no repeated-call checks)
     assert 'gcn_backward' in str(torch.ops.gist.gcn_backward.default._schema)

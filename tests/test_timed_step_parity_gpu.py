@@ -11,7 +11,8 @@ The dropout masks are not stored anywhere on the GPU: the test rebuilds them on 
 definition (seed, layer offset, element index -> splitmix64) and hands them to the oracle as `drop_masks`.
 
 Per step, against O.train_step(..., drop_masks=..., drop_p=0.2):
-  * loss and logits at 1e-4 (relative to max(1, |ref|));
+  * loss at 1e-4 (relative to max(1, |ref|)); every ROW of the logits within 1e-4 of its own largest |logit| (or of 1),
+    the absolute maximum printed;
   * the PRE-Adam gradients (Adam writes the summed split-K slabs / bias chunk sums back to the gradient arena):
     every tensor within 2e-5 of the oracle's in relative L2 norm and within 1e-4 x max|g| in max-norm;
   * the POST-step parameters in max-norm 1e-4; an element may exceed it only where Adam's update is an
@@ -21,7 +22,9 @@ Per step, against O.train_step(..., drop_masks=..., drop_p=0.2):
   * ReLU: the GPU's and the oracle's masks agree on every activation except LayerNorm outputs within 4e-6 of zero
     (at most 8 per layer and step); on those the oracle's backward follows the GPU's decision -- one such flip
     moves a 512-wide layer's weight gradient by 1e-3 of its norm, which is a property of ReLU, not of either
-    implementation;
+    implementation -- AND, with nothing overwritten, the GPU's gradients are held to the oracle's backward under its
+    OWN decisions, the allowance being exactly what the disagreeing activations contribute (the difference of the
+    oracle's two backward passes);
   * the Adam kernel itself on ALL elements: float64 Adam applied on the host to the GPU's own gradient reproduces
     the GPU's parameters to 2e-7.
 """
@@ -71,10 +74,13 @@ def _adam64(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     return p - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
 
 
-def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefetch=False):
+def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefetch=False, module=False):
+    """module=True: the step is issued by the reference's loop body on the drop-in classes (GCN.forward,
+    nn.CrossEntropyLoss, loss.backward(), optim.Adam.step(): gist_amd/module_engine.py) instead of
+    SageEngine.train_step -- same plan, three phase calls."""
     from gist_amd import hip
     from gist_amd.engine import SageEngine, dims_for
-    from gist_amd.sampler import EngineClusterIter
+    from gist_amd.sampler import ClusterIter, EngineClusterIter
     from oracle import gist_oracle as O
     from oracle import train_oracle as TO
     prev = hip.gemm_mode()
@@ -82,12 +88,28 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
     try:
         g = ds.g
         random.seed(seed)
-        it = EngineClusterIter(ds.name, g, len(ds.par_li), batch_parts,
-                               np.arange(g.number_of_nodes(), dtype=np.int64),
-                               par_li=[p.copy() for p in ds.par_li], device=DEV)
+        it = (ClusterIter if module else EngineClusterIter)(
+            ds.name, g, len(ds.par_li), batch_parts, np.arange(g.number_of_nodes(), dtype=np.int64),
+            par_li=[p.copy() for p in ds.par_li], device=DEV)
         F_, C_ = g.ndata['feat'].shape[1], ds.num_classes
         dims = dims_for(F_, hidden, C_, n_layers)
-        eng = SageEngine(dims, True, P_DROP, it.n_max, DEV, seed=seed + 11)
+        me = model = optimizer = loss_f = None
+        if module:
+            import torch.nn.functional as F
+            from gist_amd import module_engine
+            from gist_amd.modules import GCN
+            from gist_amd.nn import CrossEntropyLoss
+            from gist_amd.optim import Adam
+            model = GCN(F_, hidden, C_, n_layers, F.relu, P_DROP, True, False, False, 1, True).cuda()
+            model.set_dropout_seed(seed + 11)
+            loss_f, optimizer = CrossEntropyLoss(), Adam(model.parameters(), lr=LR, weight_decay=0.0)
+            assert it.feed()
+            me = module_engine.ModuleEngine(model, it)
+            model.__dict__['_module_engines'] = {id(it): me}
+            me.engine.prefetch = prefetch
+            eng = me.engine
+        else:
+            eng = SageEngine(dims, True, P_DROP, it.n_max, DEV, seed=seed + 11)
         assert eng.fuse                                   # the fused sequence: what bench.py times
         rs = np.random.RandomState(seed)
         params = []
@@ -95,22 +117,43 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
             s = 1.0 / np.sqrt(2 * i)
             params.append((rs.uniform(-s, s, (o, 2 * i)).astype(np.float32),
                            rs.uniform(-s, s, o).astype(np.float32)))
-        it.bind(eng)
-        eng.prefetch = prefetch                           # (what bench.py and the trainers run at the narrow widths)
+        if not module:
+            it.bind(eng)
+            eng.prefetch = prefetch                       # (what bench.py and the trainers run at the narrow widths)
         assert eng.plan is not None                       # native step driver (gist_sage_step)
         tg = TO.TrainGraph(g.rowptr.numpy().astype(np.int64), g.col.numpy().astype(np.int64),
                            g.ndata['feat'].numpy(), g.ndata['label'].numpy().astype(np.int64))
         opt = O.new_opt_state(params)
-        report, flips = [], []
+        report, flips, logit_stats = [], [], []
         for j, batch in enumerate(it):
             _teacher_force(eng, params, opt)
             before = [(W.copy(), b.copy()) for (W, b) in params]
             m_before = [(a.copy(), b.copy()) for (a, b) in opt['m']]
             v_before = [(a.copy(), b.copy()) for (a, b) in opt['v']]
             off = eng.drop_calls
-            loss = eng.train_step(batch, LR, 0.0)
-            n = batch.n
-            logits = eng.logits(n).cpu().numpy()
+            if module:
+                m_, v_ = me.flat_state(optimizer)
+                m_.copy_(eng.arena.exp_avg)
+                v_.copy_(eng.arena.exp_avg_sq)
+                optimizer.step_count = int(opt['step'])
+                cluster = batch.to(torch.cuda.current_device())      # cluster_gcn/cluster_gcn.py:96-105, verbatim
+                model.train()
+                pred = model(cluster)
+                batch_labels = cluster.ndata['label']
+                batch_train_mask = cluster.ndata['train_mask']
+                loss = loss_f(pred[batch_train_mask], batch_labels[batch_train_mask])
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                assert type(loss).__name__ == 'StepLoss' and me.state == 0      # (the fused phases ran, all three)
+                n = cluster.number_of_nodes()
+                logits = pred.detach().cpu().numpy()
+                rowptr_now = it.batcher.rowptr[:n + 1]
+            else:
+                loss = eng.train_step(batch, LR, 0.0)
+                n = batch.n
+                logits = eng.logits(n).cpu().numpy()
+                rowptr_now = batch.rowptr
             # the masks of this step, rebuilt on the host
             masks, o_ = [], off
             for (i, o) in dims:
@@ -127,11 +170,13 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
                 assert np.array_equal(it.batcher.rowptr[:len(nb[0])].cpu().numpy(), nb[0])
                 assert np.array_equal(it.batcher.col[:len(nb[1])].cpu().numpy(), nb[1])
             else:
-                assert np.array_equal(batch.rowptr.cpu().numpy(), b[0])
+                assert np.array_equal(rowptr_now.cpu().numpy(), b[0])
             # the oracle's step, composed from its own parts (O.train_step's body) so that the ReLU decision of the
             # handful of LayerNorm outputs WITHIN ROUNDING OF ZERO can follow the GPU's: everywhere else the two
             # ReLU masks must agree, and the ambiguous elements are counted
             ref_logits, caches = O.gcn_forward(b[0], b[1], b[4], params, True, drop_masks=masks, drop_p=P_DROP)
+            own_out = [c['out'].copy() if 'out' in c else None for c in caches]      # the oracle's OWN ReLU decisions
+            step_flips = 0
             for k in range(len(dims) - 1):
                 i_next = dims[k + 1][0]
                 pos_gpu = (eng.Z[k + 1][:n, :i_next] > 0)
@@ -147,18 +192,37 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
                 assert np.abs(yhat[differ]).max(initial=0.0) < 4e-6, (j, k, float(np.abs(yhat[differ]).max()))
                 assert int(differ.sum()) <= 8, (j, k, int(differ.sum()))
                 flips.append(int(differ.sum()))
+                step_flips += int(differ.sum())
                 out = caches[k]['out']
                 out[differ & pos_gpu] = np.float32(1e-30)          # backward reads only (out > 0)
                 out[differ & ~pos_gpu] = 0.0
             ref_loss, dlog = O.cross_entropy(ref_logits, b[5])
             ref_grads = O.gcn_backward(caches, dlog, b[2], b[3])
+            if step_flips:
+                # Second statement, with NOTHING overwritten: the oracle's backward under its OWN ReLU decisions.  The
+                # GPU's gradients may differ from it by what the disagreeing activations contribute -- measured on the
+                # oracle itself as the difference between its two backward passes -- plus the usual rounding bar.
+                for c, o in zip(caches, own_out):
+                    if o is not None:
+                        c['out'] = o
+                own_grads = O.gcn_backward(caches, dlog, b[2], b[3])
+                for k in range(len(dims)):
+                    for gg, g_own, g_forced in ((eng.arena.dW[k].cpu().numpy(), own_grads[k][0], ref_grads[k][0]),
+                                                (eng.arena.db[k].cpu().numpy(), own_grads[k][1], ref_grads[k][1])):
+                        nrm = lambda a: float(np.linalg.norm(a.astype(np.float64)))
+                        assert nrm(gg - g_own) <= 2e-5 * nrm(g_own) + 1.01 * nrm(g_forced - g_own), (j, k, step_flips)
             opt['step'] += 1
             for k, ((W, bb), (dW, db)) in enumerate(zip(params, ref_grads)):
                 O.adam_step(W, dW, opt['m'][k][0], opt['v'][k][0], opt['step'], LR)
                 O.adam_step(bb, db, opt['m'][k][1], opt['v'][k][1], opt['step'], LR)
             t = opt['step']
             assert abs(float(loss.item()) - float(ref_loss)) < TOL * max(1.0, abs(float(ref_loss))), (j, float(loss.item()), ref_loss)
-            assert np.abs(logits - ref_logits).max() <= TOL * max(1.0, np.abs(ref_logits).max()), j
+            # every row of the logits against ITS OWN size (not the batch's largest logit: in the H = 4096 transient
+            # they reach ~100), and the absolute maximum on record
+            row_ref = np.maximum(1.0, np.abs(ref_logits).max(axis=1))
+            row_err = np.abs(logits - ref_logits).max(axis=1)
+            assert (row_err <= TOL * row_ref).all(), (j, float((row_err / row_ref).max()))
+            logit_stats.append((float(row_err.max()), float(np.abs(ref_logits).max()), float((row_err / row_ref).max())))
             got_p = eng.arena.export()
             worst_rel, ill, n_all = 0.0, 0, 0
             for k in range(len(dims)):
@@ -188,15 +252,20 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
             report.append((j, float(ref_loss), worst_rel, ill / float(n_all)))
             if j == n_steps - 1:
                 break
+        print('timed-step parity h=%d L=%d: max |logit error| %.3g absolute (largest |logit| %.3g), %.3g of the row\'s own '
+              'size; ReLU decisions that differ from the oracle\'s: %d in %d steps; worst gradient rel. L2 %.2g'
+              % (hidden, n_layers, max(a for a, _, _ in logit_stats), max(b_ for _, b_, _ in logit_stats),
+                 max(c for _, _, c in logit_stats), sum(flips), len(report), max(r[2] for r in report)))
         return report
     finally:
         hip.gemm_mode(prev)
 
 
-@pytest.mark.parametrize('hidden', [4096, 512])
+@pytest.mark.parametrize('hidden', [4096, 2048, 1024, 512])
 def test_config3_timed_step_dropout_teacher_forced(hidden):
     """BASELINE config 3: the default bench workload (Reddit-like, L=2, H=4096: kept bf16x3 splits, block-dense
-    aggregation) and the per-rank width of its 8-GPU point (512: convert-on-load bf16x3 + fp32 kernels, LDS gather)."""
+    aggregation) and the per-rank widths of its 2-, 4- and 8-GPU points (2048: kept splits; 1024 -- config 3's own S = 4 --
+    and 512: convert-on-load bf16x3 + fp32 kernels, LDS gather)."""
     from gist_amd import datasets
     rep = _run(datasets.reddit_synth(seed=0), 20, hidden, 2, 5, seed=3)
     assert len(rep) == 5
@@ -209,6 +278,17 @@ def test_config2_timed_step_dropout_teacher_forced(prefetch):
     from gist_amd import datasets
     rep = _run(datasets.reddit_synth(seed=0), 20, 256, 4, 5, seed=4, prefetch=prefetch)
     assert len(rep) == 5
+
+
+@pytest.mark.parametrize('hidden,n_layers,prefetch', [(512, 2, True), (4096, 2, False), (256, 4, True)])
+def test_module_path_timed_step_dropout_teacher_forced(hidden, n_layers, prefetch):
+    """The SAME statements through the drop-in module path (north_star: "training scripts and GraphSAGE module API are
+    drop-in unchanged"): the reference's loop body on gist_amd.modules.GCN / nn.CrossEntropyLoss / optim.Adam /
+    sampler.ClusterIter, dropout 0.2, default GEMM mode, teacher-forced against the oracle -- config 3's 8-GPU per-rank
+    width, the metric's H = 4096, config 2."""
+    from gist_amd import datasets
+    rep = _run(datasets.reddit_synth(seed=0), 20, hidden, n_layers, 3, seed=3, prefetch=prefetch, module=True)
+    assert len(rep) == 3
 
 
 def test_config3_per_rank_width_with_prefetched_batches():
