@@ -73,7 +73,13 @@ def parse():
                          'H=32768 over 8 GPUs, or with --gpus 1 the per-rank sub-GCN (width 4096) plus the '
                          'H=32768 S=8 weight exchange measured with 8 base replicas on this GPU.  Explicit '
                          '--n-hidden / --n-layers / --dataset / --batch-parts / --iter-per-site override a preset')
-    ap.add_argument('--dataset', choices=['reddit-synth', 'amazon-synth'], default=None)
+    ap.add_argument('--dataset', choices=['reddit-synth', 'amazon-synth', 'reddit-communities'], default=None,
+                    help='reddit-communities: Reddit-sized graph with power-law communities (30-400 nodes, mixing 0.3, random node '
+                         'ids): NO planted parts -- implies --partition own')
+    ap.add_argument('--partition', choices=['planted', 'own'], default=None,
+                    help='planted: the block model\'s own blocks stand in for the METIS parts (default on the block models); own: '
+                         'the parts come from gist_partition_graph (the reference\'s cache-miss path, cluster_gcn/sampler.py:49-51)')
+    ap.add_argument('--psize', type=int, default=None, help='number of parts with --partition own (default: as many as planted / 1500)')
     ap.add_argument('--batch-parts', type=int, default=None, help='METIS parts per cluster batch')
     ap.add_argument('--n-hidden', type=int, default=None)
     ap.add_argument('--n-layers', type=int, default=None)
@@ -124,6 +130,10 @@ def parse():
             setattr(args, k, v)
     if args.config == 2 and n != 1:
         ap.error('--config 2 is the single-GPU baseline (cluster_gcn.py): use --gpus 1')
+    if args.partition is None:
+        args.partition = 'own' if args.dataset == 'reddit-communities' else 'planted'
+    if args.dataset == 'reddit-communities' and args.partition != 'own':
+        ap.error('reddit-communities has no planted k-way partition: --partition own')
     return args
 
 
@@ -477,8 +487,8 @@ def shared_dataset(name, local_rank, world, wait_s=600.0):
     (dataset, seconds, 'built' | 'loaded' | 'built, N=1')."""
     from gist_amd import datasets
     t0 = time.time()
-    build = (lambda: datasets.reddit_synth(seed=0)) if name == 'reddit-synth' else \
-            (lambda: datasets.amazon_synth(seed=1))
+    build = {'reddit-synth': lambda: datasets.reddit_synth(seed=0), 'amazon-synth': lambda: datasets.amazon_synth(seed=1),
+             'reddit-communities': lambda: datasets.reddit_communities(seed=0)}[name]
     if world == 1:
         return build(), time.time() - t0, 'built, N=1'
     tag = _shared_tag(name)
@@ -612,6 +622,27 @@ def main():
     g = ds.g
     in_feats, n_classes = g.ndata['feat'].shape[1], ds.num_classes
     train_nid = np.arange(g.number_of_nodes(), dtype=np.int64)
+    partition_info = None
+    if args.partition == 'own':
+        # the parts the training loop runs on come from the library's partitioner, like a cache miss of the reference
+        # (every rank computes the same parts: the partitioner is a function of (graph, k, seed))
+        from gist_amd.dgl_compat.transform import partition_assignment
+        k_parts = args.psize or (1500 if args.dataset != 'amazon-synth' else 15000)
+        t_p = time.time()
+        assign = partition_assignment(g, k_parts, seed=0)
+        t_p = time.time() - t_p
+        order_ = np.argsort(assign, kind='stable')
+        bounds_ = np.searchsorted(assign[order_], np.arange(k_parts + 1))
+        own_parts = [order_[bounds_[i]:bounds_[i + 1]].astype(np.int64) for i in range(k_parts)]
+        sizes_ = np.diff(bounds_)
+        planted_sizes = np.array([len(p) for p in ds.par_li])
+        ds = ds._replace(par_li=own_parts)
+        partition_info = {'partitioner': 'gist_partition_graph (multilevel, host)', 'parts': k_parts, 'seconds': round(t_p, 2),
+                          'part_size_histogram': {'min': int(sizes_.min()), 'p05': int(np.percentile(sizes_, 5)),
+                                                  'median': int(np.median(sizes_)), 'p95': int(np.percentile(sizes_, 95)),
+                                                  'max': int(sizes_.max())},
+                          'ground_truth_groups': {'count': int(planted_sizes.size), 'size_min': int(planted_sizes.min()),
+                                                  'size_median': int(np.median(planted_sizes)), 'size_max': int(planted_sizes.max())}}
     psize, batch_size = len(ds.par_li), args.batch_parts
     STEPS_PER_EPOCH = psize // batch_size                      # sampler.py:54
     S = world
@@ -1150,7 +1181,9 @@ def main():
                 'workload': '%s synthetic (N_train=%d, F=%d, C=%d, %d parts, '
                             'batch=%d parts, %d steps/epoch); GraphSAGE n_hidden=%d n_layers=%d '
                             'LayerNorm dropout=%.2f Adam lr=0.01; %s' % (
-                                'Reddit-like' if args.dataset == 'reddit-synth' else 'Amazon-like',
+                                {'reddit-synth': 'Reddit-like block model', 'amazon-synth': 'Amazon-like block model',
+                                 'reddit-communities': 'Reddit-sized power-law community graph (no planted parts)'}[args.dataset]
+                                + (', parts from gist_partition_graph' if args.partition == 'own' else ', planted blocks as parts'),
                                 g.number_of_nodes(), in_feats, n_classes, psize, batch_size, STEPS_PER_EPOCH,
                                 H, L, args.dropout,
                                 ('ONE RANK of the %d-GPU GIST run of BASELINE config %d emulated on 1 GPU: its '
@@ -1211,7 +1244,8 @@ def main():
                 nnz[i] = int(bb.rowptr[bb.n].item())
             sp = prof['spmm']
             # aggregation launches per instrumented step: 2 (L + 1) - 1, one fewer when layer 0's is formed by the extraction
-            per_step = max(len(sp) // max(len(range(0, args.steps, every)), 1), 1)
+            n_instr = len(range(every // 2, args.steps, every))      # instrumented steps (as in gemm_roofline)
+            per_step = max(len(sp) // max(n_instr, 1), 1)
             s_ms = sum(ms for ms, _ in sp)
             s_bytes = 0.0
             for idx, (ms, (n, n_src, d)) in enumerate(sp):
@@ -1220,7 +1254,6 @@ def main():
             s_ach = s_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
             traffic, src = _traffic('spmm_traffic.json')
             copy_gbs = measured_copy_gbs(dev)
-            n_instr = len(range(0, args.steps, every))
             out['roofline_spmm'] = {
                 'kernel': ('gist::spmm_csr_mfma_kernel (block-dense, wide layers)' if H // S >= 1536 else 'gist::spmm_csr_lds2_kernel (LDS gather, wide layers)') + ("; the F=%d input layer's aggregation is formed by the batch extraction (no launch)" % in_feats if engine.plan is not None and engine.plan.feat_intra else '; gist::spmm_csr_rowsplit_kernel / spmm_csr_kernel for the F=%d input layer' % in_feats), 'bound': 'hbm', 'achieved': round(s_ach, 2),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(s_ach / HBM_PEAK_GBS, 4),
@@ -1234,6 +1267,28 @@ def main():
                 'mean_batch_rows': round(float(np.mean(n_log)), 1),
                 'mean_batch_nnz': round(float(nnz.mean()), 1),
             }
+        if partition_info is not None or os.environ.get('GIST_BENCH_BATCH_STATS'):
+            # what the aggregation kernels see: of a batch row's in-batch neighbours, the share inside the row's own part
+            # (the diagonal blocks) and the rows with more than 8 neighbours in the batch's OTHER parts (the block-dense
+            # kernel keeps 8 per row inline and walks the edges of the others again)
+            ins, tot, over8, rows_ = 0, 0, 0, 0
+            for ids in timed_ids[:8]:
+                n_b = ids.numel()
+                bb = it.batcher.extract(ids, engine.z0_left(n_b))
+                rp_ = bb.rowptr[:n_b + 1].cpu().numpy().astype(np.int64)
+                cl_ = bb.col[:int(rp_[-1])].cpu().numpy().astype(np.int64)
+                po_ = it._node_part[:, 0][ids.long()].cpu().numpy()
+                row_ = np.repeat(np.arange(n_b), np.diff(rp_))
+                same = po_[row_] == po_[cl_]
+                ins += int(same.sum()); tot += same.size
+                over8 += int((np.bincount(row_[~same], minlength=n_b) > 8).sum()); rows_ += n_b
+            batch_stats = {'in_batch_edges_inside_the_rows_part': round(ins / max(tot, 1), 4),
+                           'rows_with_more_than_8_neighbours_in_other_parts': round(over8 / max(rows_, 1), 4),
+                           'sampled_batches': min(len(timed_ids), 8),
+                           'blocked_aggregation': bool(it.locality is not False), 'locality_stats': it.locality_stats}
+            out['batch_locality'] = batch_stats
+        if partition_info is not None:
+            out['partition'] = partition_info
         out.update(legs)
         if world == 1 and not args.no_cpu_baseline:
             try:

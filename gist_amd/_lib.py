@@ -35,6 +35,7 @@ SIGNATURES = {
     'gist_device_count': (_int, []),
     'gist_in_degree_norm_f32': (_int, [_p, _i64, _p, _p]),
     'gist_spmm_csr_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p]),
+    'gist_partition_last_stats': (_int, [_p, _i32]),
     'gist_partition_graph': (_int, [_p, _p, _p, _p, _i64, _i32, _u64, _i32, _f, _p]),
     'gist_spmm_csr_blocked_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _p]),
     'gist_spmm_blocks_bytes': (_i64, [_i64]),
@@ -131,7 +132,7 @@ SIGNATURES = {
 
 GIST_MAX_LAYERS = 16
 TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_splits': 4,
-        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9, 'gemm_dual': 10}
+        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9, 'gemm_dual': 10, 'host_threads': 11}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 GIST_STEP_EXTRACT_NEXT = 4

@@ -132,6 +132,67 @@ def load_arrays(directory):
     return Dataset(num_classes=int(meta[0]), g=g, par_li=par_li, name=name)
 
 
+def community_edges(n, size_lo, size_hi, exponent, out_deg, mixing, hub_frac, hub_mult, seed):
+    """A graph whose parts are NOT planted for the partitioner: communities with power-law sizes in [size_lo, size_hi]
+    (density ~ s^-exponent), every node sending out_deg (x hub_mult for hubs) edge stubs, a stub staying inside the node's
+    community with probability 1 - mixing and going to a uniformly random node otherwise (the LFR benchmark's mixing
+    parameter); symmetrised, one self loop per node; node ids are a random permutation (they say nothing about the
+    communities).  Returns (src, dst, communities as lists of node ids)."""
+    rs = np.random.RandomState(seed)
+    sizes = []
+    left = n
+    a = 1.0 - exponent
+    while left > 0:
+        u = rs.random_sample()
+        sz = int(((size_hi ** a - size_lo ** a) * u + size_lo ** a) ** (1.0 / a))      # inverse CDF of s^-exponent
+        sz = min(max(sz, size_lo), size_hi, left)
+        if left - sz < size_lo and left - sz > 0:
+            sz = left
+        sizes.append(sz)
+        left -= sz
+    sizes = np.array(sizes, np.int64)
+    n_comm = sizes.shape[0]
+    starts = np.zeros(n_comm + 1, np.int64)
+    np.cumsum(sizes, out=starts[1:])
+    comm_of = np.repeat(np.arange(n_comm), sizes)                 # in "community order" ...
+    perm = rs.permutation(n).astype(np.int64)                     # ... which the node ids do not follow
+    mult = np.ones(n, np.int64)
+    n_hub = int(n * hub_frac)
+    if n_hub:
+        mult[rs.choice(n, n_hub, replace=False)] = hub_mult
+    pos = np.repeat(np.arange(n, dtype=np.int64), out_deg * mult)
+    inside = rs.random_sample(pos.shape[0]) >= mixing
+    c = comm_of[pos]
+    dst_pos = np.where(inside, starts[c] + (rs.random_sample(pos.shape[0]) * sizes[c]).astype(np.int64),
+                       rs.randint(0, n, pos.shape[0]).astype(np.int64))
+    s_, d_ = perm[pos], perm[dst_pos]
+    nodes = np.arange(n, dtype=np.int64)
+    src = np.concatenate([s_, d_, nodes])
+    dst = np.concatenate([d_, s_, nodes])
+    comms = [np.sort(perm[starts[q]:starts[q + 1]]) for q in range(n_comm)]
+    return src, dst, comms
+
+
+def community_dataset(name, n, n_feats, n_classes, seed, size_lo=30, size_hi=400, exponent=2.0, out_deg=48, mixing=0.3,
+                      hub_frac=0.01, hub_mult=10):
+    """Dataset over community_edges (all nodes are training nodes).  `par_li` holds the COMMUNITIES -- a reference point
+    for quality, NOT a balanced k-way partition: training on this graph partitions it first (gist_partition_graph /
+    dgl_compat.transform.metis_partition, like the reference's cache miss, cluster_gcn/sampler.py:49-51)."""
+    src, dst, comms = community_edges(n, size_lo, size_hi, exponent, out_deg, mixing, hub_frac, hub_mult, seed)
+    g = Graph.from_edges(src, dst, n)
+    gen = torch.Generator().manual_seed(seed)
+    g.ndata['feat'] = torch.randn(n, n_feats, generator=gen)
+    g.ndata['label'] = torch.randint(0, n_classes, (n,), generator=gen)
+    ones = torch.ones(n, dtype=torch.bool)
+    g.ndata['train_mask'], g.ndata['val_mask'], g.ndata['test_mask'] = ones, ~ones, ~ones
+    return Dataset(num_classes=n_classes, g=g, par_li=comms, name=name)
+
+
+def reddit_communities(seed=0, n=153431):
+    """Reddit-sized (N, F, C, mean degree as reddit-synth) with power-law communities of 30-400 nodes, mixing 0.3."""
+    return community_dataset('reddit-communities', n, 602, 41, seed)
+
+
 def reddit_synth(seed=0, n=153431, n_blocks=1500, train_frac=1.0):
     return make_block_dataset('reddit-synth', n, n_blocks, 602, 41, intra_deg=28, inter_deg=20,
                               seed=seed, train_frac=train_frac)

@@ -158,13 +158,23 @@ int gist_spmm_block_units_f32(const int32_t *units, int64_t n_units, const void 
 /* k-way partition of a graph: the stand-in for dgl.transform.metis_partition
  * (cluster_gcn/partition_utils.py:11-18; METIS is not available offline).  rowptr/col: in-edge
  * CSR, t_rowptr/t_col: out-edge CSR (may be NULL for a symmetric graph); neighbours are the
- * union.  Restreaming linear-deterministic-greedy: BFS-ordered placement, then n_passes
- * refinement sweeps; every part holds at most ceil((1 + imbalance) * n / k) nodes and none is
- * empty.  part[v] in [0, k).  Deterministic for a given seed.  One-time preparation whose
- * result ClusterIter caches in the reference's ../data/{dataset}_{psize}.npy format. */
+ * union.  Multilevel (round 5): size-constrained label-propagation coarsening (chunked: the edge scans of a
+ * chunk of the visiting order run on the host's worker threads, moves are applied in order: the result is a
+ * function of (graph, k, seed) alone), greedy initial partition of the coarsest level, and per level while
+ * uncoarsening n_passes strict-gain sweeps + localised k-way Fiduccia-Mattheyses searches with rollback (negative-gain
+ * moves allowed, the best prefix kept); every part holds at most ceil((1 + imbalance) * n / k) nodes, at least
+ * floor((1 - imbalance) * n / k) where the graph allows it, and none is empty.  part[v] in [0, k).  One-time
+ * preparation whose result ClusterIter caches in the reference's ../data/{dataset}_{psize}.npy format.
+ * Measured (profiles/r05_partitioner.json): the planted cut on the block models (153 k nodes / 1 500 parts in 2.6 s,
+ * 1.71 M / 15 000 in ~10 s on 8 cores), 1.21 x the ideal cut on a torus mesh, below a partition built from the
+ * ground-truth communities on a power-law community graph. */
 int gist_partition_graph(const int32_t *rowptr, const int32_t *col,
                          const int32_t *t_rowptr, const int32_t *t_col, int64_t n, int32_t k,
                          uint64_t seed, int32_t n_passes, float imbalance, int32_t *part);
+/* Wall seconds of the stages of the LAST gist_partition_graph call of this process: [0] input graph, [1] clustering,
+ * [2] contraction, [3] visiting orders, [4] initial partition + refinement of the coarse levels, [5] refinement of the
+ * input level, [6] balance repair, [8] number of levels, [9] vertices of the coarsest level (ABI 14; host function). */
+int gist_partition_last_stats(double *out, int32_t n);
 
 /* ---------------------------------------------------------------------------
  * Dense projection (fp32 MFMA, exact fp32 arithmetic)
@@ -254,7 +264,8 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
 #define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off), 2 = its dW slabs as their own launch (not in the LayerNorm backward's grid) */
 #define GIST_TUNE_GEMM_DUAL 10    /* backward of a narrow hidden layer: 1 = dZ and dW as two launches (gist_gemm_nn_tn_dual_f32 off) */
-#define GIST_TUNE_COUNT 11
+#define GIST_TUNE_HOST_THREADS 11 /* worker threads of the host partitioner (0 = the container's CPU quota, at most 32); its RESULT does not depend on it */
+#define GIST_TUNE_COUNT 12
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
 

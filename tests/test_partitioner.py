@@ -99,7 +99,9 @@ def test_partition_without_planted_structure():
     part = partition_assignment(g, k, seed=0)
     sizes = np.bincount(part, minlength=k)
     assert sizes.min() >= int(0.97 * W * W / k) and sizes.max() <= int(np.ceil(1.03 * W * W / k))
-    assert 1 - _intra_fraction(g, part) < 0.25             # 12 x 12 squares would cut 0.083; random 0.98
+    # 12 x 12 squares cut 0.0833 (the ideal); random 0.98.  Round 5 (Fiduccia-Mattheyses searches with rollback while
+    # uncoarsening): within 1.3 x of the ideal (measured 0.1006 = 1.21 x; round 4, strict-gain sweeps only: ~2 x)
+    assert 1 - _intra_fraction(g, part) < 0.11
     rs = np.random.RandomState(0)
     n = 8000
     deg = np.minimum((rs.pareto(1.5, n) * 3 + 2).astype(int), 300)
@@ -111,6 +113,56 @@ def test_partition_without_planted_structure():
     sizes = np.bincount(part, minlength=k)
     assert sizes.min() >= int(0.97 * n / k) and sizes.max() <= int(np.ceil(1.03 * n / k))
     assert 1 - _intra_fraction(g, part) < 0.95 * (1 - 1.0 / k)
+
+
+def test_partition_does_not_depend_on_the_thread_count():
+    """The coarsening and the sweeps run their edge scans on a pool of host threads; the RESULT is a function of
+    (graph, k, seed) alone: 1, 3 and 8 threads give the same parts."""
+    from gist_amd import hip
+    ds = datasets.make_block_dataset('t', 20000, 160, 4, 3, intra_deg=10, inter_deg=6, seed=11)
+    parts = []
+    try:
+        for t in (1, 3, 8):
+            hip.tuning('host_threads', t)
+            parts.append(partition_assignment(ds.g, 160, seed=2))
+    finally:
+        hip.tuning('host_threads', 0)
+    assert np.array_equal(parts[0], parts[1]) and np.array_equal(parts[0], parts[2])
+
+
+def test_power_law_communities_without_planted_parts():
+    """A graph whose good parts are NOT handed over: communities with power-law sizes (30-400 nodes, mixing 0.3, random
+    node ids), to be cut into balanced parts of ~100 -- half of the nodes sit in communities too large for one part.
+    Reference points: a random partition, and a partition BUILT FROM THE GROUND TRUTH (every community cut into
+    near-equal pieces that fit, the pieces bin-packed).  The partitioner must beat the second."""
+    ds = datasets.community_dataset('c', 24000, 4, 3, seed=5)
+    g, n, k = ds.g, 24000, 240
+    part = partition_assignment(g, k, seed=0)
+    sizes = np.bincount(part, minlength=k)
+    cap = int(np.ceil(1.03 * n / k))
+    assert sizes.max() <= cap and sizes.min() >= int(0.97 * n / k)
+    rs = np.random.RandomState(0)
+    pieces = []
+    for ids in ds.par_li:
+        s, p = len(ids), int(np.ceil(len(ids) / cap))
+        ids = rs.permutation(ids)
+        pieces += [ids[q * s // p:(q + 1) * s // p] for q in range(p)]
+    pieces.sort(key=len, reverse=True)
+    truth, fill = np.empty(n, np.int64), np.zeros(k, np.int64)
+    for pc in pieces:
+        cand = np.flatnonzero(fill + len(pc) <= cap)
+        while len(pc):
+            b = cand[np.argmax(fill[cand])] if len(cand) else int(np.argmin(fill))
+            take = pc[:cap - fill[b]]
+            truth[take], fill[b], pc, cand = b, fill[b] + len(take), pc[len(take):], np.zeros(0, np.int64)
+    cut_ours, cut_truth = 1 - _intra_fraction(g, part), 1 - _intra_fraction(g, truth)
+    comm = np.empty(n, np.int64)
+    for q, ids in enumerate(ds.par_li):
+        comm[ids] = q
+    cut_floor = 1 - _intra_fraction(g, comm)                # the communities themselves: not balanced, not k parts
+    assert 0.25 < cut_floor < 0.35
+    assert cut_ours <= cut_truth, (cut_ours, cut_truth, cut_floor)
+    assert cut_ours < 0.62 * (1 - 1.0 / k)                  # (a random partition cuts 1 - 1/k)
 
 
 def test_partition_cache_formats_load(tmp_path):
