@@ -25,7 +25,10 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int DB_ROWS = 128;                    // = MF_ROWS of spmm_mfma.hip (the prepared image's row count)
-constexpr int DB_REM = 8;                       // = MF_REM
+#ifndef MF_REM_N
+#define MF_REM_N 8
+#endif
+constexpr int DB_REM = MF_REM_N;                // = MF_REM
 constexpr int DB_PREP_STRIDE = 16 * DB_ROWS * 16 + DB_ROWS * 4 + DB_ROWS * DB_REM * 4;      // = MF_PREP_STRIDE
 
 struct D32Args {

@@ -19,9 +19,9 @@
 //   once:   the block's counts -> LDS, [k chunk][row][8 k] bf16: one flat pass over the block's edges
 //           (all loads of a thread in flight, row of an edge by binary search in the row pointers,
 //           LDS atomics on 16-bit counters), converted in place; per row the ids of its neighbours
-//           outside the block (up to 8, restored to CSR order; a row with more of them, with a count
-//           > 256, or beyond the 128 rows a block may stage is gathered from memory in full instead:
-//           hubs, oversized blocks)
+//           outside the block (up to 8, restored to CSR order; a row with more of them walks its edge list for
+//           them in the epilogue, its in-block edges stay in the dense product; a row with a count > 256 or
+//           beyond the 128 rows a block may stage is gathered from memory in full instead: oversized blocks)
 //   tile:   X_p tile [rows x 128] -> registers (4 x 16-byte loads per thread, issued one tile ahead,
 //           branch-free) -> x src_scale -> three bf16 pieces -> LDS as X^T, [k chunk][column & 3]
 //           [column >> 2][8 k]: both MFMA operands are then one conflict-free ds_read_b128 per lane
@@ -59,7 +59,10 @@ constexpr int MF_WAVES = MF_THREADS / 64;
 constexpr int MF_CHUNK_SLOTS = 4 * 36;
 constexpr int MF_PIECE = 16 * MF_CHUNK_SLOTS * 16;
 constexpr int MF_YT_PITCH = 132;                   // floats; the fp32 result tile aliases the X^T image
-constexpr int MF_REM = 8;                          // outside neighbours listed per row
+#ifndef MF_REM_N      // (dev A/B: -DMF_REM_N=...)
+#define MF_REM_N 8
+#endif
+constexpr int MF_REM = MF_REM_N;                   // outside neighbours listed per row
 constexpr int MF_A_OFF = 3 * MF_PIECE;             // counts, [k chunk 16][row 128][8 k] bf16
 constexpr int MF_RP_OFF = MF_A_OFF + 16 * MF_ROWS * 16;          // int rowptr[132]
 constexpr int MF_REMC_OFF = MF_RP_OFF + 132 * 4;                 // int rem_cnt[128]  (-1: gather the whole row)
@@ -136,6 +139,39 @@ __device__ __forceinline__ void mf_gather_row(const MfArgs &a, int e0, int e1, i
     }
 }
 
+// the neighbours of one row OUTSIDE the block [r0, r0 + nloc), CSR order (a row whose outside neighbours do not fit the
+// per-row list: its in-block part stays in the dense product)
+__device__ __forceinline__ void mf_gather_row_outside(const MfArgs &a, int e0, int e1, int r0, int nloc, int lane, int gc,
+                                                      bool mine, float4 &v) {
+    for (int base = e0; base < e1; base += 64) {
+        const bool in = base + lane < e1;
+        const int ids = in ? a.col[base + lane] : 0;
+        unsigned long long m = __ballot(in && (ids < r0 || ids >= r0 + nloc));
+        while (m) {                                        // four row reads in flight, lowest lanes (= edge order) first
+            float4 rv[4];
+            float rs[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool on = m != 0ULL;                 // wave-uniform
+                const int l = on ? __builtin_ctzll(m) : 0;
+                if (on) m &= m - 1ULL;
+                const int g = __builtin_amdgcn_readlane(ids, l);
+                rs[t] = 0.f;
+                rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on) {
+                    rs[t] = a.src_scale ? a.src_scale[g] : 1.f;
+                    if (mine) rv[t] = *reinterpret_cast<const float4 *>(a.x + (int64_t)g * a.ldx + gc);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v.x = fmaf(rs[t], rv[t].x, v.x); v.y = fmaf(rs[t], rv[t].y, v.y);
+                v.z = fmaf(rs[t], rv[t].z, v.z); v.w = fmaf(rs[t], rv[t].w, v.w);
+            }
+        }
+    }
+}
+
 #ifdef MF_PROBE      // dev build (scripts/spmm_mf_phases.py): s_memrealtime (100 MHz) stamps of workgroup 0, wave 0
 __device__ unsigned long long g_mf_probe[64];
 #define MF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mf_probe[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -144,7 +180,8 @@ __device__ unsigned long long g_mf_probe[64];
 #endif
 
 // Edge counts of block [r0, r0 + nloc) as bf16 in `ab`, [k chunk][row][8 k], and per row its neighbours
-// outside the block (rem_cnt: how many, -1 = the row leaves the dense product and is gathered in full;
+// outside the block (rem_cnt: how many, -2 = more than the list holds: the epilogue walks the row's edges for them,
+// -1 = the row leaves the dense product and is gathered in full;
 // rem_col: their ids in CSR order).  All 1024 threads; `after_ids` is called once, right after the first
 // batch of id loads has been issued.
 template <typename F>
@@ -229,8 +266,14 @@ __device__ __forceinline__ void mf_build_block(const MfArgs &a, int r0, int nloc
     // with more than fit is gathered in full below
     if (tid < nloc) {
         const int cnt = rem_cnt[tid];
-        if (cnt > MF_REM || rp[tid + 1] - rp[tid] > 65535) {       // (65536 copies of an edge would wrap a counter)
+        if (rp[tid + 1] - rp[tid] > 65535) {       // (65536 copies of an edge would wrap a counter)
             rem_cnt[tid] = -1;
+        } else if (cnt > MF_REM) {
+            // (round 5) more outside neighbours than the list holds -- a row of a community cut into two parts of one batch
+            // has 30-80 of them: its in-block edges STAY in the dense product, the epilogue walks its edge list for the
+            // outside ones only (-1, the whole row gathered instead, cost 130-270 us per launch on every eighth batch of
+            // the power-law community graph: profiles/r05_unplanted_graph.json)
+            rem_cnt[tid] = -2;
         } else {
             for (int i = 1; i < cnt; ++i) {
                 const int e = rem_e[tid * MF_REM + i], c = rem_col[tid * MF_REM + i];
@@ -506,6 +549,8 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
                 if (rcnt[i] > 0) {
                     const int ids = lane < MF_REM ? rem_col[r * MF_REM + lane] : 0;
                     mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, rcnt[i], v[pp]);
+                } else if (rcnt[i] == -2) {
+                    mf_gather_row_outside(a, rp[r], rp[r + 1], r0, nloc, lane, gc, mine, v[pp]);
                 } else {
                     if (mine) v[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
                     mf_gather_row(a, rp[r], rp[r + 1], lane, gc, mine, v[pp]);

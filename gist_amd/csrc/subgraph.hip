@@ -288,9 +288,14 @@ constexpr int kPartsWaves = 16;
 // the hardware's range check -- no per-load address pairs, no clamping, straight-line code, and the kernel keeps the 64
 // registers that let two of these 1024-thread workgroups share a CU (with 64-bit addresses per load: 124).  Sums in edge
 // order.
-template <int NT, int RB>
+// n_remote > kRemote (round 5: a row of a community cut into two parts of one batch has 30-80 neighbours in the sibling
+// part, a hub among them hundreds): `refill(skip)` lists the next (at most kRemote) outside neighbours behind the first
+// `skip` into `rem` and returns how many -- the same register-resident accumulation, one more walk of the row's edge list
+// per 64 neighbours (a load / add loop per neighbour and 256-column piece cost 110-320 us per launch on every tenth batch
+// of the power-law community graph: profiles/r05_unplanted_graph.json).
+template <int NT, int RB, typename Refill>
 __device__ __forceinline__ void aggregate_row_regs(const PartsArgs &a, const int i, const int v_self, const int cnt,
-                                                   const int n_remote, const int32_t *rem, const int lane) {
+                                                   const int n_remote_all, const int32_t *rem, const int lane, Refill refill) {
     const float nrm = cnt > 0 ? 1.f / (float)cnt : 0.f;
     const int row_bytes = a.d * 4;
     auto row = [&](const float *base, int64_t ld, int r) {
@@ -305,6 +310,8 @@ __device__ __forceinline__ void aggregate_row_regs(const PartsArgs &a, const int
         for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t * 256, 0, 0));
     }
+    for (int done = 0; done < n_remote_all || done == 0;) {
+    const int n_remote = n_remote_all <= kRemote ? n_remote_all : refill(done);
     int k = 0;
     for (; k + RB <= n_remote; k += RB) {
         float u[RB][NT];
@@ -330,6 +337,9 @@ __device__ __forceinline__ void aggregate_row_regs(const PartsArgs &a, const int
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] += u[t];
         }
+    }
+    done += n_remote;
+    if (n_remote == 0) break;
     }
     float *__restrict__ o = a.ah + (int64_t)i * a.ldz0;
     const uint64_t i0 = a.gd.offset + (uint64_t)i * (uint64_t)a.gd.mask_ld + (uint64_t)a.d;      // mask index of ah[i][0]
@@ -460,13 +470,27 @@ __device__ __forceinline__ void extract_parts_block(const PartsArgs &a, const in
     // two barriers below (while wave 0 walks the look-back), wave 0 after them
     auto aggregate_row = [&]() {
         if (!live) return;
-        if (n_remote <= kRemote && a.d <= 16 * kWave) {      // (everything but hubs and very wide inputs)
+        if (a.d <= 16 * kWave) {                            // (everything but very wide inputs)
+            // the next <= kRemote outside neighbours behind the first `skip`, in edge order (another walk of the list)
+            auto refill = [&](int skip) {
+                int seen = 0;
+                for (int base = beg; base < end && seen < skip + kRemote; base += kWave) {
+                    int u, pt;
+                    const int r = new_id(base + lane, base + lane < end, u, pt);
+                    const bool x = r >= 0 && pt != my_part;
+                    const unsigned long long q = __ballot(x);
+                    const int pos = seen + __popcll(q & ((1ULL << lane) - 1ULL)) - skip;
+                    if (x && pos >= 0 && pos < kRemote) remote[wave][pos] = u;
+                    seen += __popcll(q);
+                }
+                return min(seen - skip, kRemote);
+            };
             const int nt = (a.d + kWave - 1) / kWave;
-            if (nt <= 2) aggregate_row_regs<2, 4>(a, i, v_self, cnt, n_remote, remote[wave], lane);
-            else if (nt <= 4) aggregate_row_regs<4, 4>(a, i, v_self, cnt, n_remote, remote[wave], lane);
-            else if (nt <= 8) aggregate_row_regs<8, 2>(a, i, v_self, cnt, n_remote, remote[wave], lane);
-            else if (nt <= 10) aggregate_row_regs<10, 2>(a, i, v_self, cnt, n_remote, remote[wave], lane);
-            else aggregate_row_regs<16, 1>(a, i, v_self, cnt, n_remote, remote[wave], lane);
+            if (nt <= 2) aggregate_row_regs<2, 4>(a, i, v_self, cnt, n_remote, remote[wave], lane, refill);
+            else if (nt <= 4) aggregate_row_regs<4, 4>(a, i, v_self, cnt, n_remote, remote[wave], lane, refill);
+            else if (nt <= 8) aggregate_row_regs<8, 2>(a, i, v_self, cnt, n_remote, remote[wave], lane, refill);
+            else if (nt <= 10) aggregate_row_regs<10, 2>(a, i, v_self, cnt, n_remote, remote[wave], lane, refill);
+            else aggregate_row_regs<16, 1>(a, i, v_self, cnt, n_remote, remote[wave], lane, refill);
             return;
         }
         const float nrm = cnt > 0 ? 1.f / (float)cnt : 0.f;

@@ -245,10 +245,17 @@ class ClusterIter(object):
             nnz = tg.number_of_edges()
             inside = intra / float(nnz)
             n_parts = max(len(self.par_li), 2)
-            outside_in_batch = (nnz - intra) / float(n_nodes) * (min(self.batch_size, n_parts) - 1) / (n_parts - 1)
+            share = (min(self.batch_size, n_parts) - 1) / float(n_parts - 1)      # of the OTHER parts, those in a row's batch
+            outside_in_batch = (nnz - intra) / float(n_nodes) * share
+            # of a batch row's neighbours INSIDE THE BATCH, the expected share in the row's own part: what the blocked kernels
+            # live on.  (Round 5: the gate used to ask for half of ALL the train graph's edges inside a part; a partition
+            # of a graph with mixing 0.3 and communities larger than a part keeps 0.48 of them, yet 0.99 of the IN-BATCH
+            # edges -- a batch holds 20 of 1500 parts -- and ran the ungrouped kernel at 2.1x the time: profiles/r05_unplanted_graph.json)
+            in_batch_inside = intra / max(intra + (nnz - intra) * share, 1.0)
             self.locality_stats = dict(edges_inside_parts=round(inside, 4),
+                                       in_batch_edges_inside_parts=round(in_batch_inside, 4),
                                        outside_neighbours_per_batch_row=round(outside_in_batch, 3))
-            self.locality = inside >= 0.5 and outside_in_batch <= 4.0
+            self.locality = in_batch_inside >= 0.8 and outside_in_batch <= 4.0
             if os.environ.get('GIST_SPMM_LOCALITY') in ('0', '1'):      # dev override
                 self.locality = os.environ['GIST_SPMM_LOCALITY'] == '1'
 

@@ -291,6 +291,23 @@ def test_module_path_timed_step_dropout_teacher_forced(hidden, n_layers, prefetc
     assert len(rep) == 3
 
 
+def test_unplanted_partition_timed_step_dropout_teacher_forced():
+    """A batch whose parts are NOT planted: a power-law community graph (sizes 30-400, mixing 0.3, random node ids) cut into
+    parts of ~100 by gist_partition_graph -- communities larger than a part are split, small ones share a part, a third of
+    a row's neighbours lie outside its part -- through the timed step (width 512, dropout 0.2, the next batch extracted
+    inside the optimiser launch), teacher-forced against the oracle like the planted configurations."""
+    from gist_amd import datasets
+    from gist_amd.dgl_compat.transform import partition_assignment
+    ds = datasets.community_dataset('communities', 30000, 602, 41, seed=3)
+    k = 300
+    assign = partition_assignment(ds.g, k, seed=0)
+    order = np.argsort(assign, kind='stable')
+    bounds = np.searchsorted(assign[order], np.arange(k + 1))
+    ds = ds._replace(par_li=[order[bounds[i]:bounds[i + 1]].astype(np.int64) for i in range(k)])
+    rep = _run(ds, 20, 512, 2, 3, seed=5, prefetch=True)
+    assert len(rep) == 3
+
+
 def test_config3_per_rank_width_with_prefetched_batches():
     """Config 3's 8-GPU per-rank width (512) as bench.py times it: every batch but the first extracted beside the
     previous step's optimiser launch."""
