@@ -1218,6 +1218,15 @@ def main():
                               'dataset_how': ('rank 0 %s the synthetic graph%s' % (
                                   dataset_how, '' if world == 1 else
                                   ' and wrote it to /dev/shm before any GPU call; the other %d ranks loaded it' % (world - 1)))},
+            # one-time work of a run that `value` does not contain, amortised over a run of the reference's default
+            # length (cluster_gcn/cluster_gcn.py:154: --n-epochs 40; per rank under GIST: 40 / S local epochs)
+            'amortised_over_a_40_epoch_run': (lambda ips, per_rank: {
+                'intra_part_sums_s': round(ips, 3),
+                'local_epochs_per_rank': 40 // world,
+                'value_with_that_second_spread_over_the_run': round(
+                    world * (40 // world) / ((40 // world) / per_rank + ips), 4) if per_rank > 0 else None,
+                'loss_of_value': round(1.0 - ((40 // world) / ((40 // world) / per_rank + ips)) / per_rank, 5) if per_rank > 0 else None,
+            })(getattr(it, 'intra_part_sums_seconds', 0.0), value / world),
             'backend': ('gloo, host-staged (validation)' if shared_gpu else 'nccl (RCCL)') if world > 1 else None,
             'per_rank_ms_per_step': [round(s / args.steps * 1e3, 4) for s in per_rank_s],
             'loss_first': round(loss_first, 5), 'loss_last': round(loss_last, 5),

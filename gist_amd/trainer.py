@@ -48,7 +48,8 @@ class FullGraphEvaluator(object):
     datasets do), else one gather pass over A (any graph); False = one gather pass."""
 
     def __init__(self, g, dims, use_layernorm, arena, device, row_block=None,
-                 block_bytes=4 << 30, node_blocks=None, pair_min_edges=300, cache_input_aggregation=True):
+                 block_bytes=4 << 30, node_blocks=None, pair_min_edges=300, cache_input_aggregation=True,
+                 pair_bytes=2 << 30):
         self.g = g if g.device == device else g.to(device)
         self.dims = [(int(i), int(o)) for i, o in dims]
         self.use_layernorm = bool(use_layernorm)
@@ -80,6 +81,7 @@ class FullGraphEvaluator(object):
         # A partition of a real graph cuts few block pairs heavily; the uniform block model cuts all pairs thinly
         # (10 edges per pair) and keeps the gathers.  0 = off.
         self.pair_min_edges = int(pair_min_edges) if os.environ.get('GIST_EVAL_PAIRS', '1') != '0' else 0
+        self.pair_bytes = int(pair_bytes)
         self.row_cuts = list(range(0, n, self.row_block)) + [n]
         hidden = max([o for (i, o) in self.dims[:-1]] + [1])
         self.h = [torch.empty(n, hidden, **f32) for _ in range(2 if L1 > 2 else 1)] if L1 > 1 else []
@@ -230,6 +232,12 @@ class FullGraphEvaluator(object):
             uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
             dense = cnt >= self.pair_min_edges
             stride = int(hip._lib.load().gist_spmm_block_image_bytes()) // 2      # bf16 elements per image
+            # the images stay in HBM for the evaluator's life (32 KiB per pair): at most pair_bytes of them, the heaviest
+            # pairs first; the others stay with the gathers
+            max_pairs = max(int(self.pair_bytes // (2 * stride)), 1)
+            if int(dense.sum().item()) > max_pairs:
+                thr = torch.topk(cnt[dense], max_pairs).values[-1]
+                dense = dense & (cnt >= thr)
             for _ in range(2):                         # (second round only if a pair had a count above 256)
                 if not bool(dense.any()):
                     break
@@ -252,16 +260,29 @@ class FullGraphEvaluator(object):
                 r_loc = er[e_dense] - bd[blk_of[er[e_dense]]]
                 k_loc = ec[e_dense] - bd[blk_of[ec[e_dense]]]
                 flat = p_e * 16384 + ((k_loc >> 3) * 128 + r_loc) * 8 + (k_loc & 7)
-                counts = torch.bincount(flat, minlength=n_pairs * 16384).view(n_pairs, 16384)
-                big = counts.max(1).values > 256       # not exact in bf16: back to the gathers
+                # the count images, 2048 pairs at a time (an int32 scatter-add into 128 MB of scratch: one bincount over all
+                # pairs was 128 KB of int64 per pair -- 2.4 GB in flight at 18 000 pairs; advisor, round 4)
+                images = torch.zeros(n_pairs, stride, dtype=torch.bfloat16, device=dev)
+                big = torch.zeros(n_pairs, dtype=torch.bool, device=dev)
+                eorder = torch.argsort(p_e)
+                flat_s, pe_s = flat[eorder], p_e[eorder]
+                ebounds = torch.searchsorted(pe_s, torch.arange(0, n_pairs + 2048, 2048, device=dev)).tolist()
+                one = torch.ones(1, dtype=torch.int32, device=dev)
+                for ci, p0 in enumerate(range(0, n_pairs, 2048)):
+                    p1 = min(n_pairs, p0 + 2048)
+                    cnt32 = torch.zeros((p1 - p0) * 16384, dtype=torch.int32, device=dev)
+                    sl = flat_s[ebounds[ci]:ebounds[ci + 1]] - p0 * 16384
+                    cnt32.index_add_(0, sl, one.expand(sl.numel()))
+                    cnt32 = cnt32.view(p1 - p0, 16384)
+                    big[p0:p1] = cnt32.max(1).values > 256       # not exact in bf16: back to the gathers
+                    images[p0:p1, :16384] = cnt32.to(torch.float32).to(torch.bfloat16)
+                    del cnt32
+                del flat, flat_s, pe_s, eorder
                 if bool(big.any()):
                     idx = torch.nonzero(dense).squeeze(1)[pos.argsort()[big]]
                     dense[idx] = False
-                    del counts
+                    del images
                     continue
-                images = torch.zeros(n_pairs, stride, dtype=torch.bfloat16, device=dev)
-                images[:, :16384] = counts.to(torch.float32).to(torch.bfloat16)
-                del counts, flat
                 rb_o, cb_o, j_o, ch_o = rb_p[order], cb_p[order], j_p[order], chunk_p[order]
                 base = cut_t[ch_o]
                 units = torch.stack([bd[rb_o] - base, bd[rb_o + 1] - base, bd[cb_o], bd[cb_o + 1]], 1).to(torch.int32).contiguous()
