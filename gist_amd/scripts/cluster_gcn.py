@@ -40,6 +40,9 @@ def build_parser():
     parser.add_argument("--use-layernorm", action='store_true')
     parser.add_argument("--use-f1", action='store_true')
     parser.add_argument("--eval-cpu", action='store_true')
+    # (not a flag of the reference) module: the reference's own loop body, statement for statement, on gist_amd.modules.GCN /
+    # nn.CrossEntropyLoss / optim.Adam / sampler.ClusterIter (gist_amd/module_engine.py); engine: one gist_sage_step per iteration
+    parser.add_argument("--host-path", choices=['engine', 'module'], default='engine')
     return parser
 
 
@@ -78,6 +81,8 @@ def main(args, dataset=None, log=print):
                 args.use_layernorm, False, False, 1, True)          # :66-69
         model_holder['m'] = m
         return m
+    if getattr(args, 'host_path', 'engine') == 'module':
+        return main_module_path(args, data, g, device, in_feats, n_classes, par_li, psize, log)
     trainer = ClusterGCNTrainer(args.dataset, g, par_li, psize, args.batch_size, args.n_hidden,
                                 args.n_layers, n_classes, args.dropout, args.use_layernorm,
                                 args.lr, args.weight_decay, device, seed=args.rnd_seed)
@@ -96,6 +101,53 @@ def main(args, dataset=None, log=print):
     log(f'Best Test: {max(test_accs):.4f}', flush=True)
     return dict(total_time=trainer.total_time, val_accs=val_accs, test_accs=test_accs,
                 model=model_holder['m'])
+
+
+def main_module_path(args, data, g, device, in_feats, n_classes, par_li, psize, log):
+    """cluster_gcn/cluster_gcn.py:24-136 on the drop-in classes: ClusterIter, GCN, CrossEntropyLoss, Adam, evaluate."""
+    import time
+    from gist_amd.modules import GCN
+    from gist_amd.nn import CrossEntropyLoss
+    from gist_amd.optim import Adam
+    from gist_amd.sampler import ClusterIter
+    from gist_amd.utils import evaluate
+    train_nid = np.nonzero(g.ndata['train_mask'].numpy())[0].astype(np.int64)
+    cluster_iterator = ClusterIter(args.dataset, g, psize, args.batch_size, train_nid, use_pp=args.use_pp,
+                                   par_li=par_li, device=device)                                      # :44-46
+    g = g.to(device)
+    labels, val_mask, test_mask = g.ndata['label'], g.ndata['val_mask'], g.ndata['test_mask']
+    model = GCN(in_feats, args.n_hidden, n_classes, args.n_layers, F.relu, args.dropout,
+                args.use_layernorm, False, False, 1, True)                                             # :66-69
+    model.cuda()
+    model.set_dropout_seed(args.rnd_seed)
+    loss_f = CrossEntropyLoss()                                                                        # :76
+    optimizer = Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)                   # :77-80
+    total_time, val_accs, test_accs = 0., [], []
+    for epoch in range(args.n_epochs):                                                                 # :89-127
+        log(f'Running epoch {epoch} / {args.n_epochs}', flush=True)
+        torch.cuda.synchronize(device)
+        start_time = time.time()
+        for j, cluster in enumerate(cluster_iterator):
+            cluster = cluster.to(torch.cuda.current_device())
+            model.train()
+            pred = model(cluster)
+            batch_labels = cluster.ndata['label']
+            batch_train_mask = cluster.ndata['train_mask']
+            loss = loss_f(pred[batch_train_mask], batch_labels[batch_train_mask])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        torch.cuda.synchronize(device)
+        total_time += time.time() - start_time
+        val_accs.append(evaluate(model, g, labels, val_mask, 'f1' if args.use_f1 else 'acc'))
+        test_accs.append(evaluate(model, g, labels, test_mask, 'f1' if args.use_f1 else 'acc'))
+        log(f'Val acc {val_accs[-1]}', flush=True)
+    log(f'Training Time: {total_time:.4f}', flush=True)                                                # :132-136
+    log(f'Last Val: {val_accs[-1]:.4f}', flush=True)
+    log(f'Best Val: {max(val_accs):.4f}', flush=True)
+    log(f'Last Test: {test_accs[-1]:.4f}', flush=True)
+    log(f'Best Test: {max(test_accs):.4f}', flush=True)
+    return dict(total_time=total_time, val_accs=val_accs, test_accs=test_accs, model=model)
 
 
 if __name__ == '__main__':

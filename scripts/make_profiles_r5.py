@@ -1,0 +1,209 @@
+"""Turn gpurun_out/final_r5 (scripts/final_profile_r5.sh) into the round-5 files under profiles/."""
+import collections, csv, json, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = os.path.join(ROOT, 'gpurun_out', 'final_r5')
+P = os.path.join(ROOT, 'profiles')
+TAG = 'r05'
+
+
+def last_json(path, key='{"metric"'):
+    return json.loads([l for l in open(path) if l.startswith(key)][-1])
+
+
+def short(name):
+    return re.sub(r'^void ', '', name.replace('(anonymous namespace)::', '')).split('(')[0]
+
+
+def clean(path):
+    return ''.join(l for l in open(path) if 'amdgpu.ids' not in l)
+
+
+# 1. bench lines: the default workload, the per-rank widths, one line per BASELINE config
+lines = {'bench_n1': last_json(os.path.join(F, 'bench_n1.log')),
+         'per_rank_width_emulation': {('n_hidden_%d' % h): last_json(os.path.join(F, 'bench_h%d.log' % h))
+                                      for h in (2048, 1024, 512)},
+         'baseline_configs': {'config_2': last_json(os.path.join(F, 'bench_cfg2.log')),
+                              'config_4_one_rank_of_8': last_json(os.path.join(F, 'bench_cfg4.log')),
+                              'config_5_one_rank_of_8_plus_exchange': last_json(os.path.join(F, 'bench_cfg5.log'))},
+         'note': 'bench.py on 1x MI355X, round 5, final code (scripts/final_profile_r5.sh).  bench_n1 = the default invocation '
+                 '(BASELINE config 3 at N = 1: Reddit-like, H = 4096, L = 2, GEMM mode bf16x3) incl. the CPU baseline over one full '
+                 'epoch; `f32_mfma` / `f16x3_split` = the same workload re-timed in the other GEMM modes, same process.  '
+                 'per_rank_width_emulation: `bench.py --n-hidden H/N --steps 300 --warmup 20` = the per-rank work of the N = 2/4/8 '
+                 'points of config 3 on one GPU (no collective).  baseline_configs: `bench.py --config 2 --steps 300`, `--config 4 '
+                 '--steps 600` (ONE rank of the 8-GPU run), `--config 5` (one rank of H = 32768 / 8 plus the H = 32768, S = 8 weight '
+                 'exchange measured with 8 base replicas on this GPU).  Multi-GPU numbers are the driver\'s.'}
+json.dump(lines, open(os.path.join(P, TAG + '_bench_lines.json'), 'w'), indent=1)
+
+# 2. kernel stats: default workload + the fused small-width steps + configs 2 and 4
+title = ('`python3 bench.py --no-cpu-baseline --no-second-leg` (150 steps + 10 warm-up, GEMM mode bf16x3 = the '
+         'default, 1x MI355X), round 5')
+ks = os.path.join(F, 'kstats', 'step_kernel_stats.csv')
+out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'profile_report.py'), ks,
+                      os.path.join(F, 'kstats_run.log'), title], capture_output=True, text=True, check=True).stdout
+open(os.path.join(P, TAG + '_bench_n1_kernel_stats.md'), 'w').write(out)
+open(os.path.join(P, TAG + '_bench_n1_kernel_stats.csv'), 'w').write(open(ks).read())
+for sub, what in (('h1024', '--n-hidden 1024'), ('h512', '--n-hidden 512'), ('cfg2', '--config 2'),
+                  ('cfg4', '--config 4')):
+    ks = os.path.join(F, 'kstats_' + sub, 'step_kernel_stats.csv')
+    d = last_json(os.path.join(F, 'kstats_%s.log' % sub))
+    rows = list(csv.DictReader(open(ks)))
+    steps = 220.0
+    step_rows = [r for r in rows if int(r['Calls']) >= 200]          # kernels of the training step
+    tot = sum(float(r['TotalDurationNs']) for r in step_rows)
+    txt = ['# rocprofv3 --kernel-trace --stats: `python3 bench.py %s --steps 200 --warmup 20 --no-second-leg '
+           '--no-cpu-baseline --no-kernel-timing`, 1x MI355X, round 5' % what, '',
+           'bench line of the profiled run: ms_per_step %.4f, value %.4f epochs/s' % (d['ms_per_step'], d['value']),
+           '', 'Kernels of the training step (called at least once per step): %.1f launches and %.1f us of kernel '
+           'time per step.' % (sum(int(r['Calls']) for r in step_rows) / steps, tot / steps / 1e3), '',
+           '| kernel | launches / step | avg us | us / step | % of step kernels |', '|---|---|---|---|---|']
+    for r in step_rows:
+        txt.append('| `%s` | %.2f | %.2f | %.2f | %.1f |' % (
+            short(r['Name'])[:90], int(r['Calls']) / steps, float(r['AverageNs']) / 1e3,
+            float(r['TotalDurationNs']) / steps / 1e3, 100.0 * float(r['TotalDurationNs']) / tot))
+    seq = os.path.join(F, 'seq_%s.txt' % sub)
+    if os.path.exists(seq):
+        txt += ['', 'The step launch by launch (scripts/step_seq.py on the same trace: median duration of every launch in stream '
+                'order; blank names = kernels in an anonymous namespace: the fused class layer `class_layer_kernel` [grid n/16 x 256] '
+                'and its `class_dw_kernel` [grid K/64 x n/128]; `gemm_f32_dual_kernel` = dZ and dW of a hidden layer in one launch):', '', '```'] + open(seq).read().rstrip().split('\n') + ['```']
+    open(os.path.join(P, '%s_step_kernels_%s.md' % (TAG, sub)), 'w').write('\n'.join(txt) + '\n')
+
+
+# 3. PMC tables
+def table(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        d[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    return d
+
+
+def traffic(fetch, write, kname):          # every instantiation whose name starts with kname
+    f = [x for k in fetch if k.startswith(kname) for x in fetch[k]['FETCH_SIZE']]
+    w = [x for k in write if k.startswith(kname) for x in write[k]['WRITE_SIZE']]
+    return dict(launches=len(f), FETCH_SIZE_KB_raw=round(sum(f) / len(f), 1),
+                WRITE_SIZE_KB=round(sum(w) / len(w), 1),
+                hbm_bytes_corrected=int((2 * sum(f) / len(f) + sum(w) / len(w)) * 1024))
+
+
+md = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), `bench.py --gemm-mode M --steps 20 '
+      '--warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing`, round 5', '',
+      'Raw counter averages per dispatch (KB). gfx950 correction: fabric read bytes = 2 x FETCH_SIZE for wide '
+      'coalesced streams (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact.', '']
+tables = {}
+for mode in ('bf16x3', 'f32'):
+    fetch = table(os.path.join(F, 'pmc_FETCH_SIZE_' + mode, 't_counter_collection.csv'))
+    write = table(os.path.join(F, 'pmc_WRITE_SIZE_' + mode, 't_counter_collection.csv'))
+    tables[mode] = (fetch, write)
+    rows = []
+    for k in fetch:
+        f = fetch[k]['FETCH_SIZE']
+        w = write.get(k, {}).get('WRITE_SIZE', [0.0])
+        rows.append((sum(f), k, len(f), sum(f) / len(f), sum(w) / max(len(w), 1)))
+    rows.sort(reverse=True)
+    md += ['## GEMM mode ' + mode + (' (the default)' if mode == 'bf16x3' else ''), '',
+           '| kernel | dispatches | FETCH_SIZE avg KB (raw) | WRITE_SIZE avg KB |', '|---|---|---|---|']
+    for tot, k, n, fa, wa in rows[:20]:
+        md.append('| `%s` | %d | %.1f | %.1f |' % (k, n, fa, wa))
+    md.append('')
+open(os.path.join(P, TAG + '_pmc_fetch_write.md'), 'w').write('\n'.join(md) + '\n')
+
+method = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --gemm-mode %s --steps 20 '
+          '--warmup 3`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests at '
+          '64 B, MI355X_MICROARCH.md section HBM; WRITE_SIZE exact)')
+fetch, write = tables['bf16x3']
+sp = {k: traffic(fetch, write, k) for k in fetch if k.startswith('gist::spmm_csr')}
+tot_l = sum(v['launches'] for v in sp.values())
+json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in sp.values()) / tot_l),
+           'method': method % 'bf16x3' + ', averaged over all SpMM launches of the step (4 x D=4096 on the block-dense '
+                                         'matrix-core kernel, 1 x D=602 on the row-split kernel)',
+           'kernels': sp, 'round': 4}, open(os.path.join(P, 'spmm_traffic.json'), 'w'), indent=1)
+gb = {k: traffic(fetch, write, k) for k in fetch if k.startswith('gist::gemm_b3_kernel')}
+tot_l = sum(v['launches'] for v in gb.values())
+json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in gb.values()) / tot_l),
+           'method': method % 'bf16x3' + ', averaged over the bf16x3 main-kernel launches of the step (5 per step)',
+           'kernels': gb, 'round': 4}, open(os.path.join(P, 'gemm_b3_traffic.json'), 'w'), indent=1)
+fetch, write = tables['f32']
+gf = {k: traffic(fetch, write, k) for k in fetch if k.startswith('gist::gemm_f32_kernel')}
+tot_l = sum(v['launches'] for v in gf.values())
+json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in gf.values()) / tot_l),
+           'method': method % 'f32' + ', averaged over the fp32 GEMM launches of the step (all layouts / tiles)',
+           'kernels': gf, 'round': 4}, open(os.path.join(P, 'gemm_f32_traffic.json'), 'w'), indent=1)
+
+# 4. MFMA occupancy / clock of the GEMM kernels
+md = ['# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES, `bench.py '
+      '--gemm-mode M --steps 20 --warmup 3 ...`, round 5', '',
+      'Per dispatch medians. cycles = GRBM_GUI_ACTIVE / 8 XCDs; MFMA pipe occupancy = SQ_VALU_MFMA_BUSY_CYCLES / '
+      '(1024 SIMDs x cycles); clock = cycles / duration (reads high on dispatches shorter than ~0.3 ms).', '',
+      '| mode | kernel | workgroups | dispatches | duration us | cycles | MFMA occupancy | clock GHz | LDS bank conflicts |',
+      '|---|---|---|---|---|---|---|---|---|']
+for mode, sub in (('bf16x3', 'pmc_mfma_bf16x3'), ('f32', 'pmc_mfma_f32')):
+    mf = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(F, sub, 't_counter_collection.csv'))):
+        if any(s in r['Kernel_Name'] for s in ('gemm_b3_kernel', 'gemm_b3c_kernel', 'gemm_f32_kernel')):
+            key = (short(r['Kernel_Name']), int(r['Grid_Size']) // int(r['Workgroup_Size']))
+            mf[key][r['Counter_Name']].append(float(r['Counter_Value']))
+            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
+                dur[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    for key in sorted(mf, key=lambda k: -sum(dur[k]))[:6]:
+        c = {k: sorted(v)[len(v) // 2] for k, v in mf[key].items()}
+        d_us = sorted(dur[key])[len(dur[key]) // 2]
+        cyc = c['GRBM_GUI_ACTIVE'] / 8
+        md.append('| %s | `%s` | %d | %d | %.1f | %.0f | %.3f | %.2f | %.0f |' % (
+            mode, key[0], key[1], len(dur[key]), d_us, cyc, c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc,
+            cyc / d_us / 1e3, c.get('SQ_LDS_BANK_CONFLICT', 0)))
+open(os.path.join(P, TAG + '_pmc_mfma.md'), 'w').write('\n'.join(md) + '\n')
+
+# 5. SQ counters of the narrow steps: what the small kernels wait for
+md = ['# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass) and '
+      '--pmc FETCH_SIZE and --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (passes of their own), `bench.py <config> --steps 20 --warmup 3 --no-cpu-baseline --no-second-leg --no-kernel-timing`, round 5', '',
+      'Per kernel of the step, medians over its dispatches.  wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave-cycles parked at s_waitcnt / '
+      's_barrier: memory latency and barriers), issue-stall share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, active share = SQ_ACTIVE_INST_ANY / '
+      'SQ_WAVE_CYCLES; MFMA occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); fabric read = 2 x FETCH_SIZE (gfx950 '
+      'correction).  The targets of the round-3 review for these steps (0.25 / 0.30 ms) were missed, and these counters say where the time of '
+      'each launch goes: the kernels that move data (extraction, LayerNorm, Adam, the LDS-gather aggregation) have 46-86 % of their '
+      'wave-cycles parked at s_waitcnt / s_barrier -- chains of dependent memory round trips, not bandwidth (fabric reads of 4-35 MB in '
+      '7-20 us = 0.6-2 TB/s); the projections are issue-stalled on the matrix pipe (57-69 %) at an occupancy of 0.32-0.59 of the fp32 MFMA '
+      'peak -- 128-1024 tiles of 64 x 64 are one to four rounds of one 32 x 32 MFMA tile per SIMD, and a launch has its ramp and tail whatever it '
+      'computes.  Third table: the default workload (H = 4096) -- `gemm_b3_kernel` at 0.72-0.76 matrix-pipe occupancy, Adam 86 % parked on '
+      'memory (it IS the bandwidth: 634 MB of reads per launch), the split pre-pass issue-stalled for more than half of its wave-cycles '
+      '(it converts every element twice, once per layout it writes), extraction and block preparation pure latency.', '']
+for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2'), ('h4096', '(the default workload: H = 4096)')):
+    f = os.path.join(F, 'pmc_sq_' + sub, 't_counter_collection.csv')
+    if not os.path.exists(f):
+        continue
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        key = (short(r['Kernel_Name'])[:70], int(r['Grid_Size']) // int(r['Workgroup_Size']))
+        d[key][r['Counter_Name']].append(float(r['Counter_Value']))
+        if r['Counter_Name'] == 'SQ_WAVE_CYCLES':
+            dur[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    fe = collections.defaultdict(list)
+    ff = os.path.join(F, 'pmc_fetch_' + sub, 't_counter_collection.csv')
+    if os.path.exists(ff):
+        for r in csv.DictReader(open(ff)):
+            fe[(short(r['Kernel_Name'])[:70], int(r['Grid_Size']) // int(r['Workgroup_Size']))].append(float(r['Counter_Value']))
+    ld = collections.defaultdict(lambda: collections.defaultdict(list))
+    fl = os.path.join(F, 'pmc_lds_' + sub, 't_counter_collection.csv')
+    if os.path.exists(fl):
+        for r in csv.DictReader(open(fl)):
+            ld[(short(r['Kernel_Name'])[:70], int(r['Grid_Size']) // int(r['Workgroup_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
+    md += ['## `bench.py %s`' % what, '', '| kernel | workgroups | dispatches | duration us (profiled) | wait share | issue-stall share | active share | MFMA occupancy | fabric read MB | LDS bank-conflict cycles / LDS active cycles |',
+           '|---|---|---|---|---|---|---|---|---|---|']
+    med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
+    for key in sorted(d, key=lambda k: -sum(dur[k])):
+        if len(dur[key]) < 15:
+            continue
+        c = {k: med(v) for k, v in d[key].items()}
+        wc = max(c.get('SQ_WAVE_CYCLES', 0.0), 1.0)
+        cyc = max(c.get('GRBM_GUI_ACTIVE', 0.0) / 8, 1.0)
+        la = med(ld[key].get('SQ_LDS_IDX_ACTIVE', []))
+        lc = med(ld[key].get('SQ_LDS_BANK_CONFLICT', []))
+        md.append('| `%s` | %d | %d | %.1f | %.2f | %.2f | %.2f | %.3f | %.2f | %s |' % (
+            key[0] or '(anonymous namespace)', key[1], len(dur[key]), med(dur[key]), c.get('SQ_WAIT_ANY', 0) / wc,
+            c.get('SQ_WAIT_INST_ANY', 0) / wc, c.get('SQ_ACTIVE_INST_ANY', 0) / wc,
+            c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cyc, 2 * med(fe.get(key, [0.0])) / 1024,
+            ('%.3f' % (lc / la)) if la > 0 else '-'))
+    md.append('')
+open(os.path.join(P, TAG + '_pmc_narrow_steps.md'), 'w').write('\n'.join(md) + '\n')
+print(open(os.path.join(P, TAG + '_pmc_mfma.md')).read())

@@ -32,6 +32,27 @@ def test_cluster_gcn_cli_contract():
     assert W0.is_cuda and torch.isfinite(W0).all()
 
 
+def test_cluster_gcn_cli_module_host_path_trains_like_the_engine_path():
+    """--host-path module: cluster_gcn.py's loop body statement for statement on the drop-in classes.  Same seeds, same
+    construction order (ClusterIter, then the model), dropout 0: the same training as the engine path -- the five result
+    lines, the accuracies of every epoch (two evaluators: to the last digit but one) and the trained weights."""
+    from gist_amd import datasets
+    from gist_amd.scripts import cluster_gcn as cli
+    out = {}
+    for hp in ('engine', 'module'):
+        args = cli.build_parser().parse_args(
+            ['--dataset', 'toy', '--n-epochs', '3', '--batch-size', '4', '--n-hidden', '32', '--n-layers', '2', '--lr', '0.01',
+             '--use-layernorm', '--rnd-seed', '0', '--dropout', '0.0', '--host-path', hp])
+        lines = []
+        out[hp] = (cli.main(args, dataset=datasets.toy(), log=lambda *a, **k: lines.append(' '.join(map(str, a)))), lines)
+        assert [l.split(':')[0] for l in lines[-5:]] == TAIL
+    e, m = out['engine'][0], out['module'][0]
+    assert getattr(m['model'], '_module_engines', None)          # (the module bound to the fused step)
+    assert np.allclose(e['val_accs'], m['val_accs'], atol=2e-3) and np.allclose(e['test_accs'], m['test_accs'], atol=2e-3)
+    for le, lm in zip(e['model'].layers, m['model'].layers):
+        assert torch.equal(le.linear.weight, lm.linear.weight) and torch.equal(le.linear.bias, lm.linear.bias)
+
+
 def test_ist_cli_world1_and_rccl_collectives():
     import torch.distributed as dist
     from gist_amd import datasets, ist
