@@ -115,18 +115,18 @@ tot_l = sum(v['launches'] for v in sp.values())
 json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in sp.values()) / tot_l),
            'method': method % 'bf16x3' + ', averaged over all SpMM launches of the step (4 x D=4096 on the block-dense '
                                          'matrix-core kernel, 1 x D=602 on the row-split kernel)',
-           'kernels': sp, 'round': 4}, open(os.path.join(P, 'spmm_traffic.json'), 'w'), indent=1)
+           'kernels': sp, 'round': 5}, open(os.path.join(P, 'spmm_traffic.json'), 'w'), indent=1)
 gb = {k: traffic(fetch, write, k) for k in fetch if k.startswith('gist::gemm_b3_kernel')}
 tot_l = sum(v['launches'] for v in gb.values())
 json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in gb.values()) / tot_l),
            'method': method % 'bf16x3' + ', averaged over the bf16x3 main-kernel launches of the step (5 per step)',
-           'kernels': gb, 'round': 4}, open(os.path.join(P, 'gemm_b3_traffic.json'), 'w'), indent=1)
+           'kernels': gb, 'round': 5}, open(os.path.join(P, 'gemm_b3_traffic.json'), 'w'), indent=1)
 fetch, write = tables['f32']
 gf = {k: traffic(fetch, write, k) for k in fetch if k.startswith('gist::gemm_f32_kernel')}
 tot_l = sum(v['launches'] for v in gf.values())
 json.dump({'hbm_bytes_per_launch': int(sum(v['hbm_bytes_corrected'] * v['launches'] for v in gf.values()) / tot_l),
            'method': method % 'f32' + ', averaged over the fp32 GEMM launches of the step (all layouts / tiles)',
-           'kernels': gf, 'round': 4}, open(os.path.join(P, 'gemm_f32_traffic.json'), 'w'), indent=1)
+           'kernels': gf, 'round': 5}, open(os.path.join(P, 'gemm_f32_traffic.json'), 'w'), indent=1)
 
 # 4. MFMA occupancy / clock of the GEMM kernels
 md = ['# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES, `bench.py '
@@ -159,14 +159,11 @@ md = ['# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
       'Per kernel of the step, medians over its dispatches.  wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave-cycles parked at s_waitcnt / '
       's_barrier: memory latency and barriers), issue-stall share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, active share = SQ_ACTIVE_INST_ANY / '
       'SQ_WAVE_CYCLES; MFMA occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); fabric read = 2 x FETCH_SIZE (gfx950 '
-      'correction).  The targets of the round-3 review for these steps (0.25 / 0.30 ms) were missed, and these counters say where the time of '
-      'each launch goes: the kernels that move data (extraction, LayerNorm, Adam, the LDS-gather aggregation) have 46-86 % of their '
-      'wave-cycles parked at s_waitcnt / s_barrier -- chains of dependent memory round trips, not bandwidth (fabric reads of 4-35 MB in '
-      '7-20 us = 0.6-2 TB/s); the projections are issue-stalled on the matrix pipe (57-69 %) at an occupancy of 0.32-0.59 of the fp32 MFMA '
-      'peak -- 128-1024 tiles of 64 x 64 are one to four rounds of one 32 x 32 MFMA tile per SIMD, and a launch has its ramp and tail whatever it '
-      'computes.  Third table: the default workload (H = 4096) -- `gemm_b3_kernel` at 0.72-0.76 matrix-pipe occupancy, Adam 86 % parked on '
-      'memory (it IS the bandwidth: 634 MB of reads per launch), the split pre-pass issue-stalled for more than half of its wave-cycles '
-      '(it converts every element twice, once per layout it writes), extraction and block preparation pure latency.', '']
+      'correction).  The round-4 review\'s targets for the narrow steps (h = 512 0.24 ms, config 2 0.28 ms) were missed again (0.264 / 0.314): the '
+      'kernels are round 4\'s (what was tried on them this round and measured out: profiles/NEGATIVES.md), and these counters are the floor '
+      'they sit on -- the data-moving launches (extraction, LayerNorm, Adam, the LDS-gather aggregation) spend most of their wave-cycles '
+      'parked at s_waitcnt / s_barrier on chains of dependent memory round trips while moving a few MB each, the projections are '
+      'issue-stalled on a matrix pipe that one 32 x 32 tile per SIMD keeps a third to a half busy.', '']
 for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2'), ('h4096', '(the default workload: H = 4096)')):
     f = os.path.join(F, 'pmc_sq_' + sub, 't_counter_collection.csv')
     if not os.path.exists(f):
@@ -207,3 +204,48 @@ for sub, what in (('h512', '--n-hidden 512'), ('cfg2', '--config 2'), ('h4096', 
     md.append('')
 open(os.path.join(P, TAG + '_pmc_narrow_steps.md'), 'w').write('\n'.join(md) + '\n')
 print(open(os.path.join(P, TAG + '_pmc_mfma.md')).read())
+
+# 6. round 5: the module path beside the engine path, the unplanted graph, the partitioner on the GPU box's host
+mp = {}
+for tag, path in (('default_H4096', 'bench_n1.log'), ('n_hidden_2048', 'bench_h2048.log'), ('n_hidden_1024', 'bench_h1024.log'),
+                  ('n_hidden_512', 'bench_h512.log'), ('config_2', 'bench_cfg2.log'), ('config_4_one_rank_of_8', 'bench_cfg4.log')):
+    d = last_json(os.path.join(F, path))
+    m = d.get('module_path') or {}
+    mp[tag] = {'engine_path_ms_per_step': d['ms_per_step'], 'module_path_ms_per_step': m.get('ms_per_step'),
+               'module_over_engine': m.get('vs_engine_path_ms_per_step'),
+               'host_issue_ms_per_step_engine': (d.get('host_issue_ms_per_step') or {}).get('median'),
+               'host_issue_ms_per_step_module': (m.get('host_issue_ms_per_step') or {}).get('median'),
+               'cfs_throttled_periods_engine': (d.get('host_counters_delta') or {}).get('cgroup_nr_throttled'),
+               'cfs_throttled_periods_module': (m.get('host_counters_delta') or {}).get('cgroup_nr_throttled')}
+json.dump({'note': 'bench.py lines of scripts/final_profile_r5.sh: the headline (engine path: one gist_sage_step per iteration) and the '
+                   'module_path leg of the same process (the reference loop body on gist_amd.modules.GCN / nn.CrossEntropyLoss / '
+                   'optim.Adam / sampler.ClusterIter: three phase calls per iteration); host_issue = median host time between the '
+                   'starts of two iterations (no synchronisation in the loop)', 'lines': mp},
+          open(os.path.join(P, TAG + '_module_path.json'), 'w'), indent=1)
+U = os.path.join(ROOT, 'gpurun_out', 'r5', 'unplanted')
+if os.path.isdir(U):
+    un = {}
+    for ds in ('reddit-synth', 'reddit-communities'):
+        for h in (4096, 512):
+            f = os.path.join(U, '%s_h%d.json' % (ds, h))
+            if not os.path.exists(f):
+                continue
+            d = json.load(open(f))
+            un['%s_h%d' % (ds, h)] = {
+                'workload': d['config']['workload'], 'ms_per_step': d['ms_per_step'], 'epochs_per_s': d['value'],
+                'module_path_ms_per_step': (d.get('module_path') or {}).get('ms_per_step'),
+                'roofline_spmm': {k: d['roofline_spmm'][k] for k in ('kernel', 'achieved', 'frac', 'avg_launch_ms', 'launches',
+                                                                      'mean_batch_rows', 'mean_batch_nnz')},
+                'gemm_avg_launch_ms': d['roofline']['avg_launch_ms'], 'batch_locality': d.get('batch_locality'),
+                'partition': d.get('partition')}
+    json.dump({'note': 'scripts/r5_unplanted.sh on one box: the planted block model (parts = its blocks) beside the power-law community '
+                       'graph (communities of 30-400 nodes, mixing 0.3, random node ids) cut into 1500 parts by gist_partition_graph, at '
+                       'the metric\'s width and at config 3\'s 8-GPU per-rank width.  What differs on the community graph: parts of 99-106 '
+                       'rows (every second batch has more than 2048 rows = a ninth 256-row tile in the projections: +13 % on '
+                       'gemm_b3_kernel), and on every eighth batch two parts of ONE community (30-80 outside neighbours per row of both: '
+                       'the block-dense kernel walks those rows\' edge lists, 125-140 us instead of 38; before this round\'s change to '
+                       'that path and to the extraction\'s aggregation: 130-270 us and 110-320 us)', 'runs': un},
+              open(os.path.join(P, TAG + '_unplanted_graph.json'), 'w'), indent=1)
+pb = os.path.join(ROOT, 'gpurun_out', 'r5', 'partitioner_box.json')
+if os.path.exists(pb):
+    open(os.path.join(P, TAG + '_partitioner.json'), 'w').write(open(pb).read())
