@@ -89,6 +89,7 @@ SIGNATURES = {
                                                _u64, _u64, _u64, _i64, _p, _p]),
     'gist_spmm_block_image_bytes': (_i64, []),
     'gist_spmm_block_units_f32': (_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),
+    'gist_spmm_block_chains_f32': (_int, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),
     'gist_spmm_prepared_useful': (_int, [_i64, _i64, _i64, _p, _p]),
     'gist_spmm_drop_takes': (_int, [_int, _i64, _i64, _i64, _p, _p, _int]),
     'gist_gemm_dual_takes': (_int, [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p]),

@@ -733,9 +733,237 @@ int launch_spmm_mfma_units(const int32_t *units, int64_t n_units, const void *pr
     return launch_status("gist_spmm_block_units_f32");
 }
 
+// ---- chains of block pairs (full-graph evaluation, round 5) ---------------------------------------------------------
+// gist_spmm_block_units_f32 launches the j-th pair of every row block together and accumulates into y: per (pair, 128-column
+// tile) 64 KB of X read + 64 KB of y read + 64 KB of y written = 7.5 us at a CU's share of the memory system, 17 ms for the
+// 18 224 pairs of the Reddit-sized graph at D = 4096 (profiles/NEGATIVES.md).  Here ONE workgroup owns a row block's tile across
+// ALL units that write it (its diagonal block and every dense off-diagonal pair: a chain): the accumulators stay in registers
+// from the chain's first unit to its last, per unit the 32-KiB count image and the 64-KB X tile are loaded (both prefetched
+// into registers under the previous unit's MFMAs), y is written once.
+struct MfChainArgs {
+    const int32_t *chain_ptr;        // [n_chains + 1]: units of chain c = [chain_ptr[c], chain_ptr[c + 1])
+    const int32_t *units;            // [n_units][4] = (r0, r1, xs0, xs1); r0 / r1 equal within a chain
+    const unsigned char *images;     // unit u's count image at images + u * MF_PREP_STRIDE
+    const float *x; int64_t ldx;
+    float *y; int64_t ldy;
+    int n_rows, d;
+    const float *out_scale;
+    int accumulate, n_chains, n_col_tiles, groups;
+};
+
+__global__ __launch_bounds__(MF_THREADS) void spmm_chain_mfma_kernel(MfChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    const int total = a.n_chains * a.groups;
+    const int per_xcd = (total + kXcds - 1) / kXcds;
+    const int unit = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    if (unit >= total) return;
+    const int grp = unit % a.groups;
+    const int chain = unit / a.groups;
+    const int u0 = a.chain_ptr[chain], u1 = a.chain_ptr[chain + 1];
+    if (u1 <= u0) return;
+    const int r0 = a.units[4 * u0];
+    const int r1 = min(a.units[4 * u0 + 1], a.n_rows);
+    const int nloc = min(r1 - r0, MF_ROWS);
+    if (nloc <= 0) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, cq = lane & 31;
+    unsigned char *xt = mf_smem;
+    float *yt = reinterpret_cast<float *>(mf_smem);
+    unsigned char *ab = mf_smem + MF_A_OFF;
+    float *sc = reinterpret_cast<float *>(mf_smem + MF_SC_OFF);
+    const int sh = lane & 1, scq = lane >> 1;
+    const int srow = 8 * wave + 4 * sh;
+    const int rr = lane & 15, kg = lane >> 4;
+    const int mt0 = (wave >> 2) * 2, nt0 = (wave & 3) * 2;
+    const bool m_on = mt0 * 16 < nloc, m_two = (mt0 + 1) * 16 < nloc;
+    int bslot[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = (nt0 + ni) * 16 + rr;
+        bslot[ni] = ((n & 3) * 36 + (n >> 2)) * 16;
+    }
+    if (tid < MF_ROWS) sc[tid] = (tid < nloc && a.out_scale) ? a.out_scale[r0 + tid] : 1.f;
+    // what is in flight for the NEXT (unit, tile): its X tile rows and its count image
+    float4 xv[4];
+    uint4 cv0, cv1;
+    int nx_next = 0;
+    auto prefetch = [&](int u, int t) {          // (clamped addresses, selected when used: branch-free loads)
+        const int xs0 = a.units[4 * u + 2];
+        nx_next = min(a.units[4 * u + 3] - xs0, MF_ROWS);
+        const bool cok = t * MF_CT + 4 * scq < a.d;
+        const float *px = a.x + (int64_t)xs0 * a.ldx + (cok ? t * MF_CT + 4 * scq : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xv[i] = *reinterpret_cast<const float4 *>(px + (int64_t)min(srow + i, max(nx_next, 1) - 1) * a.ldx);
+        const unsigned char *src = a.images + (int64_t)u * MF_PREP_STRIDE;
+        cv0 = reinterpret_cast<const uint4 *>(src)[2 * tid];
+        cv1 = reinterpret_cast<const uint4 *>(src)[2 * tid + 1];
+    };
+    constexpr int RW = MF_ROWS / MF_WAVES;
+    int ct = grp;
+    if (ct < a.n_col_tiles) prefetch(u0, ct);
+    for (; ct < a.n_col_tiles; ct += a.groups) {
+        mf_f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
+        for (int u = u0; u < u1; ++u) {
+            const int nx = nx_next;
+            // ---- this unit's X tile -> three bf16 pieces -> X^T image; its counts -> the A image ----
+            {
+                const bool cok = ct * MF_CT + 4 * scq < a.d;
+                float xs[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = cok && srow + i < nx;
+                    xs[i][0] = ok ? xv[i].x : 0.f; xs[i][1] = ok ? xv[i].y : 0.f;
+                    xs[i][2] = ok ? xv[i].z : 0.f; xs[i][3] = ok ? xv[i].w : 0.f;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    uint32_t w[3][2];
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float x0 = xs[2 * pr][jj], x1 = xs[2 * pr + 1][jj];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const mf_bf16x2 pk = __builtin_convertvector(mf_f32x2{x0, x1}, mf_bf16x2);
+                            const uint32_t uu = __builtin_bit_cast(uint32_t, pk);
+                            w[q][pr] = uu;
+                            x0 -= __builtin_bit_cast(float, uu << 16);
+                            x1 -= __builtin_bit_cast(float, uu & 0xffff0000u);
+                        }
+                    }
+                    unsigned char *dst = xt + (wave * MF_CHUNK_SLOTS + jj * 36 + scq) * 16 + sh * 8;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        *reinterpret_cast<uint2 *>(dst + q * MF_PIECE) = make_uint2(w[q][0], w[q][1]);
+                }
+                reinterpret_cast<uint4 *>(ab)[2 * tid] = cv0;
+                reinterpret_cast<uint4 *>(ab)[2 * tid + 1] = cv1;
+            }
+            // the next (unit, tile) in flight under this unit's MFMAs
+            if (u + 1 < u1) prefetch(u + 1, ct);
+            else if (ct + a.groups < a.n_col_tiles) prefetch(u0, ct + a.groups);
+            mf_barrier();
+            const int n_ks = (nx + 31) >> 5;
+            if (m_on) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < n_ks) {
+                        mf_bf16x8 av[2], bv[3][2];
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            av[mi] = *reinterpret_cast<const mf_bf16x8 *>(
+                                ab + ((ks * 4 + kg) * MF_ROWS + (mt0 + mi) * 16 + rr) * 16);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+                                bv[q][ni] = *reinterpret_cast<const mf_bf16x8 *>(
+                                    xt + q * MF_PIECE + (ks * 4 + kg) * (MF_CHUNK_SLOTS * 16) + bslot[ni]);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[q][ni], acc[0][ni], 0, 0, 0);
+                                if (m_two)
+                                    acc[1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[q][ni], acc[1][ni], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+            mf_barrier();                                  // every wave is done reading both images
+        }
+        // ---- accumulators -> fp32 result tile -> rows: x out_scale (+ y), store ----
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    yt[((mt0 + mi) * 16 + 4 * kg + e) * MF_YT_PITCH + (nt0 + ni) * 16 + rr] = acc[mi][ni][e];
+        mf_barrier();
+        const int gc = ct * MF_CT + 4 * cq;
+        const bool colok = gc < a.d;
+        float *yblk = a.y + (int64_t)r0 * a.ldy;
+        const int ldy32 = (int)a.ldy;
+        float4 v[RW / 2], yold[RW / 2];
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp) yold[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.accumulate) {
+#pragma unroll
+            for (int pp = 0; pp < RW / 2; ++pp)
+                yold[pp] = *reinterpret_cast<const float4 *>(
+                    yblk + (uint32_t)(min(wave + MF_WAVES * (2 * pp + half), nloc - 1) * ldy32 + (colok ? gc : 0)));
+        }
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp)
+            v[pp] = *reinterpret_cast<const float4 *>(
+                yt + min(wave + MF_WAVES * (2 * pp + half), MF_ROWS - 1) * MF_YT_PITCH + 4 * cq);
+        mf_barrier();                                      // (the result tile aliases the next X^T image)
+#pragma unroll
+        for (int pp = 0; pp < RW / 2; ++pp) {
+            const int r = wave + MF_WAVES * (2 * pp + half);
+            const float s = sc[min(r, MF_ROWS - 1)];
+            if (colok && r < nloc) {
+                const float4 o = make_float4(fmaf(s, v[pp].x, yold[pp].x), fmaf(s, v[pp].y, yold[pp].y),
+                                             fmaf(s, v[pp].z, yold[pp].z), fmaf(s, v[pp].w, yold[pp].w));
+                *reinterpret_cast<float4 *>(yblk + (uint32_t)(r * ldy32 + gc)) = o;
+            }
+        }
+    }
+}
+
+int launch_spmm_mfma_chains(const int32_t *chain_ptr, int64_t n_chains, const int32_t *units, const void *images,
+                            const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_rows_y, int64_t d,
+                            const float *out_scale, int accumulate, hipStream_t st) {
+    GIST_REQUIRE(ldy < (1LL << 22) && ldx < (1LL << 22) && d < (1LL << 22),
+                 "gist_spmm_block_chains_f32: row pitch of 2^22 floats or more");
+    MfChainArgs a{};
+    a.chain_ptr = chain_ptr; a.units = units; a.images = static_cast<const unsigned char *>(images);
+    a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.n_rows = (int)n_rows_y; a.d = (int)d;
+    a.out_scale = out_scale; a.accumulate = accumulate; a.n_chains = (int)n_chains;
+    a.n_col_tiles = (int)ceil_div(d, MF_CT);
+    int64_t groups = n_chains > 0 ? 512 / n_chains : 1;      // (two rounds of workgroups per CU at least)
+    if (groups < 1) groups = 1;
+    if (groups > a.n_col_tiles) groups = a.n_col_tiles;
+    a.groups = (int)groups;
+    const int64_t grid = kXcds * ceil_div(n_chains * groups, kXcds);
+    if (grid > 0x7fffffffLL) { set_error("gist_spmm_block_chains_f32: grid too large"); return GIST_EINVAL; }
+    static DeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        const int rc = mf_set_lds(reinterpret_cast<const void *>(&spmm_chain_mfma_kernel), "gist_spmm_block_chains_f32");
+        if (rc != GIST_OK) return rc;
+        once.done(dev);
+    }
+    hipLaunchKernelGGL(spmm_chain_mfma_kernel, dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    return launch_status("gist_spmm_block_chains_f32");
+}
+
 }  // namespace gist
 
 extern "C" int64_t gist_spmm_block_image_bytes(void) { return gist::MF_PREP_STRIDE; }
+
+extern "C" int gist_spmm_block_chains_f32(const int32_t *chain_ptr, int64_t n_chains, const int32_t *units, const void *images,
+                                          const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_rows_y, int64_t d,
+                                          const float *out_scale, int accumulate, gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(n_chains >= 0 && d >= 0 && n_rows_y >= 0, "gist_spmm_block_chains_f32: negative size");
+    if (n_chains == 0 || d == 0) return GIST_OK;
+    GIST_REQUIRE(chain_ptr && units && images && x && y, "gist_spmm_block_chains_f32: null pointer");
+    GIST_REQUIRE(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d && aligned16(x) && aligned16(y) &&
+                     aligned16(images),
+                 "gist_spmm_block_chains_f32: rows must be 16-byte aligned multiples of 4 floats");
+    return launch_spmm_mfma_chains(chain_ptr, n_chains, units, images, x, ldx, y, ldy, n_rows_y, d, out_scale, accumulate,
+                                   as_stream(stream));
+}
 
 extern "C" int gist_spmm_block_units_f32(const int32_t *units, int64_t n_units, const void *images, const float *x,
                                          int64_t ldx, float *y, int64_t ldy, int64_t n_rows_y, int64_t d,

@@ -523,6 +523,24 @@ def spmm_block_units(units, images, x, y, out_scale=None, accumulate=False):
     return y
 
 
+def spmm_block_chains(chain_ptr, units, images, x, y, out_scale=None, accumulate=False):
+    """gist_spmm_block_chains_f32: chain c = units [chain_ptr[c], chain_ptr[c + 1]) (same output rows); one workgroup per
+    (chain, column-tile group) keeps the accumulators across the chain: y written once."""
+    L = _lib.load()
+    xp, ldx = _mat(x, 'x')
+    yp, ldy = _mat(y, 'y')
+    d = x.shape[1]
+    nc = chain_ptr.numel() - 1
+    nu = units.shape[0]
+    with _Timed('spmm', (y.shape[0], x.shape[0], d)):
+        rc = L.gist_spmm_block_chains_f32(_vec(chain_ptr, 'chain_ptr', torch.int32, nc + 1), nc,
+                                          _vec(units, 'units', torch.int32, 4 * nu), images.data_ptr(), xp, ldx, yp, ldy,
+                                          y.shape[0], d, _opt(out_scale, 'out_scale', torch.float32), int(bool(accumulate)),
+                                          _stream())
+    _lib.check(rc, 'gist_spmm_block_chains_f32')
+    return y
+
+
 def spmm_prepared_useful(x, y):
     """Does an aggregation of x's width read a prepared block structure (gist_spmm_prepared_useful)?"""
     L = _lib.load()

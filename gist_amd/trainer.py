@@ -82,6 +82,7 @@ class FullGraphEvaluator(object):
         # (10 edges per pair) and keeps the gathers.  0 = off.
         self.pair_min_edges = int(pair_min_edges) if os.environ.get('GIST_EVAL_PAIRS', '1') != '0' else 0
         self.pair_bytes = int(pair_bytes)
+        self.use_chains = os.environ.get('GIST_EVAL_CHAINS', '1') != '0'      # (0: one launch per pair rank, round 4's form)
         self.row_cuts = list(range(0, n, self.row_block)) + [n]
         hidden = max([o for (i, o) in self.dims[:-1]] + [1])
         self.h = [torch.empty(n, hidden, **f32) for _ in range(2 if L1 > 2 else 1)] if L1 > 1 else []
@@ -140,13 +141,21 @@ class FullGraphEvaluator(object):
                     hip.block_gather(self._ah0[r0:r1], None, None, z[:, i:])
                 elif self.split is not None and self._dense_ok(cur[r0:r1, :i], z[:, i:]):
                     sp = self.split
-                    # inside the blocks: counts x features on the matrix cores (sources = this row block)
-                    hip.spmm(sp['rowptr_d'][r0:r1 + 1], sp['col_d'], cur[r0:r1, :i], z[:, i:],
-                             out_scale=self.norm[r0:r1], row_blocks=sp['blocks'][bi], prepared=sp['prepared'][bi])
+                    ch = sp.get('chains')
+                    if ch is not None:
+                        # inside the blocks AND the dense off-diagonal pairs: one chain of units per row block, the output
+                        # tile's accumulators kept across the chain (gist_spmm_block_chains_f32)
+                        cp, u_lo, u_hi = ch['chunks'][bi]
+                        hip.spmm_block_chains(cp, ch['units'][u_lo:u_hi], ch['images'][u_lo:u_hi], cur[:, :i], z[:, i:],
+                                              out_scale=self.norm[r0:r1])
+                    else:
+                        # inside the blocks: counts x features on the matrix cores (sources = this row block)
+                        hip.spmm(sp['rowptr_d'][r0:r1 + 1], sp['col_d'], cur[r0:r1, :i], z[:, i:],
+                                 out_scale=self.norm[r0:r1], row_blocks=sp['blocks'][bi], prepared=sp['prepared'][bi])
                     # everything else: gathered, accumulated -- one column tile at a time, so that the slab of
                     # X a pass gathers from (N x rest_tile floats: 238 MB at Reddit's size) stays in the
                     # Infinity Cache instead of every gather going to HBM
-                    if sp['n_pairs'] > 0:      # dense off-diagonal blocks: counts x features, accumulated --
+                    if ch is None and sp['n_pairs'] > 0:      # dense off-diagonal blocks: counts x features, accumulated --
                         # the j-th pair of every row block of this chunk in one launch (disjoint output rows)
                         for (a0, a1) in sp['rounds'].get(bi, []):
                             hip.spmm_block_units(sp['units'][a0:a1], sp['images'][a0:a1], cur[:, :i], z[:, i:],
@@ -314,6 +323,45 @@ class FullGraphEvaluator(object):
         self.split = dict(rowptr_d=rp_d, col_d=col_d, rowptr_r=rp_r, col_r=col_r, blocks=blocks,
                           prepared=prepared, diag_edges=int(col_d.numel()), rest_edges=int(col_r.numel()),
                           block_range=block_range, bounds32=torch.from_numpy(bounds.astype(np.int32)).to(dev), **pairs)
+        if self.use_chains and pairs['n_pairs'] > 0:
+            self._build_chains(bd, cut_t, rb_of_row, nb, stride)
+
+    def _build_chains(self, bd, cut_t, rb_of_row, nb, stride):
+        """Round 5: a row block's diagonal block and its dense off-diagonal pairs as ONE chain of units for
+        gist_spmm_block_chains_f32 -- one workgroup keeps the output tile's accumulators across the chain and writes y once
+        (the per-pair launches read and wrote y for every pair: 128 of the 192 KB a pair-tile moved)."""
+        sp, dev = self.split, self.device
+        n_pairs = sp['n_pairs']
+        first = sp['pair_ptr'].to(torch.int64)                              # [nb + 1]: sorted pairs of row block b
+        rb_p = torch.repeat_interleave(torch.arange(nb, device=dev), first[1:] - first[:-1])
+        cb_p = sp['pair_cb'].to(torch.int64)
+        pos = torch.empty(n_pairs, dtype=torch.int64, device=dev)           # sorted pair -> its image in launch order
+        pos[sp['pair_order']] = torch.arange(n_pairs, device=dev)
+        # diagonal images: the prepared structures of the row chunks, block by block; a row that left the dense product
+        # there (a count above 256: its rem_cnt is -1) keeps the per-launch path for the whole evaluator
+        diag = torch.cat([pb.view(torch.bfloat16).view(-1, stride) for pb in sp['prepared']], 0)
+        rem = diag[:, 16384:16384 + 256].contiguous().view(torch.int32)       # rem_cnt[128] of every block
+        if diag.shape[0] != nb or bool((rem < 0).any()):
+            return
+        n_units = n_pairs + nb
+        slot_d = first[:-1] + torch.arange(nb, device=dev)                   # chain b starts with its diagonal block
+        slot_p = torch.arange(n_pairs, device=dev) + rb_p + 1
+        images = torch.empty(n_units, stride, dtype=torch.bfloat16, device=dev)
+        images[slot_d] = diag
+        for p0 in range(0, n_pairs, 4096):                                   # (gathered in pieces: 128 MB in flight)
+            p1 = min(n_pairs, p0 + 4096)
+            images[slot_p[p0:p1]] = sp['images'][pos[p0:p1]]
+        base_b = cut_t[rb_of_row[bd[:-1]]]                                   # first row of the chunk a block belongs to
+        units = torch.empty(n_units, 4, dtype=torch.int64, device=dev)
+        units[slot_d] = torch.stack([bd[:-1] - base_b, bd[1:] - base_b, bd[:-1], bd[1:]], 1)
+        units[slot_p] = torch.stack([bd[rb_p] - base_b[rb_p], bd[rb_p + 1] - base_b[rb_p], bd[cb_p], bd[cb_p + 1]], 1)
+        cptr = torch.cat([slot_d, torch.tensor([n_units], device=dev)])
+        chunks = []
+        for (lo, hi) in sp['block_range']:
+            u_lo = int(cptr[lo].item())
+            chunks.append(((cptr[lo:hi + 1] - u_lo).to(torch.int32).contiguous(), u_lo, int(cptr[hi].item())))
+        sp['chains'] = dict(images=images, units=units.to(torch.int32).contiguous(), chunks=chunks)
+        sp['images'] = None                                                  # (the chains own the pair images now)
 
     def accuracy(self, mask_name):
         if mask_name not in self.masks:

@@ -150,6 +150,16 @@ int64_t gist_spmm_block_image_bytes(void);
 int gist_spmm_block_units_f32(const int32_t *units, int64_t n_units, const void *images, const float *x, int64_t ldx,
                               float *y, int64_t ldy, int64_t n_rows_y, int64_t d, const float *out_scale,
                               int accumulate, gist_stream_t stream);
+/* The same products for CHAINS of units (ABI 14, round 5): chain c = units [chain_ptr[c], chain_ptr[c + 1]) of `units`, all with
+ * the same output rows (r0, r1) -- a row block's diagonal block and every dense off-diagonal pair that writes it -- computed by
+ * ONE workgroup per (chain, column-tile group) whose accumulators stay in registers across the chain:
+ *   y[r0 .. r1, :d] (+)= out_scale[r] * sum over the chain's units u of C_u . x[xs0_u .. xs1_u, :d]
+ * y is read (accumulate) and written once per chain instead of once per unit (gist_spmm_block_units_f32 moves 64 KB of X +
+ * 128 KB of y per unit and 128-column tile; this form 64 KB of X + the unit's 32-KiB image).  Unit u's image is the u-th of
+ * `images`; different chains must have disjoint output rows.  Same layout and alignment rules as above. */
+int gist_spmm_block_chains_f32(const int32_t *chain_ptr, int64_t n_chains, const int32_t *units, const void *images,
+                               const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_rows_y, int64_t d,
+                               const float *out_scale, int accumulate, gist_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Data preparation (HOST function, host pointers)

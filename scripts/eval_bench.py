@@ -127,12 +127,23 @@ def variant(loc, first):
                     hip.spmm(sp['rowptr_r'][r0:r1 + 1], sp['col_r'], x[:, c0:c0 + ct], zr[:r1 - r0, c0:c0 + ct],
                              out_scale=norm[r0:r1], accumulate=True)
 
-        md = timeit(diag, 3)
-        mp = timeit(pairs, 3) if sp['n_pairs'] else 0.0
+        ch = sp.get('chains')
+
+        def chains():      # round 5: diagonal block + dense pairs of a row block as one chain (y written once)
+            for bi, (r0, r1) in enumerate(cuts):
+                cp, u_lo, u_hi = ch['chunks'][bi]
+                hip.spmm_block_chains(cp, ch['units'][u_lo:u_hi], ch['images'][u_lo:u_hi], x, zr[:r1 - r0], out_scale=norm[r0:r1])
+
+        if ch is not None:
+            md, mp = timeit(chains, 3), 0.0
+        else:
+            md = timeit(diag, 3)
+            mp = timeit(pairs, 3) if sp['n_pairs'] else 0.0
         mr = timeit(rest, 3) if sp['rest_edges'] else 0.0
         alg = 4.0 * (n + 1) + 4.0 * nnz + 8.0 * n * d
         r['aggregation_D4096'] = {
             'ms_inside_blocks_bf16x3_matrix_cores': round(md, 3), 'ms_dense_pairs_bf16x3_matrix_cores': round(mp, 3),
+            'chains': ch is not None,      # True: ms_inside_blocks is diagonal blocks + dense pairs in one launch per row chunk
             'ms_rest_gather_512_float_tiles': round(mr, 3), 'ms_total': round(md + mp + mr, 3),
             'algorithmic_GB': round(alg / 1e9, 3), 'achieved_GBps': round(alg / (md + mp + mr) / 1e6, 1),
             'frac_of_8TBps': round(alg / (md + mp + mr) / 1e6 / 8000.0, 4),

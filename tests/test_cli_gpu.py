@@ -301,6 +301,64 @@ def test_block_units_kernel_against_float64():
         assert np.all(got[:bounds[rb]] == 7.0) and np.all(got[bounds[rb + 1]:] == 7.0)
 
 
+def test_block_chains_kernel_against_float64():
+    """gist_spmm_block_chains_f32 (round 5): chain c = several units with the SAME output rows -- a row block's diagonal
+    block and its dense off-diagonal pairs -- summed in one workgroup's registers, y read / written once:
+    y[r0:r1] (+)= scale * sum_u C_u @ x[xs0_u:xs1_u].  Chains of 1 .. 5 units over unequal blocks (1 .. 128 rows / sources),
+    an EMPTY chain, widths that are not a multiple of the 128-column tile, output rows relative to a window, accumulate on
+    and off, the largest exact count (256); against float64 and against the same units through gist_spmm_block_units_f32."""
+    from gist_amd import hip, _lib
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(1)
+    sizes = np.array([100, 128, 1, 57, 128, 90, 33])
+    bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(bounds[-1])
+    stride = int(_lib.load().gist_spmm_block_image_bytes()) // 2
+    # chains: row block -> its source blocks (the first is its own diagonal block)
+    chains = {0: [0, 1, 3], 1: [1], 2: [2, 4, 0, 5, 6], 3: [], 4: [4, 0], 5: [5, 3, 1, 2], 6: [6, 6]}
+    scale = rs.rand(n).astype(np.float32) + 0.5
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for d in (512, 132, 1024 + 260):
+        x = rs.randn(n, d + 4).astype(np.float32)
+        for win, acc in (((0, n), True), ((0, n), False), ((int(bounds[1]), int(bounds[6])), True)):
+            rows = [rb for rb in chains if bounds[rb] >= win[0] and bounds[rb + 1] <= win[1]]
+            y0 = rs.randn(win[1] - win[0], d).astype(np.float32)
+            ref = y0.astype(np.float64) if acc else np.full((win[1] - win[0], d), np.nan)
+            units, imgs, cptr = [], [], [0]
+            for rb in rows:
+                tot = np.zeros((sizes[rb], d))
+                for cb in chains[rb]:
+                    c = rs.poisson(0.4, (sizes[rb], sizes[cb])).astype(np.float64)
+                    c[rs.randint(0, sizes[rb]), rs.randint(0, sizes[cb])] = 256
+                    im = np.zeros((16, 128, 8), np.float32)
+                    for k in range(sizes[cb]):
+                        im[k // 8, :sizes[rb], k % 8] = c[:, k]
+                    img = np.zeros(stride, np.float32)
+                    img[:16384] = im.ravel()
+                    imgs.append(img)
+                    units.append((bounds[rb] - win[0], bounds[rb + 1] - win[0], bounds[cb], bounds[cb + 1]))
+                    tot += c @ x[bounds[cb]:bounds[cb + 1], :d].astype(np.float64)
+                cptr.append(len(units))
+                if chains[rb]:
+                    lo, hi = bounds[rb] - win[0], bounds[rb + 1] - win[0]
+                    ref[lo:hi] = (ref[lo:hi] if acc else 0.0) + tot * scale[bounds[rb]:bounds[rb + 1], None]
+            U = t32(np.array(units, np.int32).reshape(-1, 4))
+            I = t32(np.stack(imgs)).to(torch.bfloat16).contiguous()
+            y = t32(y0.copy())
+            hip.spmm_block_chains(t32(np.array(cptr, np.int32)), U, I, t32(x)[:, :d], y,
+                                  out_scale=t32(scale[win[0]:win[1]].copy()), accumulate=acc)
+            got = y.cpu().numpy()
+            touched = ~np.isnan(ref[:, 0])
+            assert np.abs(got[touched] - ref[touched]).max() < 2e-5 * max(1.0, np.abs(ref[touched]).max()), (d, win, acc)
+            assert np.array_equal(got[~touched], y0[~touched])            # rows of empty / absent chains: untouched
+            if acc:      # the same units one by one through the per-unit kernel: equal to rounding
+                y2 = t32(y0.copy())
+                for u in range(U.shape[0]):
+                    hip.spmm_block_units(U[u:u + 1], I[u:u + 1], t32(x)[:, :d], y2,
+                                         out_scale=t32(scale[win[0]:win[1]].copy()), accumulate=True)
+                assert (y2 - y).abs().max().item() < 2e-5 * max(1.0, np.abs(ref[touched]).max())
+
+
 @pytest.mark.parametrize('locality', [0.8, 1.0])
 def test_evaluator_dense_block_pairs_agree(locality):
     """A graph whose inter-part edges go mostly to a few neighbour parts (what a partition of a real graph looks like):
@@ -327,6 +385,15 @@ def test_evaluator_dense_block_pairs_agree(locality):
         if locality == 1.0:
             assert sp['rest_edges'] < 0.02 * g.number_of_edges()        # (hub rows' thin pairs only)
         assert (ev.forward() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+        assert sp.get('chains') is not None                          # (round 5: diagonal block + pairs as chains)
+    import os
+    os.environ['GIST_EVAL_CHAINS'] = '0'                             # round 4's form: one launch per pair rank
+    try:
+        ev1 = FullGraphEvaluator(g, dims, True, arena, dev, pair_min_edges=200)
+        assert ev1.split.get('chains') is None and ev1.split['n_pairs'] > 0
+        assert (ev1.forward() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    finally:
+        del os.environ['GIST_EVAL_CHAINS']
     ev0 = FullGraphEvaluator(g, dims, True, arena, dev, pair_min_edges=10 ** 9)
     assert ev0.split['n_pairs'] == 0
     assert (ev0.forward() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
