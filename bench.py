@@ -104,6 +104,9 @@ def parse():
                          '1-thread figure times 12')
     ap.add_argument('--cpu-budget', type=float, default=90.0,
                     help='wall-time bound (s) of the all-cores oracle sample; the 1-thread sample gets half')
+    ap.add_argument('--tune', action='append', default=[], metavar='KNOB=VALUE',
+                    help='development A/B: set a tuning hook of the library (gist_amd._lib.TUNE) before the run; recorded in '
+                         'the line as config.tune')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='skip HIP-event bracketing of SpMM/GEMM launches')
     ap.add_argument('--timing-every', type=int, default=16,
@@ -613,6 +616,9 @@ def main():
     from gist_amd import datasets, hip
     from gist_amd.engine import SageEngine, dims_for
     from gist_amd.sampler import EngineClusterIter
+    for kv in args.tune:
+        knob, _, val = kv.partition('=')
+        hip.tuning(knob, float(val))
 
     # workspaces are sized for the split path (a superset of what mode f32 needs), then the
     # requested mode is selected for the headline run
@@ -1178,6 +1184,7 @@ def main():
                          'ah.bl + al.bh in fp32 -- narrower than fp32'}[eff_mode],
             'data': 'synthetic',
             'config': {
+                **({'tune': list(args.tune)} if args.tune else {}),
                 'workload': '%s synthetic (N_train=%d, F=%d, C=%d, %d parts, '
                             'batch=%d parts, %d steps/epoch); GraphSAGE n_hidden=%d n_layers=%d '
                             'LayerNorm dropout=%.2f Adam lr=0.01; %s' % (

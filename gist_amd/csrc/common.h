@@ -117,10 +117,25 @@ struct SpmmDrop {
     uint64_t sm, y_base, src_base;
     int64_t ld;
 };
+// LayerNorm + ReLU backward of the layer BELOW in the store of a reverse aggregation (mode 2, d <= 256: a wave holds a
+// whole row): what would be stored is d_out of that layer's output; dy = rstd . (g - mean(g) - yhat . mean(g . yhat)),
+// g = d_out . [yhat > 0], goes to `dy` (may be `yhat` itself), nothing to y; col_partials[unit][0..d) = the column sums of
+// the dy rows one workgroup stored (spmm_lnb_units(n_row_blocks) rows: the bias gradient's partial sums)
+struct SpmmLnBwd {
+    const float *yhat; int64_t ldy;
+    const float *rstd;            // NULL: no LayerNorm (dy = g)
+    float *dy; int64_t lddy;
+    float *col_partials;
+    int relu;
+};
 int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y, int64_t ldy,
               int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale, int accumulate,
               const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st,
-              const void *prepared = nullptr);
+              const void *prepared = nullptr, const SpmmLnBwd *ln = nullptr);
+// can a mode-2 call carry SpmmLnBwd, and how many partial rows does it write?
+bool spmm_lnb_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y, const int32_t *row_blocks,
+                    const void *prepared);
+int64_t spmm_lnb_units(int64_t n_row_blocks);
 bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
                      const int32_t *row_blocks);
 #ifdef __HIPCC__

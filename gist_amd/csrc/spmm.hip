@@ -345,6 +345,7 @@ struct L2Args {
     const int32_t *row_blocks;
     int n_blocks, n_col_tiles, row_split;
     SpmmDrop dr;
+    SpmmLnBwd ln;                // LNB instantiation only
 };
 
 #ifdef L2_PROBE_NO_LDS
@@ -415,7 +416,8 @@ __device__ __forceinline__ void l2_remote(const float *xc, int64_t ldx, bool act
     }
 }
 
-template <int DROP>      // 0 none, 1 mask on what is stored (forward), 2 masks on x and on the old y (backward)
+// LNB (with DROP == 2, one column tile): the store is the LayerNorm + ReLU backward of the layer below (SpmmLnBwd)
+template <int DROP, bool LNB = false>      // 0 none, 1 mask on what is stored (forward), 2 masks on x and on the old y (backward)
 __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // ---- workgroup -> unit: units of one block stay on one XCD (blocks b, b + 8, .. share one)
@@ -431,7 +433,11 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
     else { r0 = rbk * kL2Rows; r1 = r0 + kL2Rows; }
     r1 = min(r1, a.n_rows);
     const int nrow = r1 - r0;
-    if (nrow <= 0) return;
+    if (nrow <= 0) {
+        if constexpr (LNB)      // (an empty block still owns its rows of the partial sums)
+            for (int c = threadIdx.x; c < a.d; c += kL2Threads) a.ln.col_partials[(int64_t)unit * a.d + c] = 0.f;
+        return;
+    }
     const int nloc = min(nrow, kL2Rows);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -532,9 +538,38 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
         const float us = (rem && a.src_scale) ? a.src_scale[u] : 1.f;
         l2_remote<DROP == 2>(xc, a.ldx, active, rmask, u, us, acc, a.dr, c0);
     };
-    auto store = [&](int lr, float4 prev, float sx, float sy, float sz, float sw) {
-        if (!active) return;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);      // LNB: column sums of the dy rows this wave stored
+    auto yhat_of = [&](int lr) {                       // LNB: the row's normalised output, read early
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LNB)
+            if (active) v = *reinterpret_cast<const float4 *>(a.ln.yhat + (int64_t)(r0 + lr) * a.ln.ldy + c0);
+        return v;
+    };
+    auto store = [&](int lr, float4 prev, float4 yv, float sx, float sy, float sz, float sw) {
         const int row = r0 + lr;
+        if constexpr (LNB) {      // (every lane takes part in the row sums; lanes beyond d hold zeros)
+            const float os = lr < nloc ? rsc[lr] : (a.out_scale ? a.out_scale[row] : 1.f);
+            float4 g = make_float4(fmaf(os, sx, prev.x), fmaf(os, sy, prev.y), fmaf(os, sz, prev.z), fmaf(os, sw, prev.w));
+            if (!active) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.ln.relu) {
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            if (a.ln.rstd != nullptr) {
+                float s1 = (g.x + g.y) + (g.z + g.w);
+                float s2 = (g.x * yv.x + g.y * yv.y) + (g.z * yv.z + g.w * yv.w);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                const float m1 = s1 / (float)a.d, m2 = s2 / (float)a.d, rstd = a.ln.rstd[row];
+                g.x = rstd * (g.x - m1 - yv.x * m2); g.y = rstd * (g.y - m1 - yv.y * m2);
+                g.z = rstd * (g.z - m1 - yv.z * m2); g.w = rstd * (g.w - m1 - yv.w * m2);
+            }
+            if (!active) return;
+            *reinterpret_cast<float4 *>(a.ln.dy + (int64_t)row * a.ln.lddy + c0) = g;
+            cs.x += g.x; cs.y += g.y; cs.z += g.z; cs.w += g.w;
+            return;
+        }
+        if (!active) return;
         const float os = lr < nloc ? rsc[lr] : (a.out_scale ? a.out_scale[row] : 1.f);
         float4 *yp = reinterpret_cast<float4 *>(a.y + (int64_t)row * a.ldy + c0);
         float4 o = make_float4(fmaf(os, sx, prev.x), fmaf(os, sy, prev.y), fmaf(os, sz, prev.z),
@@ -584,7 +619,7 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
                         const float4 p = *reinterpret_cast<const float4 *>(part + w * 1024 + lane * 16);
                         sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
                     }
-                    store(lr, previous(lr), sum.x, sum.y, sum.z, sum.w);
+                    store(lr, previous(lr), yhat_of(lr), sum.x, sum.y, sum.z, sum.w);
                 }
                 ++k;
             }
@@ -616,6 +651,7 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
             const int cur = lr, cbeg = beg, cend = end, coff = off, cu = u;
             const bool crem = rem, cstaged = staged;
             const float4 prev = previous(cur);
+            const float4 yv = yhat_of(cur);
             lr = open_row(cur + step);                      // next row's indices on their way
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             l2_local(tb, min(kWave, cend - cbeg), coff, acc);
@@ -627,7 +663,7 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
                 l2_local(tb, min(kWave, cend - base), o2, acc);
                 remote(base, cend, cstaged, r2, u2, acc);
             }
-            store(cur, prev, acc[0], acc[1], acc[2], acc[3]);
+            store(cur, prev, yv, acc[0], acc[1], acc[2], acc[3]);
         }
     }
     // rows of an oversize block beyond the staged ones (their row pointers are not in LDS)
@@ -643,7 +679,21 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
             l2_local(tb, min(kWave, end - base), off, acc);
             remote(base, end, false, rem, u, acc);
         }
-        store(lr, previous(lr), acc[0], acc[1], acc[2], acc[3]);
+        store(lr, previous(lr), yhat_of(lr), acc[0], acc[1], acc[2], acc[3]);
+    }
+    if constexpr (LNB) {      // the workgroup's column sums: the waves' sums meet in LDS and are added in wave order
+        __syncthreads();      // (the long rows' partial sums are consumed)
+        *reinterpret_cast<float4 *>(part + wave * 1024 + lane * 16) = cs;
+        __syncthreads();
+        if (wave == 0 && active) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < kL2Waves; ++w) {
+                const float4 q = *reinterpret_cast<const float4 *>(part + w * 1024 + lane * 16);
+                sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+            }
+            *reinterpret_cast<float4 *>(a.ln.col_partials + (int64_t)unit * a.d + c0) = sum;
+        }
     }
 }
 
@@ -729,12 +779,19 @@ static int l2_row_split(int64_t nb, int n_col_tiles) {
     return best;
 }
 
+static int l2_split_for(int64_t nb, int n_col_tiles) {
+    const int r = tune(GIST_TUNE_SPMM_SPLIT) > 0.0 ? (int)tune(GIST_TUNE_SPMM_SPLIT) : l2_row_split(nb, n_col_tiles);
+    return r < 1 ? 1 : (r > 64 ? 64 : r);
+}
+
 static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
                             float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale,
                             const float *src_scale, int accumulate, const int32_t *row_blocks,
-                            int64_t n_row_blocks, hipStream_t st, const SpmmDrop *drop = nullptr) {
+                            int64_t n_row_blocks, hipStream_t st, const SpmmDrop *drop = nullptr,
+                            const SpmmLnBwd *ln = nullptr) {
     L2Args a;
     a.dr = SpmmDrop{};
+    a.ln = ln ? *ln : SpmmLnBwd{};
     const int dmode = (drop != nullptr && drop->p > 0.f) ? drop->mode : 0;
     if (dmode) a.dr = *drop;
     a.rowptr = rowptr; a.col = col; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
@@ -743,9 +800,7 @@ static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const flo
     const int64_t nb = row_blocks ? n_row_blocks : ceil_div(n_rows, kL2Rows);
     a.n_blocks = (int)nb;
     a.n_col_tiles = (int)ceil_div(d, 256);
-    a.row_split = tune(GIST_TUNE_SPMM_SPLIT) > 0.0 ? (int)tune(GIST_TUNE_SPMM_SPLIT)
-                                                    : l2_row_split(nb, a.n_col_tiles);
-    a.row_split = a.row_split < 1 ? 1 : (a.row_split > 64 ? 64 : a.row_split);
+    a.row_split = l2_split_for(nb, a.n_col_tiles);
     const int64_t total = nb * a.n_col_tiles * a.row_split;
     const int64_t grid = kXcds * ceil_div(total, kXcds);
     if (grid > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
@@ -755,7 +810,8 @@ static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const flo
         hipError_t e = hipSuccess;
         for (const void *fn : {reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<0>),
                                reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<1>),
-                               reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<2>)})
+                               reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<2>),
+                               reinterpret_cast<const void *>(&spmm_csr_lds2_kernel<2, true>)})
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LdsBytes);
         if (e != hipSuccess) {
@@ -764,7 +820,13 @@ static int launch_spmm_lds2(const int32_t *rowptr, const int32_t *col, const flo
         }
         once.done(dev);
     }
-    if (dmode == 1)
+    if (ln != nullptr) {
+        if (dmode != 2 || a.n_col_tiles != 1 || row_blocks == nullptr) {
+            set_error("gist_spmm_csr_drop_f32: the LayerNorm-backward store needs mode 2, d <= 256 and row blocks");
+            return GIST_EINVAL;
+        }
+        hipLaunchKernelGGL((spmm_csr_lds2_kernel<2, true>), dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
+    } else if (dmode == 1)
         hipLaunchKernelGGL(spmm_csr_lds2_kernel<1>, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
     else if (dmode == 2)
         hipLaunchKernelGGL(spmm_csr_lds2_kernel<2>, dim3((unsigned)grid), dim3(kL2Threads), kL2LdsBytes, st, a);
@@ -834,10 +896,17 @@ bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float 
     return false;
 }
 
+bool spmm_lnb_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y, const int32_t *row_blocks,
+                    const void *prepared) {
+    if (d > 256 || !spmm_drop_takes(2, d, ldx, ldy, x, y, row_blocks)) return false;
+    return !(prepared != nullptr && aligned16(prepared) && spmm_dense32_takes(d, ldx, ldy));
+}
+int64_t spmm_lnb_units(int64_t n_row_blocks) { return n_row_blocks * l2_split_for(n_row_blocks, 1); }
+
 int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y, int64_t ldy,
               int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale, int accumulate,
               const int32_t *row_blocks, int64_t n_row_blocks, const SpmmDrop &dr, hipStream_t st,
-              const void *prepared) {
+              const void *prepared, const SpmmLnBwd *ln) {
     GIST_REQUIRE(n_rows >= 0 && d >= 0, "gist_spmm_csr_drop_f32: negative size");
     if (n_rows == 0 || d == 0) return GIST_OK;
     GIST_REQUIRE(rowptr && x && y, "gist_spmm_csr_drop_f32: null pointer");
@@ -847,6 +916,14 @@ int spmm_drop(const int32_t *rowptr, const int32_t *col, const float *x, int64_t
     GIST_REQUIRE(dr.p >= 0.f && dr.p < 1.f && dr.ld >= d, "gist_spmm_csr_drop_f32: bad mask description");
     GIST_REQUIRE(spmm_drop_takes(dr.mode, d, ldx, ldy, x, y, row_blocks),
                  "gist_spmm_csr_drop_f32: this shape cannot carry the mask (use gist_dropout_f32)");
+    if (ln != nullptr) {
+        GIST_REQUIRE(dr.mode == 2 && dr.p > 0.f && spmm_lnb_takes(d, ldx, ldy, x, y, row_blocks, prepared) && ln->yhat &&
+                         ln->dy && ln->col_partials && ln->ldy >= d && ln->lddy >= d && ln->ldy % 4 == 0 &&
+                         ln->lddy % 4 == 0 && aligned16(ln->yhat) && aligned16(ln->dy) && aligned16(ln->col_partials),
+                     "gist_spmm_csr_drop_f32: this call cannot carry the LayerNorm backward");
+        return launch_spmm_lds2(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate, row_blocks,
+                                n_row_blocks, st, &dr, ln);
+    }
     if (prepared != nullptr && aligned16(prepared) && spmm_dense32_takes(d, ldx, ldy))
         return launch_spmm_dense32(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate,
                                    row_blocks, n_row_blocks, prepared, st, &dr);

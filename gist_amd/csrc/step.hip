@@ -244,11 +244,13 @@ B3Step b3_layout(const gist_step_plan *p, char *base) {
 
 // ---- fused sequence: slabs of the deferred split-K projections, bias-gradient chunk sums -------------
 namespace {
+constexpr int64_t kLnbMaxUnits = 256;
 struct FusedLayout {
     float *dw_slabs[GIST_MAX_LAYERS]; int64_t dw_bytes[GIST_MAX_LAYERS];   // dW_k = dY_k^T . Z_k
     float *logit_slabs; int64_t logit_bytes;                               // class layer's Y = Z . W^T
     float *y_slabs; int64_t y_bytes;      // a hidden layer's Y = Z . W^T until its LayerNorm has read it (one buffer)
-    float *partials[GIST_MAX_LAYERS];                                      // [row_chunks16(n_max)][n_out_k]
+    float *partials[GIST_MAX_LAYERS];                                      // [partial_rows[k] >= row_chunks16(n_max)][n_out_k]
+    int64_t partial_rows[GIST_MAX_LAYERS];
     int64_t bytes, partial_floats;
 };
 
@@ -300,7 +302,11 @@ FusedLayout fused_layout(const gist_step_plan *p, char *base, float *partials) {
         }
         f.dw_slabs[k] = f.dw_bytes[k] > 0 ? take(f.dw_bytes[k]) : nullptr;
         f.partials[k] = partials ? partials + poff : nullptr;
-        poff += ceil_div(chunks * l.n_out, 64) * 64;
+        // (a hidden layer of <= 256 columns may get its chunk sums from the reverse aggregation above it: one row per
+        // workgroup of that launch, at most kLnbMaxUnits of them)
+        const int64_t rows = (k + 1 < L1 && l.n_out <= 256 && chunks < kLnbMaxUnits) ? kLnbMaxUnits : chunks;
+        f.partial_rows[k] = rows;
+        poff += ceil_div(rows * l.n_out, 64) * 64;
     }
     const gist_layer_desc &last = p->layer[L1 - 1];
     f.logit_bytes = slab_need(2 * last.n_in, last.n_out, p->n_max, false);
@@ -703,11 +709,13 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     gist_grad_segment segs[2 * GIST_MAX_LAYERS];
     int n_segs = 0;
     const int64_t chunks16 = gist_row_chunks16(n);
-    auto bias_segment = [&](int k) {      // db_k = chunk sums, formed by the optimiser
+    int64_t lnb_rows = 0;           // > 0: the layer below got its LayerNorm backward (and that many rows of partial sums) from
+                                    // the reverse aggregation just launched
+    auto bias_segment = [&](int k, int64_t rows) {      // db_k = chunk sums, formed by the optimiser
         const gist_layer_desc &l = p->layer[k];
         gist_grad_segment &g = segs[n_segs++];
         g.begin = l.db - p->grads; g.end = g.begin + l.n_out;
-        g.src = fl.partials[k]; g.stride = l.n_out; g.n_src = (int32_t)chunks16;
+        g.src = fl.partials[k]; g.stride = l.n_out; g.n_src = (int32_t)rows;
     };
     ClassDwArgs dw_args{};          // the class layer's weight-gradient slabs, deferred to the LayerNorm backward below it
     bool dw_pending = false;
@@ -716,12 +724,16 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         const float *dy;
         int64_t lddy;
         bool db_done = false;      // this layer's bias gradient is already in chunks
+        const int64_t db_rows = lnb_rows > 0 ? lnb_rows : chunks16;
         if (k == L1 - 1) {
             dy = p->dlogits;
             lddy = p->ldc;
         } else {
             const int64_t i_next = p->layer[k + 1].n_in;      // == l.n_out
-            if (defer && plain[k]) {
+            if (lnb_rows > 0) {      // (came with the reverse aggregation of layer k + 1)
+                db_done = true;
+                lnb_rows = 0;
+            } else if (defer && plain[k]) {
                 if (dw_pending) {      // ... with the class layer's weight-gradient slabs in the same grid
                     GIST_TRY(ln_relu_bwd_colsum_class_dw(p->dZ, 2 * i_next, l.Y, l.ldy, p->use_layernorm ? l.rstd : nullptr,
                                                          l.Y, l.ldy, n, l.n_out, p->use_layernorm, 1, fl.partials[k], dw_args,
@@ -907,7 +919,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
         if (defer) {
             if (!db_done)      // (a one-layer model: no dZ kernel has seen dlogits)
                 GIST_TRY(colsum_rows16(dy, lddy, n, l.n_out, fl.partials[k], k == L1 - 1 ? false : true, st));
-            bias_segment(k);
+            bias_segment(k, db_rows);
         } else {
             GIST_TRY(gist_colsum_f32(dy, lddy, n, l.n_out, p->partials, l.db, s));
         }
@@ -917,8 +929,22 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
                 SpmmDrop dr{};
                 dr.mode = 2; dr.p = p->p_drop; dr.scale = keep; dr.sm = sm;
                 dr.y_base = offs[k]; dr.src_base = offs[k] + (uint64_t)l.n_in; dr.ld = 2 * l.n_in;
+                // the LayerNorm + ReLU backward of layer k - 1 in this launch's store (its rows are whole in one wave)
+                const gist_layer_desc &lo = p->layer[k - 1];
+                SpmmLnBwd ln{};
+                const int64_t units = blocked ? spmm_lnb_units(p->n_row_blocks) : 0;
+                const bool with_ln = defer && plain[k - 1] && !dw_pending && (int)tune(GIST_TUNE_LNB_FUSED) != 1 &&
+                                     units > 0 && units <= fl.partial_rows[k - 1] && lo.ldy % 4 == 0 && aligned16(lo.Y) &&
+                                     (!p->use_layernorm || lo.rstd != nullptr) &&
+                                     spmm_lnb_takes(l.n_in, 2 * l.n_in, 2 * l.n_in, p->dZ + l.n_in, p->dZ, p->row_blocks, prep_bwd);
+                if (with_ln) {
+                    ln.yhat = lo.Y; ln.ldy = lo.ldy; ln.rstd = p->use_layernorm ? lo.rstd : nullptr;
+                    ln.dy = lo.Y; ln.lddy = lo.ldy; ln.col_partials = fl.partials[k - 1]; ln.relu = 1;
+                    lnb_rows = units;
+                }
                 GIST_TRY(spmm_drop(p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ, 2 * l.n_in, n,
-                                   l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st, prep_bwd));
+                                   l.n_in, nullptr, p->norm, 1, p->row_blocks, p->n_row_blocks, dr, st, prep_bwd,
+                                   with_ln ? &ln : nullptr));
             } else {
                 GIST_TRY(step_spmm(p, p->t_rowptr, p->t_col, p->dZ + l.n_in, 2 * l.n_in, p->dZ,
                                    2 * l.n_in, n, l.n_in, nullptr, p->norm, 1, prep_bwd, s));
