@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class GistLibraryError(RuntimeError):
@@ -87,6 +87,9 @@ SIGNATURES = {
                                       _u64, _u64, _u64, _i64, _p]),
     'gist_spmm_csr_drop_prepared_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _int, _p, _i64, _int, _f,
                                                _u64, _u64, _u64, _i64, _p, _p]),
+    'gist_spmm_csr_drop_lnbwd_f32': (_int, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _f, _u64, _u64, _u64, _i64,
+                                            _p, _i64, _p, _p, _i64, _p, _i64, _int, _p]),
+    'gist_spmm_lnb_units': (_i64, [_i64]),
     'gist_spmm_block_image_bytes': (_i64, []),
     'gist_spmm_block_units_f32': (_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),
     'gist_spmm_block_chains_f32': (_int, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),

@@ -139,6 +139,25 @@ int64_t spmm_lnb_units(int64_t n_row_blocks);
 bool spmm_drop_takes(int mode, int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y,
                      const int32_t *row_blocks);
 #ifdef __HIPCC__
+// Sum over the 64 lanes of a wave, the same bits in every lane.  Within a row of 16 lanes on the DPP path of the vector unit
+// (lane ^ 1, lane ^ 2 as quad permutes; the other quad of the half row and the other half row as mirrors -- every lane of a
+// quad / half row holds the same partial sum by then), the four rows through the scalar unit: 4 + 4 + 3 instructions, none of
+// them on the LDS pipe (the __shfl_xor butterfly is six dependent ds_bpermute round trips).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+    v += dpp_move<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+    v += dpp_move<0x141>(v);      // row_half_mirror
+    v += dpp_move<0x140>(v);      // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
 // gist_dropout_f32's keep/scale factor of element idx, of VEC consecutive elements, of an aligned quad
 __device__ __forceinline__ float drop_keep(uint64_t idx, uint64_t sm, float p, float scale) {
     const uint64_t h = splitmix64((idx >> 1) + sm);

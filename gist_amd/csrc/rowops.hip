@@ -13,12 +13,7 @@
 
 namespace gist {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
+// (wave_sum: common.h)
 // Sum over the TPR threads that own one row (TPR = 64: a wave; TPR = 256: the block).
 template <int TPR>
 __device__ __forceinline__ float row_sum(float v, float *red) {

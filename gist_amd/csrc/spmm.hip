@@ -558,8 +558,8 @@ __global__ __launch_bounds__(kL2Threads) void spmm_csr_lds2_kernel(L2Args a) {
             if (a.ln.rstd != nullptr) {
                 float s1 = (g.x + g.y) + (g.z + g.w);
                 float s2 = (g.x * yv.x + g.y * yv.y) + (g.z * yv.z + g.w * yv.w);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
                 const float m1 = s1 / (float)a.d, m2 = s2 / (float)a.d, rstd = a.ln.rstd[row];
                 g.x = rstd * (g.x - m1 - yv.x * m2); g.y = rstd * (g.y - m1 - yv.y * m2);
                 g.z = rstd * (g.z - m1 - yv.z * m2); g.w = rstd * (g.w - m1 - yv.w * m2);
@@ -963,6 +963,26 @@ extern "C" int gist_spmm_csr_drop_f32(const int32_t *rowptr, const int32_t *col,
     return gist::spmm_drop(rowptr, col, x, ldx, y, ldy, n_rows, d, out_scale, src_scale, accumulate, row_blocks,
                            n_row_blocks, dr, gist::as_stream(stream));
 }
+
+extern "C" int gist_spmm_csr_drop_lnbwd_f32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
+                                            const float *y, int64_t ldy, int64_t n_rows, int64_t d, const float *src_scale,
+                                            const int32_t *row_blocks, int64_t n_row_blocks, float p, uint64_t seed,
+                                            uint64_t y_offset, uint64_t src_offset, int64_t mask_ld, const float *yhat,
+                                            int64_t ldyh, const float *rstd, float *dy, int64_t lddy, float *col_partials,
+                                            int64_t partial_rows, int relu, gist_stream_t stream) {
+    using namespace gist;
+    GIST_REQUIRE(row_blocks != nullptr && n_row_blocks > 0 && partial_rows >= spmm_lnb_units(n_row_blocks),
+                 "gist_spmm_csr_drop_lnbwd_f32: col_partials has fewer than gist_spmm_lnb_units(n_row_blocks) rows");
+    SpmmDrop dr{};
+    dr.mode = 2; dr.p = p; dr.scale = (p > 0.f && p < 1.f) ? 1.0f / (1.0f - p) : 1.f;
+    dr.sm = seed * 0x9E3779B97F4A7C15ULL; dr.y_base = y_offset; dr.src_base = src_offset; dr.ld = mask_ld;
+    SpmmLnBwd ln{};
+    ln.yhat = yhat; ln.ldy = ldyh; ln.rstd = rstd; ln.dy = dy; ln.lddy = lddy; ln.col_partials = col_partials; ln.relu = relu;
+    return spmm_drop(rowptr, col, x, ldx, const_cast<float *>(y), ldy, n_rows, d, nullptr, src_scale, 1, row_blocks,
+                     n_row_blocks, dr, as_stream(stream), nullptr, &ln);
+}
+
+extern "C" int64_t gist_spmm_lnb_units(int64_t n_row_blocks) { return n_row_blocks > 0 ? gist::spmm_lnb_units(n_row_blocks) : 0; }
 
 extern "C" int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx,
                                                float *y, int64_t ldy, int64_t n_rows, int64_t d,

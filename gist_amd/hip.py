@@ -584,6 +584,35 @@ def spmm_drop(rowptr, col, x, y, mode, p, seed, y_offset, src_offset, mask_ld, o
     return y
 
 
+def spmm_lnb_units(n_row_blocks):
+    return int(_lib.load().gist_spmm_lnb_units(int(n_row_blocks)))
+
+
+def spmm_drop_lnbwd(rowptr, col, x, y, p, seed, y_offset, src_offset, mask_ld, yhat, dy, col_partials, src_scale=None,
+                    row_blocks=None, rstd=None, relu=True):
+    """gist_spmm_csr_drop_lnbwd_f32: d_out = mask(y) + A . (src_scale . mask(x)); dy = LayerNorm + ReLU backward of d_out
+    (yhat, rstd); col_partials [spmm_lnb_units][d] = column sums of dy per workgroup."""
+    L = _lib.load()
+    n = rowptr.numel() - 1
+    xp, ldx = _mat(x, 'x')
+    yp, ldy = _mat(y, 'y')
+    d = x.shape[1]
+    hp, ldh = _mat(yhat, 'yhat')
+    dp, lddy = _mat(dy, 'dy')
+    cp, ldc = _mat(col_partials, 'col_partials')
+    if ldc != d:
+        raise ValueError('col_partials must be contiguous [rows][d]')
+    nb = 0 if row_blocks is None else row_blocks.numel() - 1
+    with _Timed('spmm', (n, x.shape[0], d)):
+        rc = L.gist_spmm_csr_drop_lnbwd_f32(
+            _vec(rowptr, 'rowptr', torch.int32), _vec(col, 'col', torch.int32), xp, ldx, yp, ldy, n, d,
+            _opt(src_scale, 'src_scale', torch.float32, x.shape[0]), _opt(row_blocks, 'row_blocks', torch.int32), nb,
+            float(p), int(seed), int(y_offset), int(src_offset), int(mask_ld), hp, ldh,
+            _opt(rstd, 'rstd', torch.float32, n), dp, lddy, cp, int(col_partials.shape[0]), int(bool(relu)), _stream())
+    _lib.check(rc, 'gist_spmm_csr_drop_lnbwd_f32')
+    return dy
+
+
 def gemm_dual_takes(dy, w, z, dz):
     """Does gist_gemm_nn_tn_dual_f32 take this hidden layer's backward (dy [m, k], w [k, n], z [m, n], dz [m, n])?"""
     L = _lib.load()

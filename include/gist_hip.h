@@ -130,6 +130,22 @@ int gist_spmm_csr_drop_prepared_f32(const int32_t *rowptr, const int32_t *col,
                                     const int32_t *row_blocks, int64_t n_row_blocks,
                                     int mode, float p, uint64_t seed, uint64_t y_offset, uint64_t src_offset,
                                     int64_t mask_ld, const void *prepared, gist_stream_t stream);
+/* The reverse aggregation of layer k + 1 (gist_spmm_csr_drop_f32 mode 2, accumulate, src_scale = 1 / deg) whose STORE is the
+ * LayerNorm + ReLU backward of layer k (cluster_gcn/modules.py:232-237 differentiated), for rows of at most 256 floats with
+ * locality blocks -- one wave holds a whole row in the LDS-staged kernel (config 2, --n-hidden <= 256; round 5, ABI 15).  What
+ * would be written to y is d_out; dy = rstd . (g - mean(g) - yhat . mean(g . yhat)), g = d_out . [yhat > 0] (rstd = NULL: dy =
+ * g), goes to dy (may be yhat itself), y is only read.  col_partials [gist_spmm_lnb_units(n_row_blocks)][d] receives the
+ * column sums of the dy rows each workgroup stored: the bias gradient is the sum of those rows in order
+ * (gist_adam_segments_f32 forms it).  dy equals gist_ln_relu_bwd_colsum_f32's to fp32 rounding.  Needs 0 < p < 1 (a step without
+ * dropout keeps the separate launches), d % 4 == 0, 128 <= d <= 256.  The FORWARD counterpart (LayerNorm + ReLU of layer k
+ * formed in the staging of layer k + 1's aggregation) was built and measured out: profiles/NEGATIVES.md. */
+int gist_spmm_csr_drop_lnbwd_f32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, const float *y,
+                                 int64_t ldy, int64_t n_rows, int64_t d, const float *src_scale, const int32_t *row_blocks,
+                                 int64_t n_row_blocks, float p, uint64_t seed, uint64_t y_offset, uint64_t src_offset,
+                                 int64_t mask_ld, const float *yhat, int64_t ldyh, const float *rstd, float *dy, int64_t lddy,
+                                 float *col_partials, int64_t partial_rows, int relu, gist_stream_t stream);
+int64_t gist_spmm_lnb_units(int64_t n_row_blocks);      /* rows of col_partials the call writes (host function) */
+
 /* 1 if an aggregation of this width runs on the kernel the prepared block structure is built for (the bf16x3
  * matrix-core kernel, from 1536 columns on): a caller that aggregates over a batch more than once should then
  * prepare its blocks -- and every other prepared call of the batch may use the structure too (the fp32 block-dense

@@ -555,3 +555,39 @@ def test_gemm_nn_tn_dual_equals_the_two_launches(hip, m, n, k):
     ref = dy.double().t() @ z.double()
     got = slabs[:ns * k * n].view(ns, k, n).double().sum(0) if ns > 1 else dw.double()
     assert (got - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('n,d,use_ln,n_blocks', [(700, 256, True, 7), (2046, 256, True, 20), (500, 128, True, 5), (900, 192, False, 9),
+                                                 (600, 256, True, 4)])      # (blocks of 150 rows: beyond the staged tile)
+def test_reverse_aggregation_with_the_layernorm_backward_in_its_store(hip, n, d, use_ln, n_blocks):
+    """gist_spmm_csr_drop_lnbwd_f32 == the mode-2 reverse aggregation followed by gist_ln_relu_bwd_colsum_f32: dy and the bias
+    gradient (sum of the partial rows) to fp32 rounding (the same formulas; the compiler contracts them into FMAs its own way in
+    each kernel), bit for bit without LayerNorm."""
+    rp, cl, trp, tcl, rb = block_graph(n, n_blocks, 10, 1, seed=n + d, hub=300)
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    dz = torch.randn(n, 2 * d, device=DEV, generator=gen)
+    yhat = torch.randn(n, d, device=DEV, generator=gen)
+    rstd = torch.rand(n, device=DEV, generator=gen) + 0.5
+    norm = hip.in_degree_norm(rp)
+    p, seed, off = 0.25, 5, 64
+    ref = dz.clone()
+    hip.spmm_drop(trp, tcl, ref[:, d:], ref[:, :d], 2, p, seed, off, off + d, 2 * d, src_scale=norm, accumulate=True, row_blocks=rb)
+    dy_ref = torch.zeros(n, d, device=DEV)
+    chunks = torch.zeros((n + 15) // 16, d, device=DEV)
+    hip.ln_relu_bwd_colsum(ref[:, :d], yhat, rstd if use_ln else None, dy_ref, use_ln, True, chunks)
+    new = dz.clone()
+    units = hip.spmm_lnb_units(n_blocks)
+    assert units >= n_blocks
+    parts = torch.full((units, d), float('nan'), device=DEV)
+    y_io = yhat.clone()                                   # in place, as the step runs it
+    hip.spmm_drop_lnbwd(trp, tcl, new[:, d:], new[:, :d], p, seed, off, off + d, 2 * d, y_io, y_io, parts, src_scale=norm,
+                        row_blocks=rb, rstd=rstd if use_ln else None)
+    if use_ln:
+        err_dy = (y_io - dy_ref).abs().max().item()
+        assert err_dy <= 2e-6 * max(1.0, dy_ref.abs().max().item()), err_dy
+    else:
+        assert torch.equal(y_io, dy_ref)
+    assert torch.equal(new, dz)                           # (y is only read)
+    db_ref = dy_ref.double().sum(0)
+    err = (parts.double().sum(0) - db_ref).abs().max().item()
+    assert err <= 1e-5 * max(1.0, db_ref.abs().max().item()), err
