@@ -634,6 +634,7 @@ static void b3c_choice(int64_t m, int64_t n, int64_t k, int *tm, int *tn, int *s
     if (wgs < 128) sp = 256 / wgs;                            // (only reachable through the tuning hook)
     if (sp > kt / 8) sp = kt / 8;                             // a slice keeps >= 8 k tiles
     if (t_split > 0) sp = t_split;
+    if ((int)tune(GIST_TUNE_B3C_SPLITS) > 0) sp = (int)tune(GIST_TUNE_B3C_SPLITS);
     if (sp > kt) sp = kt;
     *splits = (int)(sp < 1 ? 1 : sp);
 }

@@ -263,7 +263,8 @@ int64_t slab_need(int64_t m, int64_t n, int64_t k_max, bool k_is_rows) {
     static thread_local int memo_n = 0;
     const int mode = gist_gemm_get_mode();
     // (tuning overrides change tile and slice choices: neither read nor fill the memo while one is set)
-    const bool tuned = tune(GIST_TUNE_GEMM_TILE) != 0.0 || tune(GIST_TUNE_GEMM_SPLITS) != 0.0 || tune(GIST_TUNE_B3C) != 0.0;
+    const bool tuned = tune(GIST_TUNE_GEMM_TILE) != 0.0 || tune(GIST_TUNE_GEMM_SPLITS) != 0.0 || tune(GIST_TUNE_B3C) != 0.0 ||
+                       tune(GIST_TUNE_B3C_SPLITS) != 0.0;
     for (int i = 0; i < memo_n && !tuned; ++i)
         if (memo[i].m == m && memo[i].n == n && memo[i].k == k_max && memo[i].rows == (int)k_is_rows && memo[i].mode == mode)
             return memo[i].need;
