@@ -543,6 +543,12 @@ def drop_shared_dataset(name):
 
 def main():
     args = parse()
+    # Host hygiene (profiles/r05_module_path.md): the OpenMP workers of any multi-threaded CPU tensor operation of the set-up
+    # (parameter initialisation, a pinned copy) spin-wait afterwards by default; inside a container with a CPU quota that burns
+    # the period's quota and the kernel freezes the whole process for tens of ms -- in the middle of a timed region.  Passive
+    # waiting, before torch loads its OpenMP runtime.
+    for k_, v_ in (('OMP_WAIT_POLICY', 'PASSIVE'), ('GOMP_SPINCOUNT', '0'), ('KMP_BLOCKTIME', '0')):
+        os.environ.setdefault(k_, v_)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 
@@ -895,6 +901,8 @@ def main():
         if collect:       # (host hygiene, before a timed region only: no generation-2 pass of the cyclic GC over the
             gc.collect()  # process's ~10^6 long-lived objects inside it: 20-70 ms of host time, profiles/r05_module_path.md)
             gc.freeze()
+            torch.cuda.synchronize(dev)
+            time.sleep(0.12)      # (the set-up's CPU bursts belong to an earlier CFS period than the region's first step)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
