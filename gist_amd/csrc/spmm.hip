@@ -767,11 +767,12 @@ static int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *x
 
 // Row split R of the second LDS design: units = blocks x column tiles x R on 256 CUs, one unit
 // per CU at a time; every split re-stages the tile (cost ~1) and gathers 1/R of the block's rows
-// (cost ~2.5 / R), fitted to scripts/spmm_probe.py on a Reddit-like batch.
+// (cost ~2.5 / R), fitted to scripts/spmm_probe.py on a Reddit-like batch.  (R up to 16 since round 5: 20 blocks of <= 256
+// columns take R = 12 = 240 units in one round -- config 2 0.2994 -> 0.2918 ms/step against R = 8, h = 256 0.1782 -> 0.1741.)
 static int l2_row_split(int64_t nb, int n_col_tiles) {
     int best = 1;
     double best_cost = 1e30;
-    for (int r = 1; r <= 8; ++r) {
+    for (int r = 1; r <= 16; ++r) {
         const double rounds = (double)ceil_div(nb * n_col_tiles * r, 256);
         const double cost = rounds * (1.0 + 3.0 / r);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
