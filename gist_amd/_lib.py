@@ -136,7 +136,7 @@ SIGNATURES = {
 
 GIST_MAX_LAYERS = 16
 TUNE = {'h3_min_gflop': 0, 'h3_min_tiles': 1, 'h3_tm': 2, 'gemm_tile': 3, 'gemm_splits': 4,
-        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9, 'gemm_dual': 10, 'host_threads': 11, 'lnb_fused': 12, 'b3c_splits': 13}
+        'spmm_chunk': 5, 'spmm_split': 6, 'spmm_kernel': 7, 'b3c': 8, 'class_fused': 9, 'gemm_dual': 10, 'host_threads': 11, 'lnb_fused': 12, 'b3c_splits': 13, 'b3_tail': 14}
 GIST_STEP_EXTRACT = 1
 GIST_STEP_TRAIN = 2
 GIST_STEP_EXTRACT_NEXT = 4

@@ -172,6 +172,13 @@ struct B3Args {
     int tiles_m, tiles_n;
     int kt_per_split;                    // k tiles per blockIdx.y (even); split s writes c + s * split_stride
     int64_t split_stride;
+    // Tail units (one k slice, tiles > one per CU): the first dp_tiles logical tiles run whole, one workgroup
+    // each; every remaining tile is cut into tail_splits k slices of tail_kt k tiles (even), one workgroup
+    // each (blockIdx.x = dp_tiles + tile * tail_splits + slice), which leave their accumulators at
+    // tail_partials[unit][16 registers][512 threads] x 16 B; gemm_b3_tail_sum_kernel, the next launch,
+    // sums a tile's partials in slice order and stores C (+ bias).
+    int dp_tiles, tail_splits, tail_kt;
+    float *tail_partials;
 };
 
 // DMA instruction `inst` of an image: slot L = 64 (inst % 3) + lane of 16-row slab inst / 3; slot
@@ -219,10 +226,14 @@ __device__ unsigned long long g_b3_clock[2 * 4096];
 __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     extern __shared__ __attribute__((aligned(16))) char b3_smem[];
     constexpr int NI = 4, NJ = 4;                 // 16-row slabs per wave: 64 x 64 wave tile
-    const int nwg = g.tiles_m * g.tiles_n;
+    const int nwg = g.dp_tiles;
     const int orig = blockIdx.x;
+    const bool tail = orig >= nwg;       // a k slice of one of the tiles past the last full round
+    const int tail_tile = tail ? (orig - nwg) / g.tail_splits : 0;
+    const int tail_slice = tail ? (orig - nwg) % g.tail_splits : 0;
     const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
-    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
+    const int L = tail ? nwg + tail_tile
+                       : (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
     constexpr int GM = 8;
     const int width = GM * g.tiles_n;
     const int group = L / width;
@@ -231,8 +242,9 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     const int bm = first_m + (L % width) % gsz;
     const int bn = (L % width) / gsz;
     const int row0 = bm * B3_TM, col0 = bn * B3_TN;
-    const int kt0 = (int)blockIdx.y * g.kt_per_split;                   // split-K: this workgroup's k tiles
-    const int n_kt = min(g.kpad / B3_BK - kt0, g.kt_per_split);
+    // split-K: this workgroup's k tiles
+    const int kt0 = tail ? tail_slice * g.tail_kt : (int)blockIdx.y * g.kt_per_split;
+    const int n_kt = min(g.kpad / B3_BK - kt0, tail ? g.tail_kt : g.kt_per_split);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -290,9 +302,15 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     // cycles are 0.79 / 0.84 of the k loop's cycles at 1.95 / 1.93 GHz, against 0.71 / 0.80 at
     // 2.08 / 1.96 GHz with the barrier at the end of the step -- the chip gives back in clock most of
     // what the pipe share gains (power), the loop itself is 2-4 % shorter (508 vs 531 us).
+    // A wave whose 64 rows all lie past the end of C (the last row tile of a batch a few rows over a multiple of 256)
+    // stages its share of the images and meets the barriers, nothing else: its SIMD's other wave has the pipe alone.
+    const bool live = __builtin_amdgcn_readfirstlane(row0 + wm * (16 * NI) < g.m);
     bf16x8 a[NI][3], b[NJ][3];
     auto read_head = [&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
+#ifndef B3_NO_DEAD_SKIP
+        if (!live) return;
+#endif
 #pragma unroll
         for (int j = 0; j < NJ; ++j) b[j][0] = *reinterpret_cast<const bf16x8 *>(fb[st][0] + j * 3072);
 #pragma unroll
@@ -302,6 +320,9 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     };
     auto read_rest = [&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
+#ifndef B3_NO_DEAD_SKIP
+        if (!live) return;
+#endif
 #pragma unroll
         for (int j = 0; j < NJ; ++j) b[j][1] = *reinterpret_cast<const bf16x8 *>(fb[st][1] + j * 3072);
 #pragma unroll
@@ -324,6 +345,9 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     // (`late`) issue 16 MFMAs before each of the two non-MFMA blocks of the step.
     auto mfmas = [&](auto t0_c, auto t1_c) {
         constexpr int t0 = decltype(t0_c)::value, t1 = decltype(t1_c)::value;
+#ifndef B3_NO_DEAD_SKIP
+        if (!live) return;
+#endif
 #pragma unroll
         for (int t = t0; t < t1; ++t) {
             const int term = t / (NI * NJ), i = (t % (NI * NJ)) / NJ, j = t % NJ;
@@ -385,9 +409,23 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
     // the MFMAs above are opaque to the compiler's hazard recognizer: let the last ones retire
     // before the accumulators are read (4 passes + write-back)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int rows_valid = min(g.m - row0, B3_TM);
+    if (tail) {
+        // A wave whose 64 rows lie past the end of C has nothing to exchange (the usual tail tile is the
+        // few rows a batch has beyond a multiple of 256).
+        const bool rows_live = wm * (16 * NI) < rows_valid;
+        b3_f32x4 *mine = reinterpret_cast<b3_f32x4 *>(g.tail_partials) +
+                         (int64_t)(tail_tile * g.tail_splits + tail_slice) * (NI * NJ * B3_THREADS) + threadIdx.x;
+        if (rows_live) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mine[(i * NJ + j) * B3_THREADS] = acc[i][j];
+        }
+        return;                                      // gemm_b3_tail_sum_kernel, the next launch, finishes these tiles
+    }
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
     float *cbase = g.c + (int64_t)blockIdx.y * g.split_stride + (int64_t)row0 * g.ldc + col0;
-    const int rows_valid = min(g.m - row0, B3_TM);
     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
         cbase, 0, (int)((int64_t)rows_valid * g.ldc * 4), 0x00020000);
     const uint32_t ldc_b = (uint32_t)g.ldc * 4;
@@ -414,6 +452,30 @@ __global__ __launch_bounds__(B3_THREADS, 2) void gemm_b3_kernel(B3Args g) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, cvoff[j] + roff, 0, 0);
             }
         }
+}
+
+// The tiles the tail units computed: C tile = sum over its k slices of the partials, in slice order (+ bias).
+// Grid (tile, accumulator register 0..15); a thread holds the element(s) its twin in gemm_b3_kernel held.
+__global__ __launch_bounds__(B3_THREADS) void gemm_b3_tail_sum_kernel(B3Args g) {
+    constexpr int NI = 4, NJ = 4, GM = 8;
+    const int L = g.dp_tiles + (int)blockIdx.x;
+    const int width = GM * g.tiles_n;
+    const int first_m = (L / width) * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int row0 = (first_m + (L % width) % gsz) * B3_TM, col0 = ((L % width) / gsz) * B3_TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, rr = lane & 15, kg = lane >> 4;
+    const int reg = blockIdx.y, i = reg / NJ, j = reg % NJ;
+    const int row = row0 + wm * (16 * NI) + i * 16 + 4 * kg, col = col0 + wn * (16 * NJ) + j * 16 + rr;
+    if (row0 + wm * (16 * NI) >= g.m || col >= g.n) return;      // (the first test is the one the producer made)
+    const b3_f32x4 *part = reinterpret_cast<const b3_f32x4 *>(g.tail_partials) +
+                           ((int64_t)blockIdx.x * g.tail_splits * (NI * NJ) + reg) * B3_THREADS + threadIdx.x;
+    b3_f32x4 sum = part[0];
+    for (int q = 1; q < g.tail_splits; ++q) sum += part[(int64_t)q * (NI * NJ) * B3_THREADS];
+    const float bv = g.bias != nullptr ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (row + e < g.m) g.c[(int64_t)(row + e) * g.ldc + col] = sum[e] + bv;
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -445,9 +507,40 @@ int b3_splits(int64_t m, int64_t n, int64_t k) {
     const int64_t per = ceil_div(ceil_div(n_kt, s), 2) * 2;
     return (int)ceil_div(n_kt, per);
 }
+// Tail units: with one k slice and T tiles on P = 256 one-workgroup CUs the last round holds r = T mod P
+// tiles and leaves P - r CUs idle for a whole tile's k loop (a batch of 2049-2304 rows has a ninth row
+// tile: 288 tiles = one round + 32, twice the time of 256).  The r tiles of that round are cut into
+// floor(P / r) k slices of >= 8 k tiles, one workgroup each, so the round lasts 1 / slices of a tile;
+// the slices of a tile meet through fp32 partials that the last one to arrive sums in slice order
+// (gemm_b3_kernel).  Nothing here depends on anything but the shape.
+struct B3Tail { int dp_tiles, splits, kt; };
+constexpr int B3_CUS = 256;
+static B3Tail b3_tail(int64_t m, int64_t n, int64_t k) {
+    const int64_t tiles = ceil_div(m, B3_TM) * ceil_div(n, B3_TN);
+    B3Tail t{(int)tiles, 1, 0};
+    if (tune(GIST_TUNE_B3_TAIL) == 1.0 || tiles <= B3_CUS) return t;
+    const int64_t r = tiles % B3_CUS;
+    if (r == 0 || r > B3_CUS / 2) return t;
+    const int64_t n_kt = b3_kpad(k) / B3_BK;
+    int64_t s = B3_CUS / r;
+    if (s > n_kt / 8) s = n_kt / 8;
+    if (s < 2) return t;
+    const int64_t per = ceil_div(ceil_div(n_kt, s), 2) * 2;
+    s = ceil_div(n_kt, per);
+    if (s < 2) return t;
+    t.dp_tiles = (int)(tiles - r); t.splits = (int)s; t.kt = (int)per;
+    return t;
+}
+static int64_t b3_tail_bytes(int64_t m, int64_t n, int64_t k) {
+    const B3Tail t = b3_tail(m, n, k);
+    if (t.splits < 2) return 0;
+    const int64_t r = ceil_div(m, B3_TM) * ceil_div(n, B3_TN) - t.dp_tiles;
+    return r * t.splits * (int64_t)(B3_TM * B3_TN * 4);
+}
+// scratch of one call: fp32 slabs of a split-K call, or the partials of its tail units (never both)
 int64_t b3_slab_bytes(int64_t m, int64_t n, int64_t k) {
     const int s = b3_splits(m, n, k);
-    return s > 1 ? (int64_t)s * m * n * 4 : 0;
+    return s > 1 ? (int64_t)s * m * n * 4 : b3_tail_bytes(m, n, k);
 }
 
 // Shapes the bf16x3 path takes: enough workgroups (256 x 128 tiles x k slices) to occupy the chip, and
@@ -525,10 +618,27 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
     splits = (int)ceil_div(n_kt, g.kt_per_split);
     g.split_stride = 0;
     if (splits > 1) { g.c = slabs; g.ldc = n; g.split_stride = m * n; g.bias = nullptr; }
+    g.dp_tiles = g.tiles_m * g.tiles_n; g.tail_splits = 1; g.tail_kt = 0;
+    g.tail_partials = nullptr;
+    unsigned grid_x = (unsigned)g.dp_tiles;
+    if (splits == 1 && slabs != nullptr && aligned16(slabs)) {
+        const B3Tail t = b3_tail(m, n, k);
+        if (t.splits > 1 && slab_bytes >= b3_tail_bytes(m, n, k)) {
+            const int r = g.dp_tiles - t.dp_tiles;
+            g.dp_tiles = t.dp_tiles; g.tail_splits = t.splits; g.tail_kt = t.kt;
+            g.tail_partials = slabs;
+            grid_x = (unsigned)(t.dp_tiles + r * t.splits);
+        }
+    }
     const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: the main kernel (+ slab sum)
-    hipLaunchKernelGGL(gemm_b3_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)splits),
+    hipLaunchKernelGGL(gemm_b3_kernel, dim3(grid_x, (unsigned)splits),
                        dim3(B3_THREADS), B3_STAGES * B3_BUF_BYTES, st, g);
     int rc = launch_status(name);
+    if (rc == GIST_OK && g.tail_splits > 1) {
+        hipLaunchKernelGGL(gemm_b3_tail_sum_kernel, dim3((grid_x - (unsigned)g.dp_tiles) / (unsigned)g.tail_splits, 16),
+                           dim3(B3_THREADS), 0, st, g);
+        rc = launch_status(name);
+    }
     // deferred: the caller's consumer sums the slabs (slab s at slabs + s m n, in slab order); bias must be null
     if (deferred) *deferred = splits;
     else if (rc == GIST_OK && splits > 1) rc = splitk_reduce(name, slabs, m * n, splits, bias, c, ldc, m, n, st);

@@ -293,7 +293,8 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_HOST_THREADS 11 /* worker threads of the host partitioner (0 = the container's CPU quota, at most 32); its RESULT does not depend on it */
 #define GIST_TUNE_LNB_FUSED 12    /* 1 = the LayerNorm backward of a <= 256-wide hidden layer as its own launch (not in the store of the reverse aggregation above it) */
 #define GIST_TUNE_B3C_SPLITS 13   /* k slices of the convert-on-load bf16x3 GEMM (0 = its own choice) */
-#define GIST_TUNE_COUNT 14
+#define GIST_TUNE_B3_TAIL 14      /* bf16x3 GEMM: 1 = no k slices for the tiles past the last full round of 256 (whole tiles) */
+#define GIST_TUNE_COUNT 15
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
 

@@ -236,3 +236,67 @@ def test_bf16x3_split_k_equals_one_slice(hip, form, m, n, k):
     e_one = ((y_one[rows].double() - ref).abs() / den).max().item()
     assert e_auto <= max(1.5 * e_one, 4e-7), (e_auto, e_one)
     assert (y_auto - y_one).abs().max().item() <= 4e-6 * den.max().item()
+
+
+TAIL_SHAPES = [('nt', 2100, 4096, 8192), ('nt', 2100, 4096, 1204), ('nn', 2100, 8192, 4096),
+               ('nt', 2049, 4096, 1024), ('nt', 2304, 4096, 640), ('nt', 300, 16500, 512),
+               ('tn', 4200, 2050, 1000)]
+
+
+@pytest.mark.parametrize('form,m,n,k', TAIL_SHAPES)
+def test_bf16x3_tail_units(hip, form, m, n, k):
+    """A tile count just above a multiple of 256 (a batch of 2049-2304 rows has a ninth row tile): the tiles past
+    the last full round run as k slices that meet through partials, the last slice to arrive summing them in slice
+    order.  Same result as whole tiles up to the order of the fp32 partial sums, bias added exactly once, the
+    same bits on every run (the sum does not depend on which slice arrives last), exact on integers, nothing
+    written outside C (one valid row in the tail tile included)."""
+    hip.gemm_mode('bf16x3')
+    from gist_amd import _lib
+    L = _lib.load()
+    hip.tuning('b3_tail', 1)
+    try:
+        ws_off = L.gist_gemm_workspace_bytes(m, n, k)
+    finally:
+        hip.tuning('b3_tail', 0)
+    assert L.gist_gemm_workspace_bytes(m, n, k) > ws_off >= (m + n) * k * 6, 'not a tail-unit shape'
+    gen = torch.Generator(device=DEV).manual_seed(m + 5 * n + 11 * k)
+    a, w = _operands(form, m, n, k, gen, 'normal')
+    bias = torch.randn(n, device=DEV, generator=gen) if form == 'nt' else None
+    y_tail = _run(hip, form, a, w, bias, m, n)
+    for _ in range(3):
+        assert torch.equal(_run(hip, form, a, w, bias, m, n), y_tail)
+    hip.tuning('b3_tail', 1)
+    try:
+        y_whole = _run(hip, form, a, w, bias, m, n)
+    finally:
+        hip.tuning('b3_tail', 0)
+    assert torch.isfinite(y_tail).all()
+    rows = torch.cat([torch.arange(0, m, max(1, m // 96), device=DEV), torch.arange(m - min(m, 60), m, device=DEV)])
+    ref, den = _ref64(form, a, w, rows)
+    if bias is not None:
+        ref = ref + bias.double()
+    e_tail = ((y_tail[rows].double() - ref).abs() / den).max().item()
+    e_whole = ((y_whole[rows].double() - ref).abs() / den).max().item()
+    assert e_tail <= max(1.5 * e_whole, 4e-7), (e_tail, e_whole)
+    assert (y_tail - y_whole).abs().max().item() <= 4e-6 * den.max().item()
+    # the full rounds are the same workgroups doing the same work (where the tail is exactly the ninth row tile)
+    tn_ = -(-n // 128)
+    if 2048 < m <= 2304 and (9 * tn_) % 256 == tn_:
+        assert torch.equal(y_tail[:2048], y_whole[:2048])
+    # integers: every partial sum exact -> bit for bit, in an output window with guard bands
+    sa, sb = _shape(form, m, n, k)
+    ai = torch.randint(-8, 9, sa, device=DEV, generator=gen).float()
+    wi = torch.randint(-8, 9, sb, device=DEV, generator=gen).float()
+    ybuf = torch.full((m + 2, n + 8), 7.0, device=DEV)
+    out = ybuf[:m, 4:4 + n]
+    if form == 'nt':
+        hip.gemm_nt(ai, wi, None, out)
+        exact = ai.double() @ wi.double().t()
+    elif form == 'nn':
+        hip.gemm_nn(ai, wi, out)
+        exact = ai.double() @ wi.double()
+    else:
+        hip.gemm_tn(ai, wi, out)
+        exact = ai.double().t() @ wi.double()
+    assert torch.equal(out, exact.float())
+    assert (ybuf[m:] == 7.0).all() and (ybuf[:, :4] == 7.0).all() and (ybuf[:, 4 + n:] == 7.0).all()
