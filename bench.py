@@ -547,7 +547,8 @@ def main():
     # (parameter initialisation, a pinned copy) spin-wait afterwards by default; inside a container with a CPU quota that burns
     # the period's quota and the kernel freezes the whole process for tens of ms -- in the middle of a timed region.  Passive
     # waiting, before torch loads its OpenMP runtime.
-    for k_, v_ in (('OMP_WAIT_POLICY', 'PASSIVE'), ('GOMP_SPINCOUNT', '0'), ('KMP_BLOCKTIME', '0')):
+    # (and this process is the application: the library leaves the cyclic collector alone unless told, sampler.freeze_setup_objects)
+    for k_, v_ in (('OMP_WAIT_POLICY', 'PASSIVE'), ('GOMP_SPINCOUNT', '0'), ('KMP_BLOCKTIME', '0'), ('GIST_GC_FREEZE', '1')):
         os.environ.setdefault(k_, v_)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))

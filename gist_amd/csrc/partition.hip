@@ -48,7 +48,8 @@ namespace {
 
 // wall seconds of the last call's stages (gist_partition_last_stats): input graph, coarsening, initial partition +
 // refinement per level, balance repair; [8] = levels, [9] = coarsest vertices
-double g_stats[16];
+// (per calling thread: the "last call" is the caller's own, and concurrent calls do not write one array)
+thread_local double g_stats[16];
 struct StageTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     double lap() {
@@ -74,7 +75,9 @@ int host_threads() {
         }
         std::fclose(f);
     }
-    return n < 1 ? 1 : (n > 32 ? 32 : n);
+    // (the pool's dense per-thread accumulators are one int64 per vertex each -- 14 MB per thread at 1.7 M vertices --
+    // and the 3x over one thread was measured at 8: a machine's core count must not decide the scratch memory)
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
 }
 
 class Pool {

@@ -39,6 +39,11 @@ _NEXT_HANDLE = [1]
 
 _IDLE, _FWD_DONE, _BWD_DONE = 0, 1, 2
 
+
+def _storage_uses(t):
+    """Tensors (of any Python lifetime: views count) that share t's storage, + the probe itself."""
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
 _lib_def = torch.library.Library('gist', 'FRAGMENT')
 _lib_def.define('gcn_forward(Tensor[] params, int handle, int token, int n, int ldc, bool train) -> Tensor')
 _lib_def.define('gcn_backward(Tensor d_logits, int handle, int token, bool given) -> Tensor[]')
@@ -74,15 +79,20 @@ def _(d_logits, handle, token, given):
 class _GCNForward(torch.autograd.Function):
     """The tape entry of gist::gcn_forward: its backward is gist::gcn_backward."""
 
+    # (the node knows its engine weakly: autograd hangs it on the output -- a view of the engine's own ring buffer --
+    # and a strong reference would close engine -> buffer -> node -> engine through C++, where no collector looks)
     @staticmethod
     def forward(ctx, me, token, n, ldc, *params):
-        ctx.me, ctx.token = me, token
+        ctx.me, ctx.token, ctx.n_in = weakref.ref(me), token, 4 + len(params)
         return torch.ops.gist.gcn_forward(list(params), me.handle, token, n, ldc, True)
 
     @staticmethod
     def backward(ctx, d_y):
-        ctx.me.autograd_backward(ctx.token, d_y)
-        return (None,) * (4 + len(ctx.me.params))      # (the gradients were delivered to p.grad: arena views)
+        me = ctx.me()
+        if me is None:
+            raise RuntimeError('gist_amd: backward through the forward of a model that no longer exists')
+        me.autograd_backward(ctx.token, d_y)
+        return (None,) * ctx.n_in                      # (the gradients were delivered to p.grad: arena views)
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -90,13 +100,13 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, me, token):
-        ctx.me, ctx.token = me, token
-        return me._loss0
+        ctx.me, ctx.token = weakref.ref(me), token
+        return me._loss0.detach()                      # (an alias: the node hangs on it, not on the ring's own tensor)
 
     @staticmethod
     def backward(ctx, g):
-        me = ctx.me
-        if me.token != ctx.token or me.state != _FWD_DONE:
+        me = ctx.me()
+        if me is None or me.token != ctx.token or me.state != _FWD_DONE:
             raise RuntimeError('gist_amd: backward through a loss whose forward is no longer the model\'s latest '
                                '(the engine reuses its buffers; GIST_MODULE_ENGINE=0 for the op-by-op path)')
         n = me._pending[0].n
@@ -105,8 +115,12 @@ class _FusedLoss(torch.autograd.Function):
 
 class StepLoss(torch.Tensor):
     """The loss tensor of a fused step.  An ordinary scalar tensor whose .backward() with no arguments -- what the
-    reference's loop calls -- runs the backward phase directly (one dispatcher op, no tape walk)."""
+    reference's loop calls -- runs the backward phase directly (one dispatcher op, no tape walk).  It lives in a slot of
+    the engine's loss ring for as long as the caller holds it (a held slot is not reused); .detach() copies out."""
     __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def detach(self):
+        return torch.Tensor.detach(self).clone()
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         st = self.__dict__.get('_gist_step')
@@ -163,12 +177,15 @@ class ModuleEngine(object):
         A = eng.arena
         self.params = [p for l in layers for p in (l.linear.weight, l.linear.bias)]
         self.grad_views = [v for k in range(len(layers)) for v in (A.dW[k], A.db[k])]
-        for i, p in enumerate(self.params):
-            p._gist_me = self
+        self._home_ptrs = [v.data_ptr() for k in range(len(layers)) for v in (A.W[k], A.b[k])]
+        # (a Parameter knows its engine by HANDLE: a strong reference here would close a Parameter <-> ModuleEngine cycle
+        # that only the cyclic collector could free -- and never does once the objects are in its permanent generation)
         self.n_classes, self.ldc = eng.n_classes, eng.ldc
         self.handle = _NEXT_HANDLE[0]
         _NEXT_HANDLE[0] += 1
         _REGISTRY[self.handle] = self
+        for p in self.params:
+            p._gist_me = self.handle
         self.token = 0
         self.state = _IDLE
         self._pending = None        # (engine Batch, cluster, logits tensor)
@@ -176,16 +193,30 @@ class ModuleEngine(object):
         self._f32 = dict(dtype=torch.float32, device=dev)
         self._last = len(layers) - 1
         self._first_step = True
+        # logits and loss of a step live in small rings (no allocator call in the loop).  A slot whose tensor the caller
+        # still holds (the tensor, a view of it, `preds.append(model(c))`) is NOT reused: the ring gets a fresh buffer
+        # for that slot, and the held one stays the caller's -- every call's result is its own tensor, as in torch.
         self._logit_ring = [torch.empty(it.n_max, self.ldc, **self._f32) for _ in range(4)]
-        self._loss_ring = list(torch.zeros(1024, **self._f32).unbind(0))
+        self._loss_ring = [torch.zeros((), **self._f32) for _ in range(64)]
+        self._idle_uses = _storage_uses(self._logit_ring[0])
 
     def __deepcopy__(self, memo):
         return None                   # (a copied model binds its own engine on first use)
 
     def homed(self):
-        A = self.engine.arena
-        p = self.params
-        return (p[0].data_ptr() == A.W[0].data_ptr() and p[-1].data_ptr() == A.b[-1].data_ptr())
+        """Is EVERY parameter's storage still its arena view?  (model.to(...), an assigned .data, load_state_dict(assign=True),
+        an IST mover that swaps tensors: any of them on any parameter sends forward / Adam.step back through adoption)"""
+        for p, ptr in zip(self.params, self._home_ptrs):
+            if p.data_ptr() != ptr:
+                return False
+        return True
+
+    def _ring_slot(self, ring, i, make):
+        """ring[i] if nobody outside the engine holds it (or a view of it), else a fresh buffer put in its place."""
+        t = ring[i]
+        if _storage_uses(t) > self._idle_uses:
+            t = ring[i] = make()
+        return t
 
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward(self, g, training):
@@ -196,12 +227,15 @@ class ModuleEngine(object):
         b = self.it.batcher.lazy(g._ids)
         b.row_blocks, b.parts, b.next_info = g.row_blocks, g.parts, g.next_info
         P = eng.plan
-        # logits and loss of a step live in small rings (no allocator call in the loop): `pred` stays valid until the
-        # 4th forward after its own, the loss tensor for 1024 steps -- copy them to keep them longer
         self.token += 1
-        y = self._logit_ring[self.token & 3][:n]
+        self._pending = None          # (the previous step's view of its ring slot)
+        if not training:
+            y = torch.empty(n, self.ldc, **self._f32)      # evaluation: every call's logits are their own tensor
+        else:
+            y = self._ring_slot(self._logit_ring, self.token & 3,
+                                lambda: torch.empty(self.it.n_max, self.ldc, **self._f32))[:n]
         P.layer[self._last].Y = y.data_ptr()
-        self._loss0 = self._loss_ring[self.token & 1023]
+        self._loss0 = self._ring_slot(self._loss_ring, self.token & 63, lambda: torch.zeros((), **self._f32))
         P.loss = self._loss0.data_ptr()
         self._pending = (b, g, y)
         if not training:
@@ -346,6 +380,5 @@ def engine_for(model, g):
               and all(p.is_cuda and p.device == it.g.device and p.dtype == torch.float32 for p in model.parameters())
               and model.layers[0].linear.in_features == 2 * it.batcher.feat.shape[1])
         me = mes[id(it)] = ModuleEngine(model, it) if ok else False
-        if me:
-            me._it_ref = it                 # (keeps id(it) unique for the model's lifetime)
+        # (me.it keeps id(it) unique for the model's lifetime)
     return me or None

@@ -35,6 +35,9 @@ class Adam(object):
         # parameters that live in a step plan's arena (a GCN bound to its ClusterIter, gist_amd/module_engine.py) with
         # their gradients in its gradient arena: the whole model is one launch
         me = self.params[0].__dict__.get('_gist_me') if self.params else None
+        if me is not None:
+            from .module_engine import _REGISTRY
+            me = _REGISTRY.get(me)
         if me is not None and me.owns(self.params) and me.homed() and me.grads_in_arena():
             me.optimizer_step(self)
             return

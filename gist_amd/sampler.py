@@ -32,9 +32,10 @@ def freeze_setup_objects():
     ~10^6 Python objects -- lives until the process ends.  A full (generation 2) pass of the cyclic garbage collector
     over them takes ~70 ms on the host and lands in the middle of the training loop every few thousand iterations
     (measured: one such pass in a 300-step window, profiles/r05_module_path.md).  gc.freeze() moves them to the
-    permanent generation: later collections only walk what the loop itself allocates.  GIST_GC_FREEZE=0 leaves the
-    collector alone."""
-    if os.environ.get('GIST_GC_FREEZE', '1') != '0':
+    permanent generation: later collections only walk what the loop itself allocates.  A process-wide choice, so it is
+    the APPLICATION's: GIST_GC_FREEZE=1 turns it on (bench.py and the gist_amd/scripts entry points set that default for
+    their own process); a library user's collector is left alone."""
+    if os.environ.get('GIST_GC_FREEZE', '0') == '1':
         import gc
         gc.collect()
         gc.freeze()
@@ -151,9 +152,18 @@ class ClusterIter(object):
                     self._ones = torch.ones(self.n_max, dtype=torch.bool, device=tg.device)
         return self._feed
 
+    def _bound_run_ahead(self):
+        """An epoch that was left early (a `break`, a step cap) never reached the deferred check at its end, which is also
+        what keeps the host at most one epoch ahead of the GPU: before the staging buffer of two epochs ago is rewritten,
+        wait for the progress mark here instead."""
+        if not getattr(self, '_exhausted', True) and self.engine is not None:
+            self.engine.check_extract_deferred()
+        self._exhausted = False
+
     def __iter__(self):
         self.n = 0
         if self.feed():
+            self._bound_run_ahead()
             self._upload_epoch()
             self._epoch_cols = {}
         return self
@@ -173,6 +183,7 @@ class ClusterIter(object):
             return result
         if self._feed and self.engine is not None:
             self.engine.check_extract_deferred()
+        self._exhausted = True
         random.shuffle(self.par_li)                                  # sampler.py:92
         raise StopIteration
 
@@ -440,6 +451,7 @@ class EngineClusterIter(ClusterIter):
 
     def __iter__(self):
         self.n = 0
+        self._bound_run_ahead()
         self._upload_epoch()
         return self
 
@@ -465,5 +477,6 @@ class EngineClusterIter(ClusterIter):
             # (no queue drain per epoch); engine.check_extract() -- a synchronising read -- closes a run: the trainers
             # and bench.py call it before they report anything
             self.engine.check_extract_deferred()
+        self._exhausted = True
         random.shuffle(self.par_li)
         raise StopIteration

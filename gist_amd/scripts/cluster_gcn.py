@@ -151,6 +151,8 @@ def main_module_path(args, data, g, device, in_feats, n_classes, par_li, psize, 
 
 
 if __name__ == '__main__':
+    import os
+    os.environ.setdefault('GIST_GC_FREEZE', '1')      # this process is the application: sampler.freeze_setup_objects
     a = build_parser().parse_args()
     print(a)
     main(a)

@@ -34,4 +34,6 @@ def main(args=None, dataset=None, log=print):
 
 
 if __name__ == '__main__':
+    import os
+    os.environ.setdefault('GIST_GC_FREEZE', '1')      # this process is the application: sampler.freeze_setup_objects
     main()

@@ -290,7 +290,7 @@ int gist_gemm_get_mode(void);
 #define GIST_TUNE_B3C 8           /* convert-on-load bf16x3 GEMM: 1 = never, 2 = also below 0.25 GFLOP */
 #define GIST_TUNE_CLASS_FUSED 9   /* class layer of the fused step: 1 = the four-launch sequence (gist_class_layer_f32 off), 2 = its dW slabs as their own launch (not in the LayerNorm backward's grid) */
 #define GIST_TUNE_GEMM_DUAL 10    /* backward of a narrow hidden layer: 1 = dZ and dW as two launches (gist_gemm_nn_tn_dual_f32 off) */
-#define GIST_TUNE_HOST_THREADS 11 /* worker threads of the host partitioner (0 = the container's CPU quota, at most 32); its RESULT does not depend on it */
+#define GIST_TUNE_HOST_THREADS 11 /* worker threads of the host partitioner (0 = the container's CPU quota, at most 8; up to 64 on request); its RESULT does not depend on it */
 #define GIST_TUNE_LNB_FUSED 12    /* 1 = the LayerNorm backward of a <= 256-wide hidden layer as its own launch (not in the store of the reverse aggregation above it) */
 #define GIST_TUNE_B3C_SPLITS 13   /* k slices of the convert-on-load bf16x3 GEMM (0 = its own choice) */
 #define GIST_TUNE_B3_TAIL 14      /* bf16x3 GEMM: 1 = no k slices for the tiles past the last full round of 256 (whole tiles) */

@@ -3,7 +3,7 @@
 : ${GRAFT_REPO_ROOT:?run under gpurun}
 R=$GRAFT_REPO_ROOT
 tag=$1; shift
-O=$R/gpurun_out/r5/$tag
+O=$R/gpurun_out/${ROUND:-r6}/$tag
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o k -- python3 $R/bench.py "$@" --no-cpu-baseline --no-second-leg --no-kernel-timing > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }

@@ -287,3 +287,151 @@ def test_eval_mode_forward_on_a_cluster_batch():
                 sg = it.g.subgraph(it.batch_ids(0))
                 res.append(model(sg).clone())
     assert (res[0] - res[1]).abs().max().item() < 1e-4
+
+
+def _bound(n_feats=100, hidden=64, p_drop=0.0, bs=5, n=3000, blocks=30):
+    from gist_amd.sampler import ClusterIter
+    ds = _data(n_feats, n=n, blocks=blocks)
+    g = ds.g
+    random.seed(4)
+    it = ClusterIter('toy', g, len(ds.par_li), bs, np.arange(g.number_of_nodes(), dtype=np.int64),
+                     par_li=[p.copy() for p in ds.par_li], device=DEV)
+    return _model(n_feats, hidden, 2, p_drop).cuda(), it
+
+
+def test_every_call_returns_its_own_tensors():
+    """torch semantics: what a call returned stays what it was.  `preds.append(model(c))` over an epoch, losses kept
+    across many steps and eval-mode logits must not be overwritten by later forwards (the engine's rings skip a slot
+    whose tensor -- or a view of it -- is still held); pred[mask] may be the same object, its values may not change."""
+    from gist_amd.nn import CrossEntropyLoss
+    from gist_amd.optim import Adam
+    model, it = _bound()
+    loss_f = CrossEntropyLoss()
+    opt = Adam(model.parameters(), lr=0.01)
+    model.train()
+    kept, copies, losses, loss_copies, views = [], [], [], [], []
+    for ep in range(14):                      # 84 steps: more than the loss ring's 64 slots
+        for cluster in it:
+            pred = model(cluster)
+            loss = loss_f(pred[cluster.ndata['train_mask']], cluster.ndata['label'][cluster.ndata['train_mask']])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if len(kept) < 12:
+                kept.append(pred)
+                copies.append(pred.detach().clone())
+                views.append(pred[:7, :3])    # a view alone must hold its slot too
+            losses.append(loss)
+            loss_copies.append(float(loss.detach()))
+    for a, b in zip(kept, copies):
+        assert torch.equal(a.detach(), b)
+    for v, b in zip(views, copies):
+        assert torch.equal(v.detach(), b[:7, :3])
+    assert [float(x.detach()) for x in losses] == loss_copies
+    d = losses[0].detach()
+    assert d.data_ptr() != losses[0].data_ptr()          # detach() copies out of the ring
+    model.eval()
+    with torch.no_grad():
+        outs = [model(c) for c in it]
+        again = [model(c).clone() for c in it]
+    # (the epochs shuffle: compare each call with a clone taken when it was made)
+    with torch.no_grad():
+        held, ref = [], []
+        for c in it:
+            y = model(c)
+            held.append(y)
+            ref.append(y.clone())
+    for a, b in zip(held, ref):
+        assert torch.equal(a, b)
+    assert len({o.data_ptr() for o in outs}) == len(outs) and len(again) == len(outs)
+
+
+def test_dropped_models_give_their_memory_back():
+    """Two bound models created and dropped in one process: the arena, the activation buffers, the rings and the
+    batcher's copies must be freed by reference counting alone -- also after gc.freeze(), which an application may have
+    called (bench.py does): a Parameter <-> engine cycle would then never be collected."""
+    import gc
+    from gist_amd.nn import CrossEntropyLoss
+    from gist_amd.optim import Adam
+
+    def one():
+        model, it = _bound(hidden=256)
+        loss_f = CrossEntropyLoss()
+        opt = Adam(model.parameters(), lr=0.01)
+        model.train()
+        for cluster in it:
+            pred = model(cluster)
+            loss = loss_f(pred, cluster.ndata['label'])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        float(loss)
+        if it.engine is not None:
+            it.engine.check_extract()
+
+    one()                                # (first use: lazy imports, allocator pools)
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    gc.disable()                         # reference counting only
+    try:
+        one()
+        gc.freeze()
+        one()
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() <= base + (1 << 20), (torch.cuda.memory_allocated(), base)
+    finally:
+        gc.unfreeze()
+        gc.enable()
+
+
+def test_replacing_any_parameter_is_noticed():
+    """homed() looks at every parameter: a middle layer's weight given new storage must come back into the arena (the fused
+    step would otherwise train a stale copy while the visible parameter never changes)."""
+    from gist_amd.nn import CrossEntropyLoss
+    from gist_amd.optim import Adam
+    model, it = _bound()
+    loss_f = CrossEntropyLoss()
+    opt = Adam(model.parameters(), lr=0.01)
+    model.train()
+    batches = iter(it)
+    c = next(batches)
+    loss_f(model(c), c.ndata['label']).backward()
+    opt.step()
+    me = next(iter(model.__dict__['_module_engines'].values()))
+    assert me.homed()
+    new_w = torch.full_like(model.layers[1].linear.weight.data, 0.01)
+    model.layers[1].linear.weight.data = new_w                 # not the first, not the last parameter
+    assert not me.homed()
+    c = next(batches)
+    opt.zero_grad()
+    loss_f(model(c), c.ndata['label']).backward()
+    assert me.homed() and model.layers[1].linear.weight.data_ptr() == me.engine.arena.W[1].data_ptr()
+    assert torch.equal(me.engine.arena.W[1], new_w)            # the assigned values are what the step used
+    opt.step()
+    assert not torch.equal(model.layers[1].linear.weight.data, new_w)      # and what the optimiser updated
+
+
+def test_epochs_left_early_do_not_outrun_the_gpu():
+    """A loop that breaks out of every epoch never reaches the deferred check at the epoch's end; the iterator must still
+    keep the host within one epoch of the GPU before it rewrites a staging buffer (ids of later batches would be wrong)."""
+    from gist_amd.nn import CrossEntropyLoss
+    from gist_amd.optim import Adam
+    model, it = _bound()
+    loss_f = CrossEntropyLoss()
+    opt = Adam(model.parameters(), lr=0.01)
+    model.train()
+    marks = []
+    for ep in range(40):
+        for j, cluster in enumerate(it):
+            pred = model(cluster)
+            loss = loss_f(pred, cluster.ndata['label'])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if j == 1:
+                break
+        marks.append(getattr(it.engine, '_mark_tag', 0))
+    assert marks[-1] >= 38          # one progress mark per truncated epoch
+    it.engine.check_extract()
+    assert torch.isfinite(loss).item()
