@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GIST_LIB_PATH: dev override to A/B a variant build (gist_amd/build.py GIST_LIB_OUT=...)
 LIB_PATH = os.environ.get('GIST_LIB_PATH') or os.path.join(_HERE, 'libgist_hip.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class GistLibraryError(RuntimeError):
@@ -174,7 +174,7 @@ class StepPlan(ctypes.Structure):
                 ('node_part', _p), ('part_slot', _p),
                 ('batch_index', _i32), ('extract_scratch', _p),
                 ('next_ids', _p), ('next_n', _i64), ('next_batch_index', _i32), ('next_drop_offset', _u64),
-                ('feat_intra', _p), ('ld_feat_intra', _i64)]
+                ('feat_intra', _p), ('ld_feat_intra', _i64), ('sibling_parts', ctypes.c_int32)]
 
 
 class ExtractPartsDesc(ctypes.Structure):

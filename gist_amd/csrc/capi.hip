@@ -26,7 +26,7 @@ extern "C" double gist_tuning_get(int knob) {
 }
 
 extern "C" const char *gist_last_error(void) { return gist::g_err; }
-extern "C" int gist_abi_version(void) { return 15; }
+extern "C" int gist_abi_version(void) { return 16; }
 extern "C" int gist_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -190,8 +190,12 @@ __device__ __forceinline__ void drop_f4(float4 &v, uint64_t idx0, const SpmmDrop
 int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
                      int64_t ldy, int64_t n_rows, int64_t d, const float *out_scale, const float *src_scale,
                      int accumulate, const int32_t *row_blocks, int64_t n_row_blocks, const void *prepared,
-                     hipStream_t st, const SpmmDrop *dr = nullptr);
+                     hipStream_t st, const SpmmDrop *dr = nullptr, bool pairs = true);
 int64_t spmm_blocks_bytes(int64_t n_blocks);
+// Pairs of sibling blocks (spmm_mfma.hip): false while a caller that KNOWS its batch has none is issuing launches
+// (gist_sage_step with plan->sibling_parts == 0): the prepare kernel then looks for none and no pairs launch follows
+// an aggregation.  Everybody else: true.
+extern thread_local bool tl_spmm_pairs;
 // spmm_dense32.hip: the block-dense aggregation on the fp32 matrix cores, operands from memory (prepared blocks only)
 bool spmm_dense32_takes(int64_t d, int64_t ldx, int64_t ldy);
 int launch_spmm_dense32(const int32_t *rowptr, const int32_t *col, const float *x, int64_t ldx, float *y,
@@ -201,7 +205,7 @@ int launch_spmm_dense32(const int32_t *rowptr, const int32_t *col, const float *
 bool spmm_prepared_takes(int64_t d, int64_t ldx, int64_t ldy, const float *x, const float *y);   // spmm.hip
 int launch_spmm_blocks_prepare(const int32_t *rowptr, const int32_t *col, const int32_t *rowptr2,
                                const int32_t *col2, int64_t n_rows, const int32_t *row_blocks,
-                               int64_t n_row_blocks, void *prepared, void *prepared2, hipStream_t st);
+                               int64_t n_row_blocks, void *prepared, void *prepared2, hipStream_t st, bool pairs = true);
 
 // rowops.hip: the C-ABI kernels with the extra outputs the split projection path consumes
 int ln_relu_bwd_ex(const float *d_out, int64_t ldg, const float *yhat, int64_t ldy, const float *rstd,

@@ -29,7 +29,7 @@ constexpr int DB_ROWS = 128;                    // = MF_ROWS of spmm_mfma.hip (t
 #define MF_REM_N 8
 #endif
 constexpr int DB_REM = MF_REM_N;                // = MF_REM
-constexpr int DB_PREP_STRIDE = 16 * DB_ROWS * 16 + DB_ROWS * 4 + DB_ROWS * DB_REM * 4;      // = MF_PREP_STRIDE
+constexpr int DB_PREP_STRIDE = 16 * DB_ROWS * 16 + DB_ROWS * 4 + DB_ROWS * DB_REM * 4 + 16;      // = MF_PREP_STRIDE
 
 struct D32Args {
     const int32_t *rowptr, *col;
@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void spmm_dense32_kernel(D32Args a) {
                 const int row = (rt0 + t) * 16 + 4 * q + i;
                 ok[t][i] = rt0 + t < rt1 && row < nloc && col_ok;
                 const int rowc = min(row, nloc - 1);
-                const int c = rem_cnt[rowc];
+                // (>= 0x100: the row has edges in a pair image of its block, spmm_mfma.hip -- this kernel has no pair
+                // product: such a row is gathered in full like the negative states)
+                const int c = rem_cnt[rowc] >= 0x100 ? -1 : rem_cnt[rowc];
                 cnt[t][i] = ok[t][i] ? c : 0;
                 osc[t][i] = a.out_scale ? a.out_scale[r0 + rowc] : 1.f;
                 old[t][i] = (a.accumulate && ok[t][i]) ? a.y[(int64_t)(r0 + rowc) * a.ldy + colc] : 0.f;

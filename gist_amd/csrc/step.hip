@@ -100,6 +100,11 @@ struct Scope {   // records start now, stop at scope exit
         : t(t_), slot(timer_begin(t_, kind, m, n, k, s_)), s(s_) {}
     ~Scope() { timer_end(t, slot, s); }
 };
+struct PairsHint {     // the aggregations below look for sibling blocks only if the plan says the batch may have them
+    bool prev;
+    explicit PairsHint(bool on) : prev(tl_spmm_pairs) { tl_spmm_pairs = on; }
+    ~PairsHint() { tl_spmm_pairs = prev; }
+};
 struct ActiveTimer {   // kernels below the entry points see the armed timer for this call only
     explicit ActiveTimer(gist_timer *t) { tl_timer = t; }
     ~ActiveTimer() { tl_timer = nullptr; }
@@ -408,6 +413,7 @@ extern "C" int gist_sage_step(const gist_step_plan *p, const int32_t *ids, int64
     const int L1 = p->n_layers;
     hipStream_t st = as_stream(s);
     ActiveTimer active(p->timer);
+    PairsHint pairs_hint(p->sibling_parts != 0);
     const bool train = (flags & GIST_STEP_TRAIN) != 0;
     const bool drop = train && p->p_drop > 0.f;
     // Phases (gist_hip.h, GIST_STEP_PHASE_*): a caller whose loop is `pred = model(g); loss = f(pred); loss.backward();

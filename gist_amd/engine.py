@@ -24,6 +24,9 @@ import torch
 from . import hip
 
 
+_FORCE_PAIRS = os.environ.get('GIST_SPMM_PAIRS') == '1'      # dev: every batch is prepared with pairs / fine blocks
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -83,7 +86,7 @@ class ParamArena(object):
 class Batch(object):
     """Views into the batcher's buffers describing the current cluster batch."""
     __slots__ = ('n', 'rowptr', 'col', 't_rowptr', 't_col', 'norm', 'labels', 'ids', 'ready',
-                 'row_blocks', 'batcher', 'parts', 'z0_dropped', 'next_info', 'ah_owner')
+                 'row_blocks', 'batcher', 'parts', 'z0_dropped', 'next_info', 'ah_owner', 'siblings')
 
     def __init__(self):
         self.ready = True
@@ -96,6 +99,7 @@ class Batch(object):
         self.batcher = None         # set on lazy batches: who extracts them
         self.parts = None           # (node_part [N, 2], part_slot [parts, 2], batch index) -- sampler
         self.next_info = None       # (ids, batch index) of the batch that follows in the same epoch -- sampler
+        self.siblings = True        # may two parts of the batch share hundreds of edges? (gist_step_plan.sibling_parts)
         # the engine whose Z[0] right half already holds layer 0's aggregation of this batch (an eager extraction through
         # gist_extract_parts_desc_batch with feat_intra); cleared by the first forward that drops Z[0] in place
         self.ah_owner = None
@@ -431,6 +435,7 @@ class SageEngine(object):
         if train and phase == 0:
             self.arena.step += 1
         rb = b.row_blocks
+        P.sibling_parts = 1 if (b.siblings or _FORCE_PAIRS) else 0
         if rb is not None and rb.numel() > 1:
             P.row_blocks, P.n_row_blocks = rb.data_ptr(), rb.numel() - 1
             # room for the batch's prepared block structure (include/gist_hip.h, spmm_prepared):

@@ -282,6 +282,7 @@ class ClusterBatch(Graph):
         ids, n, row_blocks, parts, next_info = it.describe(j)
         self._ids, self._n = ids, n
         self.row_blocks, self.parts, self.next_info = row_blocks, parts, next_info
+        self.siblings = it.has_siblings(j)
         self._idtype = it.g._idtype
         self._sg = None
         self._norm = self._remap = self._nnz = None

@@ -226,6 +226,7 @@ class ModuleEngine(object):
         n = g._n
         b = self.it.batcher.lazy(g._ids)
         b.row_blocks, b.parts, b.next_info = g.row_blocks, g.parts, g.next_info
+        b.siblings = g.siblings
         P = eng.plan
         self.token += 1
         self._pending = None          # (the previous step's view of its ring slot)

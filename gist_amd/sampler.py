@@ -237,6 +237,8 @@ class ClusterIter(object):
                 self._part_of_host = part_of
                 self._node_part = torch.from_numpy(np.stack([part_of, pos], 1).copy()).to(tg.device)   # [N, 2]
         self._extract_scratch = None
+        self._sibling_keys = None
+        self._epoch_siblings = None
         # Are the parts LOCALITY blocks?  The blocked aggregation kernels (a part's feature tile staged in
         # LDS, or its diagonal block as a dense counts x features product) pay only when most neighbours of a
         # batch row lie in the row's own part: on a batch without locality the matrix-core kernel gathers
@@ -251,8 +253,18 @@ class ClusterIter(object):
             rp = tg.rowptr.to(torch.int64)
             rows = torch.repeat_interleave(torch.arange(n_nodes, device=tg.device), rp[1:] - rp[:-1])
             po = self._node_part[:, 0]
-            intra = int((po[rows] == po[tg.col.to(torch.int64)]).sum().item())
-            del rows
+            pr, pc = po[rows], po[tg.col.to(torch.int64)]
+            intra = int((pr == pc).sum().item())
+            # Sibling parts: pairs of parts joined by hundreds of edges (one community cut in two).  A batch that holds
+            # both is prepared with their off-diagonal blocks as dense pairs (gist_step_plan.sibling_parts); which batches
+            # those are is known from this table alone, on the host, once per epoch.  (Threshold = the prepare kernel's
+            # MF_PAIR_MIN; a pair listed here that the kernel does not take costs one empty launch, nothing else.)
+            cross = pr != pc
+            K = np.int64(len(self.par_li) + 1)
+            keys, cnt = torch.unique(pr[cross].to(torch.int64) * int(K) + pc[cross].to(torch.int64), return_counts=True)
+            keys = keys[cnt >= 256].cpu().numpy()
+            self._sibling_keys = np.unique(np.concatenate([keys, (keys % K) * K + keys // K]))      # either direction
+            del rows, pr, pc, cross
             nnz = tg.number_of_edges()
             inside = intra / float(nnz)
             n_parts = max(len(self.par_li), 2)
@@ -351,6 +363,17 @@ class ClusterIter(object):
             pid = self._part_of_host[firsts]
             tab[pid, 0] = (nz // bs).astype(np.int32)
             tab[pid, 1] = first[nz].astype(np.int32)
+        # which batches of this epoch hold two sibling parts (see _init_feed)
+        self._epoch_siblings = None
+        sk = self._sibling_keys
+        if sk is not None and self._node_part is not None and mx and all(len(p) for p in used):
+            pid_all = self._part_of_host[np.fromiter((p[0] for p in used), np.int64, len(used))].astype(np.int64).reshape(mx, bs)
+            if sk.size == 0:
+                self._epoch_siblings = np.zeros(mx, bool)
+            else:
+                K = np.int64(len(self.par_li) + 1)
+                pk = pid_all[:, :, None] * K + pid_all[:, None, :]
+                self._epoch_siblings = np.isin(pk.reshape(mx, -1), sk).any(1)
         return ids, off, blocks, boff, tab
 
     def _upload_epoch(self):
@@ -413,6 +436,11 @@ class ClusterIter(object):
                 next_info = (self._epoch_ids[a2:b2], j + 1)
         return ids, b - a, row_blocks, parts, next_info
 
+    def has_siblings(self, j):
+        """May batch j of the current epoch hold two parts joined by hundreds of edges?  (True when unknown.)"""
+        es = self._epoch_siblings
+        return True if es is None else bool(es[j])
+
 
 class EngineClusterIter(ClusterIter):
     """ClusterIter that feeds a SageEngine: yields engine Batches built in preallocated
@@ -469,6 +497,7 @@ class EngineClusterIter(ClusterIter):
             else:
                 batch = self.batcher.extract(ids, self.engine.z0_left(n))
             batch.row_blocks, batch.parts, batch.next_info = row_blocks, parts, next_info
+            batch.siblings = self.has_siblings(self.n)
             self.n += 1
             return batch
         if self.engine is not None:

@@ -339,7 +339,9 @@ class FullGraphEvaluator(object):
         pos[sp['pair_order']] = torch.arange(n_pairs, device=dev)
         # diagonal images: the prepared structures of the row chunks, block by block; a row that left the dense product
         # there (a count above 256: its rem_cnt is -1) keeps the per-launch path for the whole evaluator
-        diag = torch.cat([pb.view(torch.bfloat16).view(-1, stride) for pb in sp['prepared']], 0)
+        # (a prepared buffer = one record per block, then -- small block counts -- room for pair images: records only)
+        diag = torch.cat([pb[:(rb.numel() - 1) * 2 * stride].view(torch.bfloat16).view(-1, stride)
+                          for pb, rb in zip(sp['prepared'], sp['blocks'])], 0)
         rem = diag[:, 16384:16384 + 256].contiguous().view(torch.int32)       # rem_cnt[128] of every block
         if diag.shape[0] != nb or bool((rem < 0).any()):
             return

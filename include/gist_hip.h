@@ -40,7 +40,7 @@ typedef void *gist_stream_t;
 
 const char *gist_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
-int gist_abi_version(void);   /* currently 14 */
+int gist_abi_version(void);   /* currently 16 */
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int gist_device_count(void);
 
@@ -785,6 +785,12 @@ typedef struct gist_step_plan {
     /* the intra-part neighbour sums of the input features (gist_extract_parts_desc.feat_intra): when set, the one-launch
      * extraction forms layer 0's aggregation and the step skips that launch */
     const float *feat_intra; int64_t ld_feat_intra;
+    /* Sibling parts (round 6, set per call like row_blocks): non-zero = two parts of this batch may share hundreds of
+     * edges (one community cut in two): the batch's block structure is prepared WITH pairs (gist_spmm_blocks_prepare) and
+     * every wide aggregation is followed by its pairs launch.  0 = the caller knows there are none (gist_amd: from the
+     * part-to-part edge counts of the training graph, once per run): no search, no second launch.  Either value is
+     * correct for any batch; 0 on a batch that has sibling parts is the slow path (their rows walk their edge lists). */
+    int32_t sibling_parts;
 } gist_step_plan;
 
 /* Bytes of fused_workspace / floats of col_partials the plan's shapes need.  Host functions. */

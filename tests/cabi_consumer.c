@@ -9,7 +9,7 @@
 int main(void) {
     gist_step_plan plan;
     memset(&plan, 0, sizeof plan);
-    if (gist_abi_version() != 15) return 1;
+    if (gist_abi_version() != 16) return 1;
     if (gist_gemm_workspace_bytes(2046, 41, 8192) <= 0) return 2;
     if (gist_colsum_partials(129) != 3) return 3;
     /* validation happens before any device work, so these are safe without a GPU */

@@ -53,7 +53,7 @@ int main(void) {
     int e, i, j, k, n_dev = 0;
     double worst;
 
-    if (gist_abi_version() != 15) return 1;
+    if (gist_abi_version() != 16) return 1;
     HIP_OK(hipGetDeviceCount(&n_dev));
     if (n_dev < 1 || gist_device_count() < 1) { printf("no device\n"); return 2; }
     HIP_OK(hipSetDevice(0));

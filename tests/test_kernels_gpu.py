@@ -586,7 +586,8 @@ def test_spmm_blocks_prepare_rejects_bad_buffers(hip):
     rp = torch.arange(0, 301, dtype=torch.int32, device=DEV)
     cl = torch.zeros(300, dtype=torch.int32, device=DEV)
     need = L.gist_spmm_blocks_bytes(3)
-    assert need == 3 * (16 * 128 * 16 + 128 * 4 + 128 * 8 * 4)
+    # per block: count image, rem_cnt, rem_col, the pair descriptor; then (batches of <= 256 blocks) two pair images each
+    assert need == 3 * (16 * 128 * 16 + 128 * 4 + 128 * 8 * 4 + 16) + 3 * 2 * 16 * 128 * 16
     buf = torch.empty(need + 16, dtype=torch.uint8, device=DEV)
     assert L.gist_spmm_blocks_prepare(rp.data_ptr(), cl.data_ptr(), 300, None, 0, buf.data_ptr(), need - 1, None) < 0
     assert b'buffer too small' in L.gist_last_error()
@@ -598,6 +599,107 @@ def test_spmm_blocks_prepare_rejects_bad_buffers(hip):
     assert L.gist_spmm_csr_prepared_f32(rp.data_ptr(), cl.data_ptr(), x.data_ptr(), 2048, y.data_ptr(), 2048, 300,
                                         2048, None, None, 0, None, 0, None, None) < 0
     torch.cuda.synchronize()
+
+
+def _sibling_graph(rs, n_parts=20, part=102, siblings=((3, 7), (10, 11), (11, 15), (10, 15)), cross_per_row=45, extra_hub=0):
+    """A cluster batch whose parts are dense inside (40 in-part neighbours per row), with a few neighbours anywhere in the
+    batch, and SIBLING parts: every row of one has `cross_per_row` neighbours in the other (one community cut in two /
+    three) -- far more than the per-row list of outside neighbours holds."""
+    sizes = part + rs.randint(-3, 4, n_parts)
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(cuts[-1])
+    src, dst = [], []
+    for p in range(n_parts):
+        rows = np.arange(cuts[p], cuts[p + 1])
+        d_ = np.repeat(rows, 40)
+        src.append(rs.randint(cuts[p], cuts[p + 1], d_.size)); dst.append(d_)
+        d_ = np.repeat(rows, 1)
+        src.append(rs.randint(0, n, d_.size)); dst.append(d_)
+    for (p, q) in siblings:
+        for (a, b) in ((p, q), (q, p)):
+            d_ = np.repeat(np.arange(cuts[a], cuts[a + 1]), cross_per_row)
+            src.append(rs.randint(cuts[b], cuts[b + 1], d_.size)); dst.append(d_)
+    if extra_hub:
+        src.append(rs.randint(0, n, extra_hub)); dst.append(np.full(extra_hub, int(cuts[3]) + 5))
+    return n, cuts, np.concatenate(src), np.concatenate(dst)
+
+
+@pytest.mark.parametrize('d', [2048, 4096, 1540])
+def test_spmm_sibling_parts_as_dense_pairs(hip, d):
+    """Two (three) parts of one community in a batch: the off-diagonal blocks between them are multiplied like diagonal
+    ones (the prepare kernel finds them, gist_amd/csrc/spmm_mfma.hip).  Against the oracle in both forms, with the dropout
+    mask in the store, BIT FOR BIT on integer-valued features (counts x bf16x3 pieces are exact), the pairs really found,
+    and the same prepared structure read by the kernel that has no pair product (F = 602: such rows are gathered in full)."""
+    from gist_amd import _lib
+    rs = np.random.RandomState(d)
+    n, cuts, src, dst = _sibling_graph(rs, extra_hub=500)
+    rowptr, col = O.csr_from_edges(src, dst, n)
+    norm = O.in_degree_norm(rowptr)
+    rb = dev(cuts, torch.int32)
+    rp, cl = dev(rowptr, torch.int32), dev(col, torch.int32)
+    prep = hip.spmm_prepare(rp, cl, rb)
+    nb = len(cuts) - 1
+    stride = int(_lib.load().gist_spmm_block_image_bytes())
+    rec = prep[:nb * stride].view(nb, stride)
+    pinfo = rec[:, stride - 16:].contiguous().view(torch.int32).view(nb, 4).cpu().numpy()
+    want_pairs = {3: {7}, 7: {3}, 10: {11, 15}, 11: {10, 15}, 15: {10, 11}}
+    for b in range(nb):
+        got = {int(np.searchsorted(cuts, pinfo[b, 2 * j], side='right') - 1) for j in range(2) if pinfo[b, 2 * j + 1] > 0}
+        assert got == want_pairs.get(b, set()), (b, pinfo[b])
+        for j in range(2):
+            if pinfo[b, 2 * j + 1] > 0:
+                q = int(np.searchsorted(cuts, pinfo[b, 2 * j], side='right') - 1)
+                assert pinfo[b, 2 * j] == cuts[q] and pinfo[b, 2 * j + 1] == cuts[q + 1] - cuts[q]
+    x = rs.randn(n, 2 * d).astype(np.float32)
+    xt = dev(x)
+    hip.spmm(rp, cl, xt[:, :d], xt[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True, prepared=prep)
+    ref = x.copy()
+    ref[:, d:] = O.spmm_sum(rowptr, col, np.ascontiguousarray(x[:, :d]), out_scale=norm)
+    close(xt, ref)
+    # backward form on the reversed graph: src_scale + accumulate
+    t_rp, t_cl = O.transpose_csr(rowptr, col)
+    trp, tcl = dev(t_rp, torch.int32), dev(t_cl, torch.int32)
+    prep_t = hip.spmm_prepare(trp, tcl, rb)
+    g = rs.randn(n, 2 * d).astype(np.float32)
+    gt = dev(g)
+    hip.spmm(trp, tcl, gt[:, d:], gt[:, :d], src_scale=dev(norm), accumulate=True, row_blocks=rb, blocked=True, prepared=prep_t)
+    dh = np.ascontiguousarray(g[:, :d])
+    O.spmm_sum(t_rp, t_cl, g[:, d:], src_scale=norm, out=dh, accumulate=True)
+    close(gt[:, :d], dh)
+    # the forward dropout mask in the store
+    if d % 4 == 0:
+        xd = dev(x)
+        p_, seed, off = 0.3, 11, 1000
+        hip.spmm_drop(rp, cl, xd[:, :d], xd[:, d:], 1, p_, seed, off + d, off, 2 * d, out_scale=dev(norm), row_blocks=rb,
+                      prepared=prep)
+        mask = _dropout_mask_ref(n, 2 * d, p_, seed, off)[:, d:]
+        close(xd[:, d:], ref[:, d:] * mask / (1 - p_))
+    # integers: every partial sum exact in fp32 whatever the order -> bit for bit
+    xi = np.zeros((n, 2 * d), np.float32)
+    xi[:, :d] = rs.randint(-(1 << 20), 1 << 20, (n, d)).astype(np.float32) / 4096.0 * (rs.rand(n, d) < 0.05)
+    xit = dev(xi)
+    hip.spmm(rp, cl, xit[:, :d], xit[:, d:], row_blocks=rb, blocked=True, prepared=prep)
+    want = O.spmm_sum(rowptr, col, np.ascontiguousarray(xi[:, :d]))
+    ref64 = np.zeros((n, d))
+    np.add.at(ref64, np.repeat(np.arange(n), np.diff(rowptr)), xi[col, :d].astype(np.float64))
+    assert np.array_equal(want.astype(np.float64), ref64), 'test data: the fp32 sums are not exact'
+    assert np.array_equal(xit[:, d:].cpu().numpy(), want)
+    # the unprepared kernel (no pairs: those rows walk their edge lists) agrees to rounding
+    x2 = dev(x)
+    hip.tuning('spmm_kernel', 2)
+    try:
+        hip.spmm(rp, cl, x2[:, :d], x2[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True)
+    finally:
+        hip.tuning('spmm_kernel', 0)
+    close(x2, ref)
+    # F = 602: the fp32 block-dense kernel reads the same structure
+    f = 602
+    xf = rs.randn(n, 2 * f).astype(np.float32)
+    xft = dev(xf)
+    hip.spmm(rp, cl, xft[:, :f], xft[:, f:], out_scale=dev(norm), row_blocks=rb, blocked=True, prepared=prep)
+    reff = xf.copy()
+    reff[:, f:] = O.spmm_sum(rowptr, col, np.ascontiguousarray(xf[:, :f]), out_scale=norm)
+    close(xft, reff)
 
 
 def _spmm_blocked_case(hip, n, d, deg, hub, blocks, prepared=False):
@@ -634,7 +736,12 @@ def _spmm_blocked_case(hip, n, d, deg, hub, blocks, prepared=False):
             hip.spmm(rp, cl, x2[:, :d], x2[:, d:], out_scale=dev(norm), row_blocks=rb, blocked=True)
         finally:
             hip.tuning('spmm_kernel', 0)
-        assert torch.equal(x2, xt)
+        # (blocks cut at row 57 make [0, 57) and [57, 100) sibling parts: the prepared structure then multiplies their
+        # off-diagonal blocks as pairs, another order of the same fp32 sums; without pairs the arithmetic is the same)
+        if blocks == 'parts' and n > 57:
+            close(x2, xt.cpu().numpy(), tol=2e-5)
+        else:
+            assert torch.equal(x2, xt)
     # backward form: src_scale + accumulate, reversed graph
     t_rp, t_cl = O.transpose_csr(rowptr, col)
     g = rs.randn(n, 2 * d).astype(np.float32)

@@ -365,7 +365,7 @@ def test_dropped_models_give_their_memory_back():
             opt.zero_grad()
             loss.backward()
             opt.step()
-        float(loss)
+        float(loss.detach())
         if it.engine is not None:
             it.engine.check_extract()
 
