@@ -96,6 +96,9 @@ def parse():
                          'gist_amd.modules.GCN / nn.CrossEntropyLoss / optim.Adam / sampler.ClusterIter (N = 1 only)')
     ap.add_argument('--no-module-leg', action='store_true',
                     help='skip the module_path leg of the default N = 1 line')
+    ap.add_argument('--no-unplanted-leg', action='store_true',
+                    help='skip the unplanted_graph leg of the default N = 1 line (the same model on the power-law community '
+                         'graph cut by gist_partition_graph, in a child process)')
     ap.add_argument('--no-second-leg', action='store_true',
                     help='N=1: skip re-timing the workload in the other GEMM mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -1107,7 +1110,7 @@ def main():
     if world == 1 and ist_model is None and not module_headline and not args.no_module_leg:
         try:
             ml = ModuleLoop()
-            n_re = max(args.steps // 2, 10)
+            n_re = max(args.steps, 10)      # (as many steps as the headline: a 10-step leg is noise-limited)
             ml.run(max(min(args.warmup, 10), 3))
             fence(collect=True)
             t0 = time.time()
@@ -1147,6 +1150,41 @@ def main():
         except Exception as e:                          # report, never fake
             legs['module_path'] = {'value': None, 'error': repr(e)}
         torch.cuda.empty_cache()
+
+    # ---- N=1: the same model on a graph whose parts are NOT planted (a child process: its own dataset, partition, engine) ----
+    # The headline's batches are 20 planted blocks of 102 / 103 rows: 2045-2046 rows = exactly eight 256-row tiles.  Parts cut
+    # by a partitioner are uneven (every second batch of this graph has a ninth row tile) and now and then two parts of one
+    # community share a batch: the kernels' schedule for those shapes is part of the product (sampler.py:85-93 batches
+    # whatever METIS returns), so its number sits in the same line.
+    if (world == 1 and ist_model is None and not args.no_unplanted_leg and args.dataset == 'reddit-synth'
+            and args.partition == 'planted' and args.host_path == 'engine'):
+        import subprocess
+        n_un = max(args.steps // 2, 50)
+        cmd = [sys.executable, os.path.abspath(__file__), '--dataset', 'reddit-communities', '--steps', str(n_un),
+               '--warmup', str(max(min(args.warmup, 10), 3)), '--n-hidden', str(H), '--n-layers', str(L),
+               '--dropout', str(args.dropout), '--gemm-mode', args.gemm_mode, '--batch-parts', str(batch_size),
+               '--no-second-leg', '--no-module-leg', '--no-cpu-baseline', '--no-unplanted-leg']
+        for kv in args.tune:
+            cmd += ['--tune', kv]
+        try:
+            torch.cuda.synchronize()
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                timeout=float(os.environ.get('GIST_BENCH_UNPLANTED_TIMEOUT_S', '600')))
+            line = [l for l in cp.stdout.splitlines() if l.startswith('{"metric"')]
+            if cp.returncode != 0 or not line:
+                raise RuntimeError('child exited %d: %s' % (cp.returncode, cp.stderr[-400:]))
+            cu = json.loads(line[-1])
+            legs['unplanted_graph'] = {
+                'value': cu['value'], 'unit': 'epochs/s', 'ms_per_step': cu['ms_per_step'], 'steps': cu['steps'],
+                'vs_planted_ms_per_step': round(cu['ms_per_step'] / (elapsed / args.steps * 1e3), 4),
+                'workload': cu['config']['workload'], 'partition': cu.get('partition'),
+                'roofline': cu.get('roofline'), 'roofline_spmm': cu.get('roofline_spmm'),
+                'batch_rows': cu.get('batch_rows'),
+                'note': 'a child process of this run, after the headline: same model, GEMM mode and step count rule on '
+                        'the Reddit-sized power-law community graph, parts from gist_partition_graph (99-106 rows, '
+                        'every second batch has more than 2048 rows); not `value`'}
+        except Exception as e:                          # report, never fake
+            legs['unplanted_graph'] = {'value': None, 'error': repr(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -1292,6 +1330,10 @@ def main():
                 'mean_batch_rows': round(float(np.mean(n_log)), 1),
                 'mean_batch_nnz': round(float(nnz.mean()), 1),
             }
+        if n_log:
+            nl = np.asarray(n_log)
+            out['batch_rows'] = {'min': int(nl.min()), 'mean': round(float(nl.mean()), 1), 'max': int(nl.max()),
+                                 'share_over_2048': round(float((nl > 2048).mean()), 3)}
         if partition_info is not None or os.environ.get('GIST_BENCH_BATCH_STATS'):
             # what the aggregation kernels see: of a batch row's in-batch neighbours, the share inside the row's own part
             # (the diagonal blocks) and the rows with more than 8 neighbours in the batch's OTHER parts (the block-dense
