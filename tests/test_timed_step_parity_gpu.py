@@ -74,7 +74,8 @@ def _adam64(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     return p - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
 
 
-def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefetch=False, module=False):
+def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefetch=False, module=False, first_parts=None,
+         expect=None):
     """module=True: the step is issued by the reference's loop body on the drop-in classes (GCN.forward,
     nn.CrossEntropyLoss, loss.backward(), optim.Adam.step(): gist_amd/module_engine.py) instead of
     SageEngine.train_step -- same plan, three phase calls."""
@@ -91,6 +92,10 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
         it = (ClusterIter if module else EngineClusterIter)(
             ds.name, g, len(ds.par_li), batch_parts, np.arange(g.number_of_nodes(), dtype=np.int64),
             par_li=[p.copy() for p in ds.par_li], device=DEV)
+        if first_parts is not None:      # these parts of ds.par_li lead the first epoch's (shuffled) order
+            lead = {int(ds.par_li[i][0]) for i in first_parts}
+            it.par_li = ([p for i in first_parts for p in it.par_li if int(p[0]) == int(ds.par_li[i][0])] +
+                         [p for p in it.par_li if int(p[0]) not in lead])
         F_, C_ = g.ndata['feat'].shape[1], ds.num_classes
         dims = dims_for(F_, hidden, C_, n_layers)
         me = model = optimizer = loss_f = None
@@ -154,6 +159,8 @@ def _run(ds, batch_parts, hidden, n_layers, n_steps, seed, mode='bf16x3', prefet
                 n = batch.n
                 logits = eng.logits(n).cpu().numpy()
                 rowptr_now = batch.rowptr
+            if expect is not None:
+                expect(j, n, bool(getattr(batch, 'siblings', False)))
             # the masks of this step, rebuilt on the host
             masks, o_ = [], off
             for (i, o) in dims:
@@ -306,6 +313,44 @@ def test_unplanted_partition_timed_step_dropout_teacher_forced():
     ds = ds._replace(par_li=[order[bounds[i]:bounds[i + 1]].astype(np.int64) for i in range(k)])
     rep = _run(ds, 20, 512, 2, 3, seed=5, prefetch=True)
     assert len(rep) == 3
+
+
+@pytest.mark.parametrize('hidden', [2048, 4096])
+def test_unplanted_batches_over_2048_rows_with_sibling_parts_teacher_forced(hidden):
+    """What the planted model never shows, at the widths that take the kept-split bf16x3 projections and the block-dense
+    matrix-core aggregation: batches of 2049-2150 rows (a NINTH 256-row tile: the projections' tail units, gemm_b3.hip) that
+    hold two parts of one community (their off-diagonal blocks as dense pairs, spmm_mfma.hip) -- the power-law community
+    graph cut by gist_partition_graph into parts of ~104, the first batches led by sibling parts -- through the timed
+    step, dropout 0.2, teacher-forced against the oracle."""
+    from gist_amd import datasets
+    from gist_amd.dgl_compat.transform import partition_assignment
+    ds = datasets.community_dataset('communities', 30000, 602, 41, seed=3)
+    k = 288
+    assign = partition_assignment(ds.g, k, seed=0)
+    order = np.argsort(assign, kind='stable')
+    bounds = np.searchsorted(assign[order], np.arange(k + 1))
+    ds = ds._replace(par_li=[order[bounds[i]:bounds[i + 1]].astype(np.int64) for i in range(k)])
+    # sibling parts: pairs joined by >= 256 edges in one direction (the prepare kernel's threshold)
+    rp, col = ds.g.rowptr.numpy().astype(np.int64), ds.g.col.numpy().astype(np.int64)
+    rows = np.repeat(np.arange(ds.g.number_of_nodes()), np.diff(rp))
+    pr, pc = assign[rows].astype(np.int64), assign[col].astype(np.int64)
+    keys, cnt = np.unique(pr[pr != pc] * k + pc[pr != pc], return_counts=True)
+    sib = [(int(q // k), int(q % k)) for q in keys[cnt >= 256]]
+    assert len(sib) >= 3, 'test data: the partition splits no community across two parts'
+    lead, used = [], set()
+    for (a, b) in sib:                       # three disjoint pairs, one for each of the first three batches
+        if a not in used and b not in used and len(lead) < 3:
+            lead.append((a, b))
+            used.update((a, b))
+    rest = [i for i in range(k) if i not in used]
+    first = []
+    for j, (a, b) in enumerate(lead):
+        first += [a, b] + rest[18 * j:18 * (j + 1)]
+    seen = []
+    rep = _run(ds, 20, hidden, 2, 3, seed=5, first_parts=first, expect=lambda j, n, s_: seen.append((n, s_)))
+    assert len(rep) == 3
+    assert all(s_ for _, s_ in seen), seen                       # the host knew: every one of these batches has sibling parts
+    assert any(2049 <= n <= 2150 for n, _ in seen), seen         # a ninth row tile
 
 
 def test_config3_per_rank_width_with_prefetched_batches():
