@@ -1043,6 +1043,40 @@ def main():
     elapsed = max(per_rank_s)                                   # MAX over ranks
     loss_first, loss_last = (float(loss_log[0].item()), float(loss_log[-1].item()))
 
+    # ---- the launch floor: how many kernels a step issues, and what as many EMPTY kernels cost on this box ------------
+    # (a narrow-width step is launch-bound: 14-27 kernels of 5-50 us; the chain of empty launches is the time below which
+    # no arrangement of the same number of kernels can go -- reported in the same line as the step it bounds)
+    launch_floor = None
+    if native and rank == 0:
+        try:
+            Lc = hip._lib.load()
+            c0 = int(Lc.gist_launch_count())
+            run_steps(8)
+            fence()
+            per_step = (int(Lc.gist_launch_count()) - c0) / 8.0
+            n_l = int(round(per_step))
+            strm = torch.cuda.current_stream(dev).cuda_stream
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps_ = 200
+            for _ in range(20):
+                Lc.gist_empty_launches(n_l, 256, 256, strm)
+            torch.cuda.synchronize(dev)
+            e0_.record()
+            for _ in range(reps_):
+                Lc.gist_empty_launches(n_l, 256, 256, strm)
+            e1_.record()
+            torch.cuda.synchronize(dev)
+            chain_us = e0_.elapsed_time(e1_) / reps_ * 1e3
+            launch_floor = {'launches_per_step': round(per_step, 2), 'empty_chain_us': round(chain_us, 2),
+                            'us_per_empty_launch': round(chain_us / max(n_l, 1), 3),
+                            'share_of_step': round(chain_us / (elapsed / args.steps * 1e6), 4),
+                            'note': 'gist_empty_launches: %d back-to-back launches of a kernel that does nothing (256 x 256 '
+                                    'threads), the step\'s own launch count (gist_launch_count over 8 steps), HIP events on '
+                                    'the step\'s stream, mean of %d chains' % (n_l, reps_)}
+            engine.check_extract()
+        except Exception as e:                          # report, never fake
+            launch_floor = {'error': repr(e)}
+
     # ---- weight exchange, measured on its own (outside the timed region) ----------------------
     sync_info = None
     if ist_model is not None:
@@ -1356,6 +1390,8 @@ def main():
             out['batch_locality'] = batch_stats
         if partition_info is not None:
             out['partition'] = partition_info
+        if launch_floor is not None:
+            out['launch_floor'] = launch_floor
         out.update(legs)
         if world == 1 and not args.no_cpu_baseline:
             try:

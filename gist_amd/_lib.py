@@ -46,6 +46,8 @@ SIGNATURES = {
     'gist_gemm_get_mode': (_int, []),
     'gist_tuning_set': (_int, [_int, ctypes.c_double]),
     'gist_tuning_get': (ctypes.c_double, [_int]),
+    'gist_launch_count': (ctypes.c_uint64, []),
+    'gist_empty_launches': (_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p]),
     'gist_gemm_nt_f32': (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_gemm_nn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     'gist_gemm_tn_f32': (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _p]),

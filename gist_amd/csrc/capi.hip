@@ -11,6 +11,8 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+std::atomic<uint64_t> g_launches{0};
+__global__ void empty_kernel() {}
 static std::atomic<double> g_tune[GIST_TUNE_COUNT];
 double tune(int knob) { return g_tune[knob].load(std::memory_order_relaxed); }
 }  // namespace gist
@@ -23,6 +25,19 @@ extern "C" int gist_tuning_set(int knob, double value) {
 }
 extern "C" double gist_tuning_get(int knob) {
     return knob >= 0 && knob < GIST_TUNE_COUNT ? gist::tune(knob) : -1.0;
+}
+
+extern "C" uint64_t gist_launch_count(void) { return gist::g_launches.load(std::memory_order_relaxed); }
+extern "C" int gist_empty_launches(int32_t n, int32_t grid, int32_t block, gist_stream_t stream) {
+    GIST_REQUIRE(n >= 0 && grid >= 1 && block >= 1 && block <= 1024, "gist_empty_launches: bad arguments");
+    for (int32_t i = 0; i < n; ++i)
+        hipLaunchKernelGGL(gist::empty_kernel, dim3((unsigned)grid), dim3((unsigned)block), 0, gist::as_stream(stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gist::set_error("gist_empty_launches: %s", hipGetErrorString(e));
+        return GIST_ELAUNCH;
+    }
+    return GIST_OK;
 }
 
 extern "C" const char *gist_last_error(void) { return gist::g_err; }

@@ -17,8 +17,13 @@ void set_error(const char *fmt, ...);
 
 static inline hipStream_t as_stream(gist_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Kernel launches issued by this process through the library (gist_launch_count): a measurement aid -- the launch count
+// of a step, next to the cost of as many EMPTY launches (gist_empty_launches), is the floor of a launch-bound step.
+extern std::atomic<uint64_t> g_launches;
+
 // Checks the launch itself (not completion): calls stay asynchronous.
 static inline int launch_status(const char *what) {
+    g_launches.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));

@@ -298,6 +298,12 @@ int gist_gemm_get_mode(void);
 int gist_tuning_set(int knob, double value);
 double gist_tuning_get(int knob);
 
+/* Measurement aids.  gist_launch_count: kernel launches this process has issued through the library so far (a step's
+ * launch count = the difference across it).  gist_empty_launches: n launches of a kernel that does nothing (grid x block
+ * threads) on `stream` -- timed by the caller, the floor of a launch-bound sequence of n kernels on this box. */
+uint64_t gist_launch_count(void);
+int gist_empty_launches(int32_t n, int32_t grid, int32_t block, gist_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Row-wise epilogues of one ISTSAGELayer
  * ------------------------------------------------------------------------- */
