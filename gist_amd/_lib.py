@@ -93,6 +93,7 @@ SIGNATURES = {
                                             _p, _i64, _p, _p, _i64, _p, _i64, _int, _p]),
     'gist_spmm_lnb_units': (_i64, [_i64]),
     'gist_spmm_block_image_bytes': (_i64, []),
+    'gist_spmm_pair_min_edges': (ctypes.c_int32, []),
     'gist_spmm_block_units_f32': (_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),
     'gist_spmm_block_chains_f32': (_int, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _int, _p]),
     'gist_spmm_prepared_useful': (_int, [_i64, _i64, _i64, _p, _p]),

@@ -85,7 +85,13 @@ static_assert(MF_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
 // edges are in no per-row list.
 constexpr int MF_PAIRS = 2;
 constexpr int MF_IMG_BYTES = 16 * MF_ROWS * 16;                  // one count image
-constexpr int MF_PAIR_MIN = 256;                                 // edges into the other block
+#ifndef MF_PAIR_MIN_N      // (dev A/B: unplanted H = 4096 step, aggregation launch average: 256 49.9 us, 128 50.0, 48 53.0)
+#define MF_PAIR_MIN_N 256
+#endif
+constexpr int MF_PAIR_MIN = MF_PAIR_MIN_N;                       // edges into the other block (gist_spmm_pair_min_edges)
+#ifndef MF_FINE_TILES      // column tiles per workgroup of a block with pairs (dev A/B: 2 tiles 53.5 us against 50.0)
+#define MF_FINE_TILES 1
+#endif
 constexpr int MF_PAIR_BLOCKS = 256;                              // batches of up to this many blocks look for pairs
 // (prepare kernel only, in the idle X^T region: the pair images, the outside-edge histogram, the row blocks)
 constexpr int MF_PHIST_OFF = MF_PAIRS * MF_IMG_BYTES;
@@ -210,9 +216,16 @@ __device__ __forceinline__ void mf_gather_row_outside(const MfArgs &a, int e0, i
 
 #ifdef MF_PROBE      // dev build (scripts/spmm_mf_phases.py): s_memrealtime (100 MHz) stamps of workgroup 0, wave 0
 __device__ unsigned long long g_mf_probe[64];
+#ifdef MF_PROBE_PAIRS   // ... of the first workgroup of the blocks-with-pairs class instead (block 0 must have a pair)
+#define MF_STAMP_B(i) do { } while (0)
+#define MF_STAMP(i) do { if (PAIRK && bid == 0 && threadIdx.x == 0) g_mf_probe[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
 #define MF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mf_probe[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MF_STAMP_B(i) MF_STAMP(i)
+#endif
 #else
 #define MF_STAMP(i) do { } while (0)
+#define MF_STAMP_B(i) do { } while (0)
 #endif
 
 // Edge counts of block [r0, r0 + nloc) as bf16 in `ab`, [k chunk][row][8 k], and per row its neighbours
@@ -262,7 +275,7 @@ __device__ __forceinline__ void mf_build_block(const MfArgs &a, int rbk, int r0,
         }
     }
     mf_barrier();
-    MF_STAMP(1);
+    MF_STAMP_B(1);
     if constexpr (PAIRS) {
         // outside edges per other block of the batch (the block of a source row by binary search in the row blocks)
         const int E0 = rp[0], E1 = rp[nloc];
@@ -366,7 +379,7 @@ __device__ __forceinline__ void mf_build_block(const MfArgs &a, int rbk, int r0,
         }
     }
     mf_barrier();
-    MF_STAMP(2);
+    MF_STAMP_B(2);
     // outside neighbours of a row back into CSR order (the slots were taken in arrival order); a row
     // with more than fit is gathered in full below
     if (tid < nloc) {
@@ -966,7 +979,7 @@ template <int DROP>
 __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_pairs_kernel(MfArgs a, int grid_main) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
     if ((int)blockIdx.x < grid_main) mf_body<true, DROP, false>(a, mf_smem, (int)blockIdx.x, a.groups);
-    else mf_body<true, DROP, true>(a, mf_smem, (int)blockIdx.x - grid_main, a.n_col_tiles);
+    else mf_body<true, DROP, true>(a, mf_smem, (int)blockIdx.x - grid_main, (a.n_col_tiles + MF_FINE_TILES - 1) / MF_FINE_TILES);
 }
 
 // One workgroup per block: its counts image and outside-neighbour lists -> memory, for every aggregation
@@ -1093,7 +1106,7 @@ int launch_spmm_mfma(const int32_t *rowptr, const int32_t *col, const float *x, 
     hipLaunchKernelGGL((spmm_csr_mfma_kernel<P, D>), dim3((unsigned)grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a)
     if (prepared && a.pairs) {
         // + the blocks with pairs, one workgroup per (block, column tile), behind the others in the same grid
-        const int64_t grid_p = kXcds * ceil_div(nb * a.n_col_tiles, kXcds);
+        const int64_t grid_p = kXcds * ceil_div(nb * ((a.n_col_tiles + MF_FINE_TILES - 1) / MF_FINE_TILES), kXcds);
         if (grid + grid_p > 0x7fffffffLL) { set_error("gist_spmm_csr_blocked_f32: grid too large"); return GIST_EINVAL; }
         if (mode == 1)
             hipLaunchKernelGGL((spmm_csr_mfma_pairs_kernel<1>), dim3((unsigned)(grid + grid_p)), dim3(MF_THREADS), MF_LDS_BYTES,
@@ -1358,6 +1371,7 @@ int launch_spmm_mfma_chains(const int32_t *chain_ptr, int64_t n_chains, const in
 }  // namespace gist
 
 extern "C" int64_t gist_spmm_block_image_bytes(void) { return gist::MF_PREP_STRIDE; }
+extern "C" int32_t gist_spmm_pair_min_edges(void) { return gist::MF_PAIR_MIN; }
 
 extern "C" int gist_spmm_block_chains_f32(const int32_t *chain_ptr, int64_t n_chains, const int32_t *units, const void *images,
                                           const float *x, int64_t ldx, float *y, int64_t ldy, int64_t n_rows_y, int64_t d,

@@ -257,12 +257,12 @@ class ClusterIter(object):
             intra = int((pr == pc).sum().item())
             # Sibling parts: pairs of parts joined by hundreds of edges (one community cut in two).  A batch that holds
             # both is prepared with their off-diagonal blocks as dense pairs (gist_step_plan.sibling_parts); which batches
-            # those are is known from this table alone, on the host, once per epoch.  (Threshold = the prepare kernel's
-            # MF_PAIR_MIN; a pair listed here that the kernel does not take costs one empty launch, nothing else.)
+            # those are is known from this table alone, on the host, once per epoch.  (Threshold = the prepare kernel's,
+            # gist_spmm_pair_min_edges; a pair listed here that the kernel does not take costs a few empty workgroups.)
             cross = pr != pc
             K = np.int64(len(self.par_li) + 1)
             keys, cnt = torch.unique(pr[cross].to(torch.int64) * int(K) + pc[cross].to(torch.int64), return_counts=True)
-            keys = keys[cnt >= 256].cpu().numpy()
+            keys = keys[cnt >= int(hip._lib.load().gist_spmm_pair_min_edges())].cpu().numpy()
             self._sibling_keys = np.unique(np.concatenate([keys, (keys % K) * K + keys // K]))      # either direction
             del rows, pr, pc, cross
             nnz = tg.number_of_edges()

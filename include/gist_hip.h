@@ -163,6 +163,10 @@ int gist_spmm_prepared_useful(int64_t d, int64_t ldx, int64_t ldy, const float *
  * pair of every row block together, j = 0, 1, ...  0.7 us of chip time per unit at D = 4096 (an fp32-MFMA form with
  * operands from memory was measured at 1.7 us per pair and removed: profiles/NEGATIVES.md). */
 int64_t gist_spmm_block_image_bytes(void);
+/* Edges from one block's rows into another block of the batch from which gist_spmm_blocks_prepare treats the two as a
+ * pair (their off-diagonal block multiplied like a diagonal one): what a caller compares its part-to-part edge counts
+ * with to set gist_step_plan.sibling_parts.  Host function. */
+int32_t gist_spmm_pair_min_edges(void);
 int gist_spmm_block_units_f32(const int32_t *units, int64_t n_units, const void *images, const float *x, int64_t ldx,
                               float *y, int64_t ldy, int64_t n_rows_y, int64_t d, const float *out_scale,
                               int accumulate, gist_stream_t stream);

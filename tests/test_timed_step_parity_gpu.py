@@ -330,12 +330,13 @@ def test_unplanted_batches_over_2048_rows_with_sibling_parts_teacher_forced(hidd
     order = np.argsort(assign, kind='stable')
     bounds = np.searchsorted(assign[order], np.arange(k + 1))
     ds = ds._replace(par_li=[order[bounds[i]:bounds[i + 1]].astype(np.int64) for i in range(k)])
-    # sibling parts: pairs joined by >= 256 edges in one direction (the prepare kernel's threshold)
+    # sibling parts: pairs joined by at least gist_spmm_pair_min_edges() edges in one direction (the prepare kernel's threshold)
     rp, col = ds.g.rowptr.numpy().astype(np.int64), ds.g.col.numpy().astype(np.int64)
     rows = np.repeat(np.arange(ds.g.number_of_nodes()), np.diff(rp))
     pr, pc = assign[rows].astype(np.int64), assign[col].astype(np.int64)
     keys, cnt = np.unique(pr[pr != pc] * k + pc[pr != pc], return_counts=True)
-    sib = [(int(q // k), int(q % k)) for q in keys[cnt >= 256]]
+    from gist_amd import _lib
+    sib = [(int(q // k), int(q % k)) for q in keys[cnt >= int(_lib.load().gist_spmm_pair_min_edges())]]
     assert len(sib) >= 3, 'test data: the partition splits no community across two parts'
     lead, used = [], set()
     for (a, b) in sib:                       # three disjoint pairs, one for each of the first three batches
