@@ -132,6 +132,9 @@ class GCN(nn.Module):
             layer.drop_seed = int(seed) * 1000003 + k
 
     def forward(self, g):
+        """cluster_gcn/modules.py:310-314.  The returned logits are the caller's own tensor, as in torch: on the fused
+        path they come from a small ring of buffers, and a buffer the caller still holds (the tensor or a view of it) is
+        never handed out again (gist_amd/module_engine.py); evaluation-mode logits are freshly allocated."""
         # A cluster batch from ClusterIter: the whole forward is ONE dispatcher op on the preallocated step plan
         # (gist_amd/module_engine.py); anything else -- the full graph of an evaluation, a hand-built graph -- runs
         # layer by layer below
