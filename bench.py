@@ -1047,7 +1047,7 @@ def main():
     # (a narrow-width step is launch-bound: 14-27 kernels of 5-50 us; the chain of empty launches is the time below which
     # no arrangement of the same number of kernels can go -- reported in the same line as the step it bounds)
     launch_floor = None
-    if native and rank == 0:
+    if native and world == 1:      # (N > 1: extra steps on one rank would enter a weight exchange alone)
         try:
             Lc = hip._lib.load()
             c0 = int(Lc.gist_launch_count())
