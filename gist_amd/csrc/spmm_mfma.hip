@@ -85,8 +85,8 @@ static_assert(MF_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
 // edges are in no per-row list.
 constexpr int MF_PAIRS = 2;
 constexpr int MF_IMG_BYTES = 16 * MF_ROWS * 16;                  // one count image
-#ifndef MF_PAIR_MIN_N      // (dev A/B: unplanted H = 4096 step, aggregation launch average: 256 49.9 us, 128 50.0, 48 53.0)
-#define MF_PAIR_MIN_N 256
+#ifndef MF_PAIR_MIN_N      // (dev A/B: unplanted H = 4096 step, aggregation launch average: 256 49.9 us, 128 50.0, 48 53.0; 128 for the tail: fewer 70-136-us launches)
+#define MF_PAIR_MIN_N 128
 #endif
 constexpr int MF_PAIR_MIN = MF_PAIR_MIN_N;                       // edges into the other block (gist_spmm_pair_min_edges)
 #ifndef MF_FINE_TILES      // column tiles per workgroup of a block with pairs (dev A/B: 2 tiles 53.5 us against 50.0)
