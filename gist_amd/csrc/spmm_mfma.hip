@@ -180,15 +180,17 @@ __device__ __forceinline__ void mf_gather_row(const MfArgs &a, int e0, int e1, i
 
 // the neighbours of one row OUTSIDE the block [r0, r0 + nloc) and its pairs' source rows, CSR order (a row whose outside
 // neighbours do not fit the per-row list: its in-block and in-pair edges stay in the dense products)
+template <bool PP>
 __device__ __forceinline__ void mf_gather_row_outside(const MfArgs &a, int e0, int e1, int r0, int nloc, int4 pairs,
                                                       int lane, int gc, bool mine, float4 &v) {
     for (int base = e0; base < e1; base += 64) {
         const bool in = base + lane < e1;
         const int ids = in ? a.col[base + lane] : 0;
         // (unsigned compares: inside [s, s + n) <=> (unsigned)(id - s) < n; an absent pair has n = 0)
-        unsigned long long m = __ballot(in && (unsigned)(ids - r0) >= (unsigned)nloc &&
-                                        (unsigned)(ids - pairs.x) >= (unsigned)pairs.y &&
-                                        (unsigned)(ids - pairs.z) >= (unsigned)pairs.w);
+        unsigned long long m = PP ? __ballot(in && (unsigned)(ids - r0) >= (unsigned)nloc &&
+                                             (unsigned)(ids - pairs.x) >= (unsigned)pairs.y &&
+                                             (unsigned)(ids - pairs.z) >= (unsigned)pairs.w)
+                                  : __ballot(in && (ids < r0 || ids >= r0 + nloc));
         while (m) {                                        // four row reads in flight, lowest lanes (= edge order) first
             float4 rv[4];
             float rs[4];
@@ -459,7 +461,10 @@ __device__ __forceinline__ void mf_build_block(const MfArgs &a, int rbk, int r0,
 // units cost registers this code does not have (128 at 1024 threads): in one kernel, even behind a branch that is never
 // taken, they moved the register allocation of the common path -- 49 us per D = 4096 launch on a batch WITHOUT pairs
 // against 36 (88 spilled registers against 3).
-template <bool PREP, int DROP, bool PAIRK>
+// PP = false (spmm_csr_mfma_kernel: structures prepared WITHOUT pairs, or not prepared): no pair descriptor is read, no
+// rem_cnt carries bit 8, the edge-list walk knows no pair ranges -- the code every batch without sibling parts runs is the
+// code it ran before pairs existed (this kernel answers epilogue edits with another register allocation: NEGATIVES.md).
+template <bool PREP, int DROP, bool PAIRK, bool PP>
 __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem, int bid, int groups) {
     MF_STAMP(0);
     // ---- workgroup -> (block, column group); the groups of one block stay on one XCD ----
@@ -471,7 +476,7 @@ __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem,
     const int rbk = unit / groups;
     // the block's pairs (prepared batches only): (first source row, source rows) x 2, uniform
     int4 pin = make_int4(0, 0, 0, 0);
-    if constexpr (PREP) {
+    if constexpr (PREP && PP) {
         if (a.pairs && a.units == nullptr && a.row_blocks != nullptr && a.n_blocks <= MF_PAIR_BLOCKS) {
             const int4 t = *reinterpret_cast<const int4 *>(a.prep + (int64_t)rbk * MF_PREP_STRIDE + MF_PREP_PINFO);
             pin = make_int4(__builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(min(t.y, MF_ROWS)),
@@ -711,7 +716,7 @@ __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem,
         for (int i = 0; i < RW; ++i) {
             const int r = wave + MF_WAVES * i;
             const int rc = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
-            rcnt[i] = rc >= 0 ? (rc & 0xff) : rc;
+            rcnt[i] = (PP && rc >= 0) ? (rc & 0xff) : rc;
         }
 #pragma unroll
         for (int pp = 0; pp < RW / 2; ++pp) rsc[pp] = sc[min(wave + MF_WAVES * (2 * pp + half), MF_ROWS - 1)];
@@ -744,7 +749,7 @@ __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem,
                     const int ids = lane < MF_REM ? rem_col[r * MF_REM + lane] : 0;
                     mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, rcnt[i], v[pp]);
                 } else if (rcnt[i] == -2) {
-                    mf_gather_row_outside(a, rp[r], rp[r + 1], r0, nloc, pin, lane, gc, mine, v[pp]);
+                    mf_gather_row_outside<PP>(a, rp[r], rp[r + 1], r0, nloc, pin, lane, gc, mine, v[pp]);
                 } else {
                     if (mine) v[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
                     mf_gather_row(a, rp[r], rp[r + 1], lane, gc, mine, v[pp]);
@@ -890,7 +895,7 @@ __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem,
         for (int i = 0; i < RW; ++i) {
             const int r = wave + MF_WAVES * i;
             const int rc = r < nloc ? __builtin_amdgcn_readfirstlane(rem_cnt[r]) : 0;
-            rcnt[i] = rc >= 0 ? (rc & 0xff) : rc;
+            rcnt[i] = (PP && rc >= 0) ? (rc & 0xff) : rc;
         }
 #pragma unroll
         for (int pp = 0; pp < RW / 2; ++pp) rsc[pp] = sc[min(wave + MF_WAVES * (2 * pp + half), MF_ROWS - 1)];
@@ -923,7 +928,7 @@ __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem,
                     const int ids = lane < MF_REM ? rem_col[r * MF_REM + lane] : 0;
                     mf_gather(a.x, a.ldx, a.src_scale, gc, mine, ids, rcnt[i], v[pp]);
                 } else if (rcnt[i] == -2) {
-                    mf_gather_row_outside(a, rp[r], rp[r + 1], r0, nloc, pin, lane, gc, mine, v[pp]);
+                    mf_gather_row_outside<PP>(a, rp[r], rp[r + 1], r0, nloc, pin, lane, gc, mine, v[pp]);
                 } else {
                     if (mine) v[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
                     mf_gather_row(a, rp[r], rp[r + 1], lane, gc, mine, v[pp]);
@@ -969,7 +974,7 @@ __device__ __forceinline__ void mf_body(const MfArgs &a, unsigned char *mf_smem,
 template <bool PREP, int DROP = 0>
 __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
-    mf_body<PREP, DROP, false>(a, mf_smem, (int)blockIdx.x, a.groups);
+    mf_body<PREP, DROP, false, false>(a, mf_smem, (int)blockIdx.x, a.groups);
 }
 // Prepared structure WITH pairs: ONE launch whose first grid_main workgroups are spmm_csr_mfma_kernel's (a block with
 // pairs: exit) and whose others take the blocks with pairs, one workgroup per (block, column tile) -- they start on the
@@ -978,8 +983,8 @@ __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_kernel(MfArgs a) {
 template <int DROP>
 __global__ __launch_bounds__(MF_THREADS) void spmm_csr_mfma_pairs_kernel(MfArgs a, int grid_main) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
-    if ((int)blockIdx.x < grid_main) mf_body<true, DROP, false>(a, mf_smem, (int)blockIdx.x, a.groups);
-    else mf_body<true, DROP, true>(a, mf_smem, (int)blockIdx.x - grid_main, (a.n_col_tiles + MF_FINE_TILES - 1) / MF_FINE_TILES);
+    if ((int)blockIdx.x < grid_main) mf_body<true, DROP, false, true>(a, mf_smem, (int)blockIdx.x, a.groups);
+    else mf_body<true, DROP, true, true>(a, mf_smem, (int)blockIdx.x - grid_main, (a.n_col_tiles + MF_FINE_TILES - 1) / MF_FINE_TILES);
 }
 
 // One workgroup per block: its counts image and outside-neighbour lists -> memory, for every aggregation
