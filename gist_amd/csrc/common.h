@@ -103,7 +103,7 @@ int b3_gemm_presplit(const char *name, const uint16_t *sa, const uint16_t *sb, c
 int gemm_slabs(int layout, const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, float *c,
                int64_t ldc, int64_t m, int64_t n, int64_t k, void *slabs, int64_t slab_bytes, int *n_slabs,
                hipStream_t st);
-int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k);
+int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k, bool tn = false);      // tn: a weight gradient (A and B k-major)
 // gemm.hip: dz = dy . w (NN) and dW = dy^T . z (TN, slabs) in one launch of the fp32 kernel's tiles
 bool gemm_dual_takes(int64_t m, int64_t n1, int64_t k1, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddz,
                      const float *dy, const float *w, const float *z, const float *dz);

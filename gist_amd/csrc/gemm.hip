@@ -650,7 +650,7 @@ int64_t b3_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda, const float *b,
              int64_t ldb, const float *bias, float *c, int64_t ldc, int64_t m, int64_t n, int64_t k,
              void *ws, int64_t ws_bytes, hipStream_t st, int *deferred);
-int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k);      // -1: shape not taken
+int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k, bool tail = true);      // -1: shape not taken
 
 // deferred: the k slices are summed by the kernel that consumes the result (gist_gemm_slabs_f32) -- no reduce
 // launch, only the slabs' write and read.
@@ -855,11 +855,11 @@ void gemm_f32_choice(int64_t m, int64_t n, int64_t k, int *tile, int *splits) {
 
 // slab bytes of the split-K choice for this shape on the fp32 kernel or the convert-on-load bf16x3 kernel,
 // whichever is larger (0: one k slice)
-int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k) {
+int64_t gemm_f32_slab_bytes(int64_t m, int64_t n, int64_t k, bool tn) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const int sp = choose_cfg(m, n, k, true).splits;      // (sized for the deferred form: what these slabs are for)
     const int64_t f32 = sp > 1 ? (int64_t)sp * m * n * 4 : 0;
-    const int64_t c3 = b3c_slab_bytes(m, n, k);
+    const int64_t c3 = b3c_slab_bytes(m, n, k, !tn);
     return c3 > f32 ? c3 : f32;
 }
 

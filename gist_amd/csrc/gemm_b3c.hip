@@ -22,6 +22,7 @@
 // chunk kg (k = 8 kg .. 8 kg + 7) of row r sits at position kg ^ ((r >> 1) & 3) of its row, so the eight
 // lanes of a ds_read_b128 group (rows r .. r + 7, one kg) hit eight different 16-byte slots of the
 // 128-byte bank line, and so do the writes of eight consecutive chunks.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -40,6 +41,12 @@ struct C3Args {
     int tiles_m, tiles_n;
     int k_per_split;       // multiple of 32
     int64_t split_stride;  // elements between split slabs (0 = write C directly)
+    // Tail units (one k slice, more tiles than the chip holds at once; as gemm_b3.hip): the first dp_tiles tiles of the
+    // launch order run whole; every other tile is cut into tail_splits k slices of tail_k (a multiple of 32), one
+    // workgroup each (blockIdx.x = dp_tiles + tile * tail_splits + slice), which leave their TM x TN fp32 results
+    // at tail[(tile * tail_splits + slice) * TM * TN]; gemm_b3c_tail_sum_kernel adds them in slice order (+ bias) into C.
+    int dp_tiles, tail_splits, tail_k;
+    float *tail;
 };
 
 constexpr int C3_BK = 32;
@@ -228,10 +235,13 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     constexpr int NI = WM / 16, NJ = WN / 16;                // 16 x 16 MFMA tiles per wave
 
     // ---- block -> output tile, 8 x 8 super-tiles per XCD (as gemm.hip) ----
-    const int nwg = g.tiles_m * g.tiles_n;
+    const int nwg = g.dp_tiles;
     const int orig = blockIdx.x;
+    const bool tailu = orig >= nwg;
+    const int tail_unit = tailu ? orig - nwg : 0;
     const int qd = nwg / kXcds, rm = nwg % kXcds, xcd = orig % kXcds;
-    const int L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
+    const int L = tailu ? nwg + tail_unit / g.tail_splits
+                        : (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + orig / kXcds;
     constexpr int GM = 8;
     const int width = GM * g.tiles_n;
     const int group = L / width;
@@ -240,8 +250,8 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     const int bm = first_m + (L % width) % gsz;
     const int bn = (L % width) / gsz;
     const int row0 = bm * TM, col0 = bn * TN;
-    const int k_begin = blockIdx.z * g.k_per_split;
-    const int k_end = min(g.k, k_begin + g.k_per_split);
+    const int k_begin = tailu ? (tail_unit % g.tail_splits) * g.tail_k : blockIdx.z * g.k_per_split;
+    const int k_end = min(g.k, k_begin + (tailu ? g.tail_k : g.k_per_split));
     const int n_kt = (k_end - k_begin + C3_BK - 1) / C3_BK;
     const int n_full = (k_end - k_begin) / C3_BK;            // tiles that need no mask
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -556,6 +566,17 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
     }
     }      // (the two-set consumer of the 32 x 32 / 64 x 32 wave tiles)
     // ---- epilogue: C/D of 16x16x32: col = lane & 15, row = 4 (lane >> 4) + e ----
+    if (tailu) {      // this slice's tile, dense, for gemm_b3c_tail_sum_kernel
+        float *tb = g.tail + (int64_t)tail_unit * (TM * TN);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    tb[(wm * WM + i * 16 + 4 * kg + e) * TN + wn * WN + j * 16 + rr] = acc[i][j][e];
+        return;
+    }
     float *cbase = g.c + (int64_t)blockIdx.z * g.split_stride;
     const bool add_bias = g.bias != nullptr && g.split_stride == 0;
 #pragma unroll
@@ -570,6 +591,29 @@ __global__ __launch_bounds__(512, 1) void gemm_b3c_kernel(C3Args g) {
                 const int row = row0 + wm * WM + i * 16 + 4 * kg + e;
                 if (row < g.m) cbase[(int64_t)row * g.ldc + col] = acc[i][j][e] + bv;
             }
+    }
+}
+
+// C tile = sum over its k slices of the tail units' results, in slice order (+ bias).  Grid (tail tile, TM * TN / 1024).
+__global__ __launch_bounds__(256) void gemm_b3c_tail_sum_kernel(C3Args g, int tm, int tn) {
+    const int L = g.dp_tiles + (int)blockIdx.x;
+    constexpr int GM = 8;
+    const int width = GM * g.tiles_n, first_m = (L / width) * GM, gsz = min(g.tiles_m - first_m, GM);
+    const int row0 = (first_m + (L % width) % gsz) * tm, col0 = ((L % width) / gsz) * tn;
+    const int e4 = ((int)blockIdx.y * 256 + (int)threadIdx.x) * 4;      // four consecutive columns of one tile row
+    const int r = e4 / tn, c = e4 % tn;
+    if (r >= tm || row0 + r >= g.m) return;
+    const float *src = g.tail + (int64_t)blockIdx.x * g.tail_splits * (tm * tn) + e4;
+    float4 sum = *reinterpret_cast<const float4 *>(src);
+    for (int q = 1; q < g.tail_splits; ++q) {
+        const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)q * (tm * tn));
+        sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+    }
+    const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int col = col0 + c + u;
+        if (col < g.n) g.c[(int64_t)(row0 + r) * g.ldc + col] = v[u] + (g.bias != nullptr ? g.bias[col] : 0.f);
     }
 }
 
@@ -607,9 +651,18 @@ static int b3c_launch(const char *name, C3Args &g, int splits, hipStream_t st) {
     }
     g.tiles_m = (int)ceil_div(g.m, TM);
     g.tiles_n = (int)ceil_div(g.n, TN);
-    hipLaunchKernelGGL((gemm_b3c_kernel<A_KC, B_KC, TM, TN>),
-                       dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), smem, st, g);
-    return launch_status(name);
+    const int tiles = g.tiles_m * g.tiles_n;
+    unsigned grid = (unsigned)tiles;
+    if (g.tail_splits > 1) grid = (unsigned)(g.dp_tiles + (tiles - g.dp_tiles) * g.tail_splits);
+    else g.dp_tiles = tiles;
+    hipLaunchKernelGGL((gemm_b3c_kernel<A_KC, B_KC, TM, TN>), dim3(grid, 1, (unsigned)splits), dim3(512), smem, st, g);
+    int rc = launch_status(name);
+    if (rc == GIST_OK && g.tail_splits > 1) {
+        hipLaunchKernelGGL(gemm_b3c_tail_sum_kernel, dim3((unsigned)(tiles - g.dp_tiles), (unsigned)(TM * TN / 1024)), dim3(256), 0, st,
+                           g, TM, TN);
+        rc = launch_status(name);
+    }
+    return rc;
 }
 
 // Tile and k slices (fp32 slabs, reduced by the call or left to the consumer).  Fitted to scripts/b3c_bench.py.
@@ -639,11 +692,34 @@ static void b3c_choice(int64_t m, int64_t n, int64_t k, int *tm, int *tn, int *s
     *splits = (int)(sp < 1 ? 1 : sp);
 }
 
-int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k) {
+// Tail units (as gemm_b3.hip's): one k slice and T tiles on S workgroup slots (64 x 64 tiles: two workgroups per CU = 512,
+// the larger tiles one = 256) with 0 < T mod S <= S / 2 -- a batch of 2049-2112 rows makes 528 tiles of 64 x 64 out of 512,
+// 272 of 128 x 128 out of 256: a second round for 16 tiles -- cut the tiles of the last round into k slices of >= 4 k tiles.
+struct C3Tail { int dp_tiles, splits, k_per; };
+static C3Tail b3c_tail(int64_t m, int64_t n, int64_t k, int tm, int tn) {
+    const int64_t tiles = ceil_div(m, tm) * ceil_div(n, tn), slots = (tm == 64 && tn == 64) ? 512 : 256;
+    C3Tail t{(int)tiles, 1, 0};
+    if ((int)tune(GIST_TUNE_B3_TAIL) == 1 || tiles <= slots) return t;
+    const int64_t r = tiles % slots, kt = ceil_div(k, C3_BK);
+    if (r == 0 || r > slots / 2) return t;
+    int64_t s = std::min<int64_t>(slots / r, kt / 4);
+    if (s < 2) return t;
+    const int64_t per = ceil_div(kt, s);
+    s = ceil_div(kt, per);
+    if (s < 2) return t;
+    t.dp_tiles = (int)(tiles - r); t.splits = (int)s; t.k_per = (int)(per * C3_BK);
+    return t;
+}
+// (tail = false: a layout this path does not take by default -- TN, the weight gradients: its scratch must not make a
+// slab buffer exist that the caller's routing reads as "this projection's slices are summed by its consumer")
+int64_t b3c_slab_bytes(int64_t m, int64_t n, int64_t k, bool tail) {
     if (!b3c_shape_ok(m, n, k)) return -1;
     int tm, tn, sp;
     b3c_choice(m, n, k, &tm, &tn, &sp);
-    return sp > 1 ? (int64_t)sp * m * n * 4 : 0;
+    if (sp > 1) return (int64_t)sp * m * n * 4;
+    if (!tail) return 0;
+    const C3Tail t = b3c_tail(m, n, k, tm, tn);
+    return t.splits > 1 ? (ceil_div(m, tm) * ceil_div(n, tn) - t.dp_tiles) * (int64_t)t.splits * tm * tn * 4 : 0;
 }
 
 // Returns 1 if the projection was issued here, 0 if this call is not for this path (the caller falls back
@@ -665,6 +741,13 @@ int b3c_gemm(const char *name, bool a_kc, bool b_kc, const float *a, int64_t lda
     splits = (int)ceil_div(k, g.k_per_split);
     g.split_stride = 0;
     if (splits > 1) { g.c = static_cast<float *>(ws); g.ldc = n; g.split_stride = m * n; g.bias = nullptr; }
+    g.dp_tiles = 0; g.tail_splits = 1; g.tail_k = 0; g.tail = nullptr;
+    if (splits == 1 && ws != nullptr && aligned16(ws)) {
+        const C3Tail t = b3c_tail(m, n, k, tm, tn);
+        if (t.splits > 1 && ws_bytes >= (ceil_div(m, tm) * ceil_div(n, tn) - t.dp_tiles) * (int64_t)t.splits * tm * tn * 4) {
+            g.dp_tiles = t.dp_tiles; g.tail_splits = t.splits; g.tail_k = t.k_per; g.tail = static_cast<float *>(ws);
+        }
+    }
     const int64_t slot = timer_begin(tl_timer, 2, m, n, k, st);      // kind 2: a bf16x3 main kernel
     int rc;
 #define C3_GO(AK, BK_)                                                                        \

@@ -277,7 +277,7 @@ int64_t slab_need(int64_t m, int64_t n, int64_t k_max, bool k_is_rows) {
     // every 32 rows down to half the largest batch (the model's slice count is not monotone in the reduction
     // length: two neighbouring batch sizes can differ by a factor of two)
     for (int64_t rows = k_max; rows > 0 && rows >= k_max / 2; rows -= 32) {
-        const int64_t b = k_is_rows ? gemm_f32_slab_bytes(m, n, rows) : gemm_f32_slab_bytes(rows, n, m);
+        const int64_t b = k_is_rows ? gemm_f32_slab_bytes(m, n, rows, true) : gemm_f32_slab_bytes(rows, n, m);
         need = b > need ? b : need;
     }
     if (!tuned) {      // a full table overwrites its oldest entry instead of recomputing every call

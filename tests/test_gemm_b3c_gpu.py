@@ -172,3 +172,47 @@ def test_b3c_tiles_agree_bit_for_bit(hip, form, m, n, k, splits):
     assert torch.isfinite(out[64]).all()
     assert torch.equal(out[64], out[128])
     assert torch.equal(out[64], out[128128])
+
+
+@pytest.mark.parametrize('form,m,n,k', [('nt', 2100, 1024, 2048), ('nt', 2100, 1024, 1204), ('nn', 2100, 2048, 1024),
+                                        ('nt', 2080, 1024, 500), ('nn', 2150, 1032, 1024)])
+def test_b3c_tail_units(hip, form, m, n, k):
+    """More tiles than the chip holds at once, by a few (a batch of 2049-2112 rows: 528 tiles of 64 x 64 on 512 workgroup
+    slots, 272 of 128 x 128 on 256): the tiles of the last round run as k slices summed in slice order by a follow-up
+    launch.  Same result as whole tiles up to the order of the fp32 partial sums, bias once, the same bits on every run,
+    exact on integers, nothing written outside C."""
+    hip.gemm_mode('bf16x3')
+    gen = torch.Generator(device=DEV).manual_seed(m + 5 * n + 11 * k)
+    a, w = _operands(form, m, n, k, gen, 'normal')
+    bias = torch.randn(n, device=DEV, generator=gen) if form == 'nt' else None
+    y_tail = _run(hip, form, a, w, bias, m, n)
+    for _ in range(3):
+        assert torch.equal(_run(hip, form, a, w, bias, m, n), y_tail)
+    hip.tuning('b3_tail', 1)
+    try:
+        y_whole = _run(hip, form, a, w, bias, m, n)
+    finally:
+        hip.tuning('b3_tail', 0)
+    assert torch.isfinite(y_tail).all()
+    assert not torch.equal(y_tail, y_whole), 'not a tail-unit shape (the hook changed nothing)'
+    rows = torch.cat([torch.arange(0, m, max(1, m // 96), device=DEV), torch.arange(m - 70, m, device=DEV)])
+    ref, den = _ref64(form, a, w, rows)
+    if bias is not None:
+        ref = ref + bias.double()
+    e_tail = ((y_tail[rows].double() - ref).abs() / den).max().item()
+    e_whole = ((y_whole[rows].double() - ref).abs() / den).max().item()
+    assert e_tail <= max(1.5 * e_whole, 4e-7), (e_tail, e_whole)
+    assert (y_tail - y_whole).abs().max().item() <= 4e-6 * den.max().item()
+    sa, sb = {'nt': ((m, k), (n, k)), 'nn': ((m, k), (k, n))}[form]
+    ai = torch.randint(-8, 9, sa, device=DEV, generator=gen).float()
+    wi = torch.randint(-8, 9, sb, device=DEV, generator=gen).float()
+    ybuf = torch.full((m + 2, n + 8), 7.0, device=DEV)
+    out = ybuf[:m, 4:4 + n]
+    if form == 'nt':
+        hip.gemm_nt(ai, wi, None, out)
+        exact = ai.double() @ wi.double().t()
+    else:
+        hip.gemm_nn(ai, wi, out)
+        exact = ai.double() @ wi.double()
+    assert torch.equal(out, exact.float())
+    assert (ybuf[m:] == 7.0).all() and (ybuf[:, :4] == 7.0).all() and (ybuf[:, 4 + n:] == 7.0).all()
