@@ -912,8 +912,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_region(steps, with_timer):
-        """Exactly `steps` steps between two fences; returns (elapsed, kernel records, logs)."""
+    def timed_region(steps, with_timer, warmup=0):
+        """`warmup` untimed steps, then exactly `steps` steps between two fences (barrier + synchronize on both sides);
+        returns (elapsed, kernel records, logs).  The host hygiene of a region (a full collection, the 0.12-s wait for a
+        fresh CFS period) comes BEFORE its warm-up steps, not between them and the timed steps: 120 ms of idle GPU in front
+        of the first timed step is a clock ramp inside the region -- 2.69 ms per step over 20 steps against 2.59 over 150
+        (the driver's invocation is 20 steps) for a sleep this script put there itself."""
         sample_timer = None
         if with_timer and native:   # HIP events recorded by the native step driver on the launch stream
             sample_timer = engine.enable_timer((steps // every + 1) * (12 * len(dims) + 4))
@@ -921,6 +925,10 @@ def main():
             hip.profile_begin()
         ids_log, n_log, loss_log = [], [], []
         fence(collect=True)
+        if warmup > 0:
+            run_steps(warmup)
+            del sync_ms[:]             # syncs of the warm-up are not part of the timed region
+            fence()
         t0 = time.time()
         run_steps(steps, sample_timer, ids_log, n_log, loss_log)
         fence()
@@ -1022,11 +1030,9 @@ def main():
         # rank's flat sub-model into the gather buffer), which changes no weight
         ist_model.sync_gather()
         torch.cuda.synchronize(dev)
-    run_steps(args.warmup)
-    del sync_ms[:]                 # syncs of the warm-up are not part of the timed region
     timing = not args.no_kernel_timing
     hc_head0 = host_counters()
-    elapsed_local, prof, timed_ids, n_log, loss_log = timed_region(args.steps, timing)
+    elapsed_local, prof, timed_ids, n_log, loss_log = timed_region(args.steps, timing, warmup=args.warmup)
     hc_head = counter_delta(hc_head0, host_counters())
     head_gaps = np.diff(np.asarray(host_stamps)) * 1e3
     engine.check_extract()         # no batch of the warm-up / timed region was built from a timed-out extraction
@@ -1124,8 +1130,7 @@ def main():
                 continue
             hip.gemm_mode(other)
             n_re = max(args.steps // 3, 10)
-            run_steps(3)
-            e2, prof2, _, _, _ = timed_region(n_re, timing)
+            e2, prof2, _, _, _ = timed_region(n_re, timing, warmup=3)
             leg = {'value': round(n_re / STEPS_PER_EPOCH / e2, 4), 'unit': 'epochs/s',
                    'ms_per_step': round(e2 / n_re * 1e3, 4), 'steps': n_re, 'gemm_mode': other,
                    'dtype': {'f32': 'f32',
@@ -1145,8 +1150,9 @@ def main():
         try:
             ml = ModuleLoop()
             n_re = max(args.steps, 10)      # (as many steps as the headline: a 10-step leg is noise-limited)
-            ml.run(max(min(args.warmup, 10), 3))
             fence(collect=True)
+            ml.run(max(min(args.warmup, 10), 3))
+            fence()
             t0 = time.time()
             stamps = []
             hc0 = host_counters()
