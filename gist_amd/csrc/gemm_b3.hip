@@ -511,8 +511,9 @@ int b3_splits(int64_t m, int64_t n, int64_t k) {
 // tiles and leaves P - r CUs idle for a whole tile's k loop (a batch of 2049-2304 rows has a ninth row
 // tile: 288 tiles = one round + 32, twice the time of 256).  The r tiles of that round are cut into
 // floor(P / r) k slices of >= 8 k tiles, one workgroup each, so the round lasts 1 / slices of a tile;
-// the slices of a tile meet through fp32 partials that the last one to arrive sums in slice order
-// (gemm_b3_kernel).  Nothing here depends on anything but the shape.
+// the slices of a tile leave fp32 partials that gemm_b3_tail_sum_kernel, the next launch, adds in slice
+// order (a hand-over inside the kernel -- the last slice to arrive sums -- was measured first: its
+// device-scope fences cost 45-70 us per launch).  Nothing here depends on anything but the shape.
 struct B3Tail { int dp_tiles, splits, kt; };
 constexpr int B3_CUS = 256;
 static B3Tail b3_tail(int64_t m, int64_t n, int64_t k) {
